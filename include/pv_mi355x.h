@@ -1,0 +1,250 @@
+/*
+ * pv_mi355x.h -- C ABI of the MI355X (gfx950) forward path for PyTorchVideo-style models.
+ *
+ * The reference (facebookresearch/pytorchvideo) has no native code and therefore no FFI
+ * of its own; every FLOP on its hot path is an ATen op called from Python.  The entry
+ * points below are what a reference-side binding (ctypes) binds for
+ * the deploy form of an `EfficientBlockBase` (pytorchvideo/accelerator/efficient_blocks/
+ * efficient_block_base.py:8-35) registered under the target device "mi355x" in
+ * EFFICIENT_BLOCK_TRANSMUTER_REGISTRY (pytorchvideo/accelerator/deployment/common/
+ * model_transmuter.py:16).  Each function cites the reference op graph it replaces.
+ *
+ * Conventions
+ *   - plain pointers (device memory) + sizes in POD descriptors; no torch types.
+ *   - activations are channels-last: voxel (b,t,h,w) of a tensor lives at
+ *         ptr + b*bs + ((t*H + h)*W + w)*ld          (element units)
+ *     and carries `round_up(C,8)` channels, the padding channels being exactly 0.
+ *     Token tensors (B,N,C) are the same thing with T=H=1, W=N.
+ *   - dtype is PV_F32 or PV_BF16 for activations and packed weights; all accumulation,
+ *     BN/bias epilogues, softmax, LayerNorm statistics are fp32.
+ *   - every call is asynchronous on `stream`, never allocates, never synchronises and is
+ *     safe under hipGraph capture.  Return value: PV_OK or a negative pv_status.
+ */
+#ifndef PV_MI355X_H_
+#define PV_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pv_stream_t; /* hipStream_t */
+
+enum pv_status {
+  PV_OK = 0,
+  PV_ERR_UNSUPPORTED = -1, /* shape/option not implemented by the kernels            */
+  PV_ERR_INVALID = -2,     /* inconsistent descriptor (reference raises RuntimeError) */
+  PV_ERR_HIP = -3          /* a HIP runtime call failed; see pv_last_error()          */
+};
+
+enum pv_dtype { PV_F32 = 0, PV_BF16 = 1 };
+
+enum pv_act {
+  PV_ACT_NONE = 0,
+  PV_ACT_RELU = 1,
+  PV_ACT_SWISH = 2,  /* x*sigmoid(x): pytorchvideo/layers/swish.py:7-34 */
+  PV_ACT_GELU = 3,   /* exact erf form: nn.GELU default, layers/attention.py:74 */
+  PV_ACT_SIGMOID = 4
+};
+
+enum pv_pool_mode { PV_POOL_MAX = 0, PV_POOL_AVG = 1 };
+
+/* ---- library ---------------------------------------------------------------------- */
+int pv_version(void);             /* ABI version, bumped on any descriptor change */
+const char* pv_last_error(void);  /* text of the last PV_ERR_HIP on this thread   */
+int pv_device_count(void);        /* hipGetDeviceCount; 0 when no GPU is visible  */
+
+/* ---- dense convolution / linear as implicit GEMM on MFMA ---------------------------
+ * Replaces nn.Conv3d(groups=1, dilation=1) [+ BatchNorm3d eval | + bias] [+ residual]
+ * [+ activation] and nn.Linear [+ bias][+ GELU][+ residual]:
+ *   models/x3d.py:169-171,210-212,297-305,480-494 (1x1x1 convs), models/resnet.py:98-132
+ *   (conv_a T x1x1, conv_b 1x3x3, conv_c), models/stem.py:80-107 (stems),
+ *   models/slowfast.py:672-694 (lateral 7x1x1 stride 4), models/stem.py:295-338 (patch
+ *   embed), layers/attention.py:102-114,425-451,541 (Mlp / qkv / proj Linear),
+ *   models/head.py:376-382 (head Linear).
+ * y = act( (sum_k x'[..]*w[..]) * scale[c] + shift[c] + residual ),
+ * x' = a_act(x * a_gate[b][k]) when a_gate/a_act are given (squeeze-excitation scale and
+ * Swish of models/x3d.py:190-207 folded into the consumer conv_c).
+ * Weights are packed [cout][kt*kh*kw][cin] (cin = padded channel count, tap-major K).
+ */
+typedef struct pv_conv3d_desc {
+  const void* x;         /* input activations                                   */
+  const void* w;         /* packed weights, dtype `dtype`                        */
+  void* y;               /* output                                              */
+  const float* scale;    /* [cout] or NULL (=1)                                 */
+  const float* shift;    /* [cout] or NULL (=0)                                 */
+  const void* residual;  /* same geometry as y, dtype `dtype`, or NULL           */
+  const float* a_gate;   /* [B][cin] fp32 multiplier on x, or NULL               */
+  int64_t x_bs, y_bs, r_bs; /* batch strides, elements                          */
+  int32_t ldx, ldy, ldr;    /* voxel strides, elements                          */
+  int32_t B, Ti, Hi, Wi, cin; /* cin: channels read per voxel (multiple of 8)   */
+  int32_t To, Ho, Wo, cout;   /* cout: true output channels                     */
+  int32_t kt, kh, kw, st, sh, sw, pt, ph, pw;
+  int32_t act;           /* pv_act applied last                                  */
+  int32_t a_act;         /* pv_act applied to x (after a_gate) on load           */
+  int32_t dtype;         /* pv_dtype of x, w, residual                           */
+  int32_t y_f32;         /* 1: y is fp32 regardless of dtype (logits)            */
+} pv_conv3d_desc;
+int pv_conv3d(const pv_conv3d_desc* d, pv_stream_t stream);
+
+/* ---- depthwise convolution ---------------------------------------------------------
+ * Replaces nn.Conv3d(groups=C) [+ BatchNorm3d eval][+ activation]:
+ *   models/x3d.py:66-88 (stem 5x1x1), models/x3d.py:180-189 (3x3x3), models/csn.py:169,
+ *   layers/attention.py:363-404 (MViT pool_q/k/v; weights shared over heads -> w_mod).
+ * Weights packed [taps][round_up(w_mod or C, 8)] fp32.  If psum != NULL the kernel also
+ * writes per-block partial sums of the (pre-activation) output over T,H,W:
+ * psum[b][blk][c], blk < pv_dwconv3d_psum_blocks(d) -- the squeeze half of
+ * fvcore SqueezeExcitation (mean over T,H,W) without atomics (deterministic).
+ */
+typedef struct pv_dwconv3d_desc {
+  const void* x; const float* w; void* y;
+  const float* scale; const float* shift; /* [C] or NULL */
+  float* psum;                            /* or NULL      */
+  int64_t x_bs, y_bs;
+  int32_t ldx, ldy;
+  int32_t B, Ti, Hi, Wi, C;  /* C: true channels; round_up(C,8) are read/written */
+  int32_t To, Ho, Wo;
+  int32_t kt, kh, kw, st, sh, sw, pt, ph, pw;
+  int32_t w_mod;             /* 0, or weights indexed by (c % w_mod)             */
+  int32_t act;
+  int32_t dtype;
+} pv_dwconv3d_desc;
+int pv_dwconv3d(const pv_dwconv3d_desc* d, pv_stream_t stream);
+int pv_dwconv3d_psum_blocks(const pv_dwconv3d_desc* d);
+
+/* ---- squeeze-excitation gate -------------------------------------------------------
+ * fvcore.nn.squeeze_excitation.SqueezeExcitation as used at models/x3d.py:190-198:
+ * gate[b][c] = sigmoid(W2 . relu(W1 . mean_{T,H,W}(x) + b1) + b2); the multiply is done
+ * by the consumer (pv_conv3d a_gate).  w1 [cr][C], w2 [C][cr] fp32 row-major.
+ */
+typedef struct pv_se_gate_desc {
+  const float* psum;   /* [B][nblk][c_p]           */
+  float* gate;         /* [B][c_p]; padding = 0    */
+  const float* w1; const float* b1; const float* w2; const float* b2;
+  int32_t B, C, c_p, cr, nblk;
+  float inv_count;     /* 1/(T*H*W)                */
+} pv_se_gate_desc;
+int pv_se_gate(const pv_se_gate_desc* d, pv_stream_t stream);
+
+/* ---- pooling -----------------------------------------------------------------------
+ * nn.MaxPool3d / nn.AvgPool3d (floor mode, zero/-inf padding, count_include_pad):
+ *   models/stem.py:98-104 (stem max pool), models/x3d.py:791-806 and
+ *   models/slowfast.py:608-620 (head average pools), layers/attention.py:677-679,720-727
+ *   (MViT skip-path max pool on tokens; n_prefix = 1 copies the cls token through).
+ */
+typedef struct pv_pool3d_desc {
+  const void* x; void* y;
+  int64_t x_bs, y_bs;
+  int32_t ldx, ldy;
+  int32_t B, Ti, Hi, Wi, C, To, Ho, Wo;
+  int32_t kt, kh, kw, st, sh, sw, pt, ph, pw;
+  int32_t mode;      /* pv_pool_mode */
+  int32_t n_prefix;  /* rows before the grid in each batch item copied verbatim */
+  int32_t dtype;
+} pv_pool3d_desc;
+int pv_pool3d(const pv_pool3d_desc* d, pv_stream_t stream);
+
+/* ---- layout ingest / egress --------------------------------------------------------
+ * The reference API is NCDHW (models/net.py:41-44).  Ingest converts a contiguous
+ * [B,C,T,H,W] tensor (fp32 or bf16) to NDHWC `dtype` with C padded to c_p (zeros);
+ * t_stride/t_offset select frames (SlowFast PackPathway: transforms/functional.py:134).
+ * Egress is the inverse (channels [0,C)), used by block-level forwards and tests.
+ */
+typedef struct pv_layout_desc {
+  const void* src; void* dst;
+  int32_t B, C, T, H, W;    /* logical NCDHW extent of the NCDHW side           */
+  int32_t c_p, ld;          /* NDHWC side: padded channels written, voxel stride */
+  int64_t bs;               /* NDHWC side batch stride                           */
+  int32_t src_dtype, dst_dtype;
+} pv_layout_desc;
+int pv_ingest_ncdhw(const pv_layout_desc* d, pv_stream_t stream);
+int pv_egress_ncdhw(const pv_layout_desc* d, pv_stream_t stream);
+
+/* ---- row ops on (rows, C) matrices -------------------------------------------------
+ * pv_layernorm: nn.LayerNorm(eps) over C (models/vision_transformers.py:333-335,
+ *   layers/attention.py:199-205).
+ * pv_softmax_rows: nn.Softmax(dim=channel) head activation (models/head.py:384).
+ * pv_mean_rows: AdaptiveAvgPool3d(1)+view (models/head.py:386-390): y[b][c] = mean over
+ *   `rows_per_batch` rows, fp32 out.
+ * pv_add_posenc: SpatioTemporalClsPositionalEncoding.forward
+ *   (layers/positional_encoding.py:112-136): writes the cls row and adds the separable
+ *   spatial + temporal (+ class) embedding in place.
+ */
+typedef struct pv_rows_desc {
+  const void* x; void* y;
+  const float* gamma; const float* beta;  /* layernorm only */
+  int64_t rows; int32_t C, ldx, ldy;
+  int32_t rows_per_batch;                 /* mean_rows only */
+  float eps;
+  int32_t dtype;                          /* of x; y same except mean_rows (fp32) */
+} pv_rows_desc;
+int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream);
+int pv_softmax_rows(const pv_rows_desc* d, pv_stream_t stream);
+int pv_mean_rows(const pv_rows_desc* d, pv_stream_t stream);
+
+typedef struct pv_posenc_desc {
+  void* x;                    /* [B][1+T*HW][ld] tokens, row 0 = cls (written here) */
+  const float* cls_token;     /* [C] or NULL (no cls: rows start at the grid)       */
+  const float* pos_spatial;   /* [HW][C]  (separable) or full [T*HW(+1)][C]          */
+  const float* pos_temporal;  /* [T][C]  or NULL when pos_spatial is the full table  */
+  const float* pos_class;     /* [C] or NULL                                        */
+  int32_t B, T, HW, C, ld;
+  int32_t dtype;
+} pv_posenc_desc;
+int pv_add_posenc(const pv_posenc_desc* d, pv_stream_t stream);
+
+/* ---- fused pooled attention --------------------------------------------------------
+ * softmax((q*scale) k^T) v [+ q] of layers/attention.py:531-539 without materialising
+ * the scores.  q/k/v/o are token tensors whose channel dim is heads*head_dim
+ * (head h at channel offset h*head_dim); fp32 online softmax, MFMA QK^T and PV.
+ */
+typedef struct pv_attention_desc {
+  const void* q; const void* k; const void* v; void* o;
+  int64_t q_bs, k_bs, v_bs, o_bs;
+  int32_t ldq, ldk, ldv, ldo;
+  int32_t B, heads, head_dim, Nq, Nk;
+  float scale;
+  int32_t residual_q;   /* 1: o += q (residual_pool, layers/attention.py:536-537) */
+  int32_t dtype;
+} pv_attention_desc;
+int pv_attention(const pv_attention_desc* d, pv_stream_t stream);
+
+/* ---- elementwise -------------------------------------------------------------------
+ * y = act(a + b) over (rows, C): residual joins that cannot ride in a conv epilogue.
+ */
+typedef struct pv_add_desc {
+  const void* a; const void* b; void* y;
+  int64_t rows; int32_t C, lda, ldb, ldy;
+  int32_t act, dtype;
+} pv_add_desc;
+int pv_add_act(const pv_add_desc* d, pv_stream_t stream);
+
+/* ---- execution plan ----------------------------------------------------------------
+ * A deploy-form model is specialised to one input size (reference contract:
+ * accelerator/deployment/mobile_cpu/utils/model_conversion.py:100-103), so its forward
+ * is a fixed launch list.  The plan records descriptors once; pv_plan_launch replays them
+ * from C++ (no Python per layer), optionally through a captured hipGraph.
+ */
+enum pv_op_kind {
+  PV_OP_CONV3D = 1, PV_OP_DWCONV3D = 2, PV_OP_SE_GATE = 3, PV_OP_POOL3D = 4,
+  PV_OP_LAYERNORM = 5, PV_OP_SOFTMAX_ROWS = 6, PV_OP_MEAN_ROWS = 7, PV_OP_POSENC = 8,
+  PV_OP_ATTENTION = 9, PV_OP_ADD_ACT = 10, PV_OP_INGEST = 11, PV_OP_EGRESS = 12
+};
+typedef struct pv_plan pv_plan;
+pv_plan* pv_plan_create(void);
+void pv_plan_destroy(pv_plan* p);
+int pv_plan_add(pv_plan* p, int op_kind, const void* desc, size_t desc_bytes); /* returns op index */
+int pv_plan_size(const pv_plan* p);
+int pv_plan_launch(pv_plan* p, pv_stream_t stream);                 /* eager replay   */
+int pv_plan_launch_range(pv_plan* p, int first, int last, pv_stream_t stream);
+int pv_plan_graph_build(pv_plan* p, pv_stream_t stream);           /* capture+instantiate */
+int pv_plan_graph_launch(pv_plan* p, pv_stream_t stream);
+/* per-op device time in ms (HIP events on `stream`), averaged over `iters` replays */
+int pv_plan_profile(pv_plan* p, pv_stream_t stream, int iters, float* ms_per_op);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PV_MI355X_H_ */

@@ -1,0 +1,60 @@
+"""Deterministic, key-addressed weight fill (TEST INFRASTRUCTURE).
+
+The reference's default init is degenerate for parity purposes: the gamma of every
+block-final BN is zero (pytorchvideo/models/weight_init.py:34-35), so every `branch2`
+contributes exactly 0 and conv_a/b/c are never exercised.  This fill
+follows the reference's own `rand_init_bn` recipe (tests/test_fuse_bn.py:58-63) for norm
+statistics and a variance-preserving normal for everything else.
+
+Each tensor is generated from a CPU generator seeded by crc32(key) ^ seed, so the values
+depend only on (key, shape, seed) -- NOT on construction order.  The same call on the
+reference model (in the survey container) and on this package's model (on the GPU box)
+therefore produces identical weights provided the state_dict keys and shapes agree, which
+is itself part of the drop-in claim.
+"""
+import zlib
+
+import torch
+
+
+def _gen(key, seed):
+    g = torch.Generator()
+    g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    return g
+
+
+def _uniform(shape, lo, hi, g):
+    return torch.rand(shape, generator=g) * (hi - lo) + lo
+
+
+@torch.no_grad()
+def deterministic_fill(model, seed=0):
+    sd = model.state_dict()
+    for key, t in sd.items():
+        if key.endswith("num_batches_tracked") or not t.is_floating_point():
+            continue
+        g = _gen(key, seed)
+        shape = tuple(t.shape)
+        if key.endswith("running_var"):
+            v = _uniform(shape, 0.5, 1.5, g)
+        elif key.endswith("running_mean"):
+            v = _uniform(shape, -0.5, 0.5, g)
+        elif "pos_embed" in key or "cls_token" in key:
+            v = torch.randn(shape, generator=g) * 0.5
+        elif t.dim() == 1 and key.endswith("weight"):
+            v = _uniform(shape, 0.5, 1.5, g)         # norm gammas
+        elif t.dim() == 1:
+            v = _uniform(shape, -0.3, 0.3, g)        # biases / betas
+        else:
+            fan_in = max(1, t.numel() // shape[0])
+            v = torch.randn(shape, generator=g) * (1.5 / fan_in) ** 0.5
+        t.copy_(v.to(t.dtype))
+    return model
+
+
+def seeded_input(shape, seed=0, dist="randn"):
+    g = torch.Generator()
+    g.manual_seed(1000 + seed)
+    if dist == "randn":
+        return torch.randn(shape, generator=g)
+    return torch.rand(shape, generator=g)

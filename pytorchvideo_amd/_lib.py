@@ -1,0 +1,146 @@
+"""ctypes binding of include/pv_mi355x.h (the C ABI of the gfx950 kernels).
+
+The structures below mirror the header field-for-field; `pv_plan_add` double-checks the
+descriptor size on the C side so a drifted binding fails loudly instead of corrupting
+memory.  There is deliberately no CPU fallback here: if the shared library is missing,
+`lib()` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libpv_mi355x.so")
+
+PV_OK, PV_ERR_UNSUPPORTED, PV_ERR_INVALID, PV_ERR_HIP = 0, -1, -2, -3
+PV_F32, PV_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SWISH, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+POOL_MAX, POOL_AVG = 0, 1
+(OP_CONV3D, OP_DWCONV3D, OP_SE_GATE, OP_POOL3D, OP_LAYERNORM, OP_SOFTMAX_ROWS, OP_MEAN_ROWS,
+ OP_POSENC, OP_ATTENTION, OP_ADD_ACT, OP_INGEST, OP_EGRESS) = range(1, 13)
+
+_p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+def _struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": fields})
+
+
+def _ints(*names):
+    return [(n, _i32) for n in names]
+
+
+Conv3dDesc = _struct("Conv3dDesc", [
+    ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("residual", _p), ("a_gate", _p),
+    ("x_bs", _i64), ("y_bs", _i64), ("r_bs", _i64)]
+    + _ints("ldx", "ldy", "ldr", "B", "Ti", "Hi", "Wi", "cin", "To", "Ho", "Wo", "cout",
+            "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "act", "a_act", "dtype", "y_f32"))
+
+DwConv3dDesc = _struct("DwConv3dDesc", [
+    ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("psum", _p),
+    ("x_bs", _i64), ("y_bs", _i64)]
+    + _ints("ldx", "ldy", "B", "Ti", "Hi", "Wi", "C", "To", "Ho", "Wo",
+            "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "w_mod", "act", "dtype"))
+
+SeGateDesc = _struct("SeGateDesc", [
+    ("psum", _p), ("gate", _p), ("w1", _p), ("b1", _p), ("w2", _p), ("b2", _p)]
+    + _ints("B", "C", "c_p", "cr", "nblk") + [("inv_count", _f32)])
+
+Pool3dDesc = _struct("Pool3dDesc", [
+    ("x", _p), ("y", _p), ("x_bs", _i64), ("y_bs", _i64)]
+    + _ints("ldx", "ldy", "B", "Ti", "Hi", "Wi", "C", "To", "Ho", "Wo",
+            "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "mode", "n_prefix", "dtype"))
+
+LayoutDesc = _struct("LayoutDesc", [
+    ("src", _p), ("dst", _p)] + _ints("B", "C", "T", "H", "W", "c_p", "ld")
+    + [("bs", _i64)] + _ints("src_dtype", "dst_dtype"))
+
+RowsDesc = _struct("RowsDesc", [
+    ("x", _p), ("y", _p), ("gamma", _p), ("beta", _p), ("rows", _i64)]
+    + _ints("C", "ldx", "ldy", "rows_per_batch") + [("eps", _f32), ("dtype", _i32)])
+
+PosencDesc = _struct("PosencDesc", [
+    ("x", _p), ("cls_token", _p), ("pos_spatial", _p), ("pos_temporal", _p), ("pos_class", _p)]
+    + _ints("B", "T", "HW", "C", "ld", "dtype"))
+
+AttentionDesc = _struct("AttentionDesc", [
+    ("q", _p), ("k", _p), ("v", _p), ("o", _p),
+    ("q_bs", _i64), ("k_bs", _i64), ("v_bs", _i64), ("o_bs", _i64)]
+    + _ints("ldq", "ldk", "ldv", "ldo", "B", "heads", "head_dim", "Nq", "Nk")
+    + [("scale", _f32)] + _ints("residual_q", "dtype"))
+
+AddDesc = _struct("AddDesc", [
+    ("a", _p), ("b", _p), ("y", _p), ("rows", _i64)]
+    + _ints("C", "lda", "ldb", "ldy", "act", "dtype"))
+
+DESC_FOR_OP = {
+    OP_CONV3D: Conv3dDesc, OP_DWCONV3D: DwConv3dDesc, OP_SE_GATE: SeGateDesc, OP_POOL3D: Pool3dDesc,
+    OP_LAYERNORM: RowsDesc, OP_SOFTMAX_ROWS: RowsDesc, OP_MEAN_ROWS: RowsDesc, OP_POSENC: PosencDesc,
+    OP_ATTENTION: AttentionDesc, OP_ADD_ACT: AddDesc, OP_INGEST: LayoutDesc, OP_EGRESS: LayoutDesc,
+}
+
+# every symbol the header declares: (name, restype, argtypes)
+_SYMBOLS = [
+    ("pv_version", C.c_int, []),
+    ("pv_last_error", C.c_char_p, []),
+    ("pv_device_count", C.c_int, []),
+    ("pv_conv3d", C.c_int, [C.POINTER(Conv3dDesc), _p]),
+    ("pv_dwconv3d", C.c_int, [C.POINTER(DwConv3dDesc), _p]),
+    ("pv_dwconv3d_psum_blocks", C.c_int, [C.POINTER(DwConv3dDesc)]),
+    ("pv_se_gate", C.c_int, [C.POINTER(SeGateDesc), _p]),
+    ("pv_pool3d", C.c_int, [C.POINTER(Pool3dDesc), _p]),
+    ("pv_ingest_ncdhw", C.c_int, [C.POINTER(LayoutDesc), _p]),
+    ("pv_egress_ncdhw", C.c_int, [C.POINTER(LayoutDesc), _p]),
+    ("pv_layernorm", C.c_int, [C.POINTER(RowsDesc), _p]),
+    ("pv_softmax_rows", C.c_int, [C.POINTER(RowsDesc), _p]),
+    ("pv_mean_rows", C.c_int, [C.POINTER(RowsDesc), _p]),
+    ("pv_add_posenc", C.c_int, [C.POINTER(PosencDesc), _p]),
+    ("pv_attention", C.c_int, [C.POINTER(AttentionDesc), _p]),
+    ("pv_add_act", C.c_int, [C.POINTER(AddDesc), _p]),
+    ("pv_plan_create", _p, []),
+    ("pv_plan_destroy", None, [_p]),
+    ("pv_plan_add", C.c_int, [_p, C.c_int, _p, C.c_size_t]),
+    ("pv_plan_size", C.c_int, [_p]),
+    ("pv_plan_launch", C.c_int, [_p, _p]),
+    ("pv_plan_launch_range", C.c_int, [_p, C.c_int, C.c_int, _p]),
+    ("pv_plan_graph_build", C.c_int, [_p, _p]),
+    ("pv_plan_graph_launch", C.c_int, [_p, _p]),
+    ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
+]
+EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
+ABI_VERSION = 1
+
+_lib = None
+
+
+class PvError(RuntimeError):
+    """Raised for any non-OK status.  Shape/descriptor errors are RuntimeError like the
+    reference's (torch raises RuntimeError for a channel mismatch, tests/test_models_x3d.py:64-67)."""
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PvError(
+                "libpv_mi355x.so is not built (%s). Run `python -m pytorchvideo_amd.csrc.build`; "
+                "the MI355X deploy form has no CPU fallback." % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, res, args in _SYMBOLS:
+            fn = getattr(h, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if h.pv_version() != ABI_VERSION:
+            raise PvError("ABI mismatch: library %d, binding %d" % (h.pv_version(), ABI_VERSION))
+        _lib = h
+    return _lib
+
+
+def check(status, what=""):
+    if status >= 0:
+        return status
+    names = {PV_ERR_UNSUPPORTED: "unsupported", PV_ERR_INVALID: "invalid descriptor", PV_ERR_HIP: "HIP error"}
+    msg = names.get(status, "status %d" % status)
+    if status == PV_ERR_HIP:
+        msg += ": " + (lib().pv_last_error() or b"").decode()
+    raise PvError("%s: %s" % (what or "pv call", msg))

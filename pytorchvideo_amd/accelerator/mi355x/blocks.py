@@ -1,0 +1,175 @@
+"""MI355X efficient blocks and their transmuters.
+
+A block *adopts* the reference module it replaces (same children, parameters, buffers and
+attributes, so `state_dict()` keys and `model.blocks[i]` indexing are unchanged) and keeps
+that module's own `forward` as its original form.  `convert()` emits the block's kernel
+launches into a deploy `Session`; after that `forward` runs only HIP kernels through the
+C ABI (it raises if the library or the GPU is missing -- there is no fallback).
+"""
+import torch
+import torch.nn as nn
+
+from ... import _lib as L
+from ..efficient_blocks import EfficientBlockBase
+from . import emit as E
+from .session import Session
+
+
+class Mi355xBlock(EfficientBlockBase):
+    """Generic single-input / single-output block (stem, res stage, res block, head, pool)."""
+
+    def __init__(self, original: nn.Module):
+        super().__init__()
+        # adopt the original module's state wholesale: children, params, buffers, hooks, plain attrs
+        self.__dict__.update(original.__dict__)
+        self.__dict__["_orig_cls"] = type(original)
+        self.__dict__["convert_flag"] = False
+        self.__dict__["_sess"] = None
+        self.__dict__["_in_ref"] = None
+        self.__dict__["_out_ref"] = None
+        self.__dict__["_op_range"] = None
+        self.__dict__["_owns_session"] = False
+
+    # name shown in reprs / logs
+    def _get_name(self):
+        return "Mi355x[%s]" % self._orig_cls.__name__
+
+    # -- original form ---------------------------------------------------------------
+    def _original_forward(self, *args, **kwargs):
+        return self._orig_cls.forward(self, *args, **kwargs)
+
+    # -- conversion ------------------------------------------------------------------
+    def _emit(self, sess, x_ref):
+        return E.emit_module(sess, self, x_ref)
+
+    def convert(self, input_blob_size, *args, session=None, input_ref=None, dtype=None, **kwargs):
+        """Build the deploy form for inputs of `input_blob_size` (B,C,T,H,W).  Unknown
+        kwargs of other devices (`convert_for_quantize`, `native_conv3d_op_qnnpack`) are
+        accepted and ignored, as the reference's blocks do."""
+        assert self.convert_flag is False, "already converted, cannot be converted again"
+        self.eval()
+        sess = session
+        if sess is None:
+            sess = Session(dtype=dtype or torch.bfloat16)
+            self.__dict__["_owns_session"] = True
+        if input_ref is None:
+            B, Cc, T, H, W = [int(v) for v in input_blob_size]
+            input_ref = sess.alloc_act(B, T, H, W, Cc)
+        first = len(sess.ops)
+        out_ref = self._emit(sess, input_ref)
+        self.__dict__.update(_sess=sess, _in_ref=input_ref, _out_ref=out_ref, _op_range=(first, len(sess.ops)))
+        if self._owns_session:
+            sess.finalize()
+        self.__dict__["convert_flag"] = True
+
+    # -- deploy form -----------------------------------------------------------------
+    def _deploy_forward(self, x):
+        sess = self._sess
+        sess.finalize()
+        if not sess.matches(x, self._in_ref):
+            sess.ingest(x, self._in_ref)
+        sess.launch(*self._op_range)
+        out = self._out_ref
+        if out.T == out.H == out.W == 1 and out.f32:
+            return sess.view_rows(out)[:, 0, :]
+        return sess.view(out)
+
+    def forward(self, *args, **kwargs):
+        if self.convert_flag:
+            return self._deploy_forward(*args, **kwargs)
+        return self._original_forward(*args, **kwargs)
+
+
+# ------------------------------------------------------------------------- transmuters
+_SINGLE_IO = ("ResNetBasicStem", "ResStage", "ResBlock", "ResNetBasicHead")
+
+
+def _probe(module):
+    """Structural support check without geometry: walk the module with the emitters' own
+    predicates.  Returns True when every piece is something the kernels implement."""
+    n = type(module).__name__
+    try:
+        if n == "ResNetBasicStem":
+            conv = module.conv
+            E.act_code(module.activation)
+            if type(conv).__name__ == "Conv2plus1d":
+                E.check_conv3d(conv.conv_t), E.check_conv3d(conv.conv_xy)
+                E.act_code(conv.activation), E.fold_norm(conv.norm, _out_ch(conv, first=True))
+            else:
+                E.check_conv3d(conv)
+            _check_norm(module.norm)
+            if module.pool is not None and not isinstance(module.pool, (nn.MaxPool3d, nn.AvgPool3d)):
+                return False
+            return True
+        if n == "ResStage":
+            return all(type(b).__name__ == "ResBlock" and _probe(b) for b in module.res_blocks)
+        if n == "ResBlock":
+            if not E.is_add_fusion(module.branch_fusion) or type(module.branch2).__name__ != "BottleneckBlock":
+                return False
+            E.act_code(module.activation)
+            if module.branch1_conv is not None:
+                if E.check_conv3d(module.branch1_conv):
+                    return False
+                _check_norm(module.branch1_norm)
+            bb = module.branch2
+            if E.check_conv3d(bb.conv_a) or E.check_conv3d(bb.conv_c):
+                return False
+            E.act_code(bb.act_a), E.act_code(bb.act_b)
+            _check_norm(bb.norm_a), _check_norm(bb.norm_c)
+            bn, se = E._split_norm_b(bb.norm_b)
+            _check_norm(bn)
+            if type(bb.conv_b).__name__ == "Conv2plus1d":
+                if se is not None:
+                    return False
+                E.check_conv3d(bb.conv_b.conv_t), E.check_conv3d(bb.conv_b.conv_xy)
+                E.act_code(bb.conv_b.activation), _check_norm(bb.conv_b.norm)
+            else:
+                dw = E.check_conv3d(bb.conv_b)
+                if se is not None and not dw:
+                    return False
+            return True
+        if n == "ResNetBasicHead":
+            if module.pool is not None and type(module.pool).__name__ != "ProjectedPool" and \
+                    not isinstance(module.pool, (nn.AvgPool3d, nn.MaxPool3d, nn.AdaptiveAvgPool3d)):
+                return False
+            if not isinstance(module.proj, nn.Linear):
+                return False
+            if module.activation is not None and not isinstance(module.activation, nn.Softmax):
+                return False
+            if module.dropout is not None and not isinstance(module.dropout, nn.Dropout):
+                return False
+            return True
+    except (E.Unsupported, AttributeError):
+        return False
+    return False
+
+
+def _check_norm(norm):
+    if norm is None or isinstance(norm, nn.Identity):
+        return
+    if not isinstance(norm, nn.modules.batchnorm._BatchNorm) or norm.running_mean is None:
+        raise E.Unsupported("norm %s" % type(norm).__name__)
+
+
+def _out_ch(conv2plus1d, first):
+    c = conv2plus1d.conv_xy if (conv2plus1d.conv_xy_first == first) else conv2plus1d.conv_t
+    return c.out_channels
+
+
+def transmute_single_io(module: nn.Module):
+    """Stem / stage / res-block / head -> Mi355xBlock, or None (decline)."""
+    if isinstance(module, EfficientBlockBase):
+        return None
+    if type(module).__name__ not in _SINGLE_IO or not _probe(module):
+        return None
+    return Mi355xBlock(module)
+
+
+def transmute_pool(module: nn.Module):
+    """Bare pooling layers that sit between blocks (e.g. create_resnet's stage1_pool)."""
+    if isinstance(module, (nn.MaxPool3d, nn.AvgPool3d)) and not getattr(module, "ceil_mode", False):
+        return Mi355xBlock(module)
+    return None
+
+
+EFFICIENT_BLOCK_TRANSMUTER_MI355X = [transmute_single_io, transmute_pool]

@@ -1,0 +1,124 @@
+"""Convert driver for the "mi355x" target (reference:
+pytorchvideo/accelerator/deployment/mobile_cpu/utils/model_conversion.py:87-125).
+
+Same contract as the reference driver: record every module's input size with forward
+hooks during one eval forward, remove the hooks, deep-copy the model and call `convert()`
+on every `EfficientBlockBase` top-down without descending into it.  Two MI355X additions:
+
+  * the probing forward runs on a single clip (sizes are per-sample; the batch dimension
+    is patched back), so converting for a batch of 32 does not need a 32-clip CPU forward;
+  * all blocks of one model share a deploy `Session` (one arena, one launch plan).  When
+    the converted model is a `Net` whose blocks are all MI355X blocks, consecutive blocks
+    are chained zero-copy inside the plan and `model.forward` becomes one plan replay.
+"""
+import types
+from copy import deepcopy
+
+import torch
+import torch.nn as nn
+
+from ... import _lib as L
+from ..efficient_blocks import EfficientBlockBase
+from .session import Session
+
+
+def _record_input_sizes(model, sample):
+    lut, handles = {}, []
+
+    def add(module, name):
+        def hook(_m, _in, _out):
+            if len(_in) > 0 and isinstance(_in[0], torch.Tensor):
+                lut[name] = tuple(_in[0].size())
+        handles.append(module.register_forward_hook(hook))
+        for child_name, child in module.named_children():
+            add(child, f"{name}.{child_name}")
+
+    add(model, "")
+    model.eval()
+    with torch.no_grad():
+        model(sample)
+    for h in handles:
+        h.remove()
+    return lut
+
+
+def _one_clip(x):
+    if isinstance(x, torch.Tensor):
+        return x[:1].detach().float().cpu()
+    return [_one_clip(t) for t in x]
+
+
+def _batch_of(x):
+    return x.shape[0] if isinstance(x, torch.Tensor) else x[0].shape[0]
+
+
+def _convert_children(module, lut, batch, name, sess, dtype, kwargs):
+    if isinstance(module, EfficientBlockBase):
+        size = lut.get(name)
+        if size is not None:
+            size = (batch,) + tuple(size[1:])
+        module.convert(size, session=sess, dtype=dtype, **kwargs)
+        return
+    for child_name, child in module.named_children():
+        _convert_children(child, lut, batch, f"{name}.{child_name}", sess, dtype, kwargs)
+
+
+def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quantize: bool = False,
+                               native_conv3d_op_qnnpack: bool = False, dtype=None, use_graph: bool = True):
+    """Return a deploy-form copy of a transmuted `model`, specialised to `input_tensor`'s
+    shape.  `dtype` (torch.bfloat16 | torch.float32) selects the kernels' storage type and
+    defaults to the input tensor's dtype (fp32 input -> fp32 kernels)."""
+    if dtype is None:
+        t0 = input_tensor if isinstance(input_tensor, torch.Tensor) else input_tensor[0]
+        dtype = torch.bfloat16 if t0.dtype == torch.bfloat16 else torch.float32
+    L.lib()  # fail early and loudly when the HIP library is not built
+    lut = _record_input_sizes(model, _one_clip(input_tensor))
+    converted = deepcopy(model)
+    converted.eval()
+    sess = Session(dtype=dtype)
+    batch = _batch_of(input_tensor)
+    fused = _try_fuse_net(converted, lut, batch, sess, dtype)
+    if not fused:
+        _convert_children(converted, lut, batch, "", sess, dtype,
+                          dict(convert_for_quantize=convert_for_quantize,
+                               native_conv3d_op_qnnpack=native_conv3d_op_qnnpack))
+    sess.finalize()
+    converted.__dict__["_pv_session"] = sess
+    converted.__dict__["_pv_use_graph"] = use_graph
+    return converted
+
+
+# ------------------------------------------------------------------ whole-Net fusion
+def _try_fuse_net(model, lut, batch, sess, dtype):
+    """`Net` (models/net.py:11-44) whose blocks are all Mi355xBlocks taking one tensor:
+    chain them inside the plan and make forward a single replay."""
+    from .blocks import Mi355xBlock
+
+    blocks = getattr(model, "blocks", None)
+    if type(model).__name__ != "Net" or blocks is None or len(blocks) == 0:
+        return False
+    if not all(type(b) is Mi355xBlock for b in blocks):
+        return False
+    size = lut.get(".blocks.0")
+    if size is None or len(size) != 5:
+        return False
+    cur = None
+    for i, blk in enumerate(blocks):
+        blk.convert((batch,) + tuple(size[1:]) if i == 0 else None, session=sess, input_ref=cur, dtype=dtype)
+        if cur is not None and cur is not blocks[0]._in_ref:
+            sess.release(cur)  # its consumer has been emitted
+        cur = blk._out_ref
+    first_in, last = blocks[0]._in_ref, blocks[-1]
+
+    def fused_forward(self, x):
+        s = self._pv_session
+        if not s.matches(x, first_in):
+            s.ingest(x, first_in)
+        s.launch(use_graph=self._pv_use_graph)
+        out = last._out_ref
+        if out.T == out.H == out.W == 1 and out.f32:
+            return s.view_rows(out)[:, 0, :]
+        return s.view(out)
+
+    model.forward = types.MethodType(fused_forward, model)
+    return True

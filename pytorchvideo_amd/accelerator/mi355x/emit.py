@@ -1,0 +1,469 @@
+"""Emitters: turn (reference-shaped) nn.Modules into kernel launches of a deploy Session.
+
+Each `emit_*` takes the session, a module in its *original form* (the reference module
+tree, weights in fp32) and the input activation reference(s), appends ops and returns the
+output reference.  BatchNorm is folded in fp64 on the host into per-channel scale/shift
+that ride in the producing kernel's epilogue; activations, residual adds, squeeze-excite
+scaling and Swish are fused into conv epilogues / prologues as described in DESIGN.md.
+
+`Unsupported` is raised for anything the kernels do not implement; transmuters probe with
+`supports(module)` and *decline* (return None) in that case, leaving the reference module
+in place (reference convention: transmuter_mobile_cpu.py:21-22).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from ... import _lib as L
+from .session import TRef, pad8
+
+
+class Unsupported(Exception):
+    pass
+
+
+# --------------------------------------------------------------------------- helpers
+def _cls_name(m):
+    """Class name of a module; an Mi355x block answers with the reference class it adopted."""
+    return getattr(m, "_orig_cls", type(m)).__name__
+
+
+def act_code(act):
+    """Map an activation module to the kernel's enum (None/Identity -> NONE)."""
+    if act is None or isinstance(act, nn.Identity):
+        return L.ACT_NONE
+    if isinstance(act, nn.ReLU):
+        return L.ACT_RELU
+    if _cls_name(act) == "Swish" or isinstance(act, nn.SiLU):
+        return L.ACT_SWISH
+    if isinstance(act, nn.GELU):
+        if getattr(act, "approximate", "none") != "none":
+            raise Unsupported("tanh GELU")
+        return L.ACT_GELU
+    if isinstance(act, nn.Sigmoid):
+        return L.ACT_SIGMOID
+    raise Unsupported("activation %s" % _cls_name(act))
+
+
+def fold_norm(norm, channels, conv_bias=None):
+    """(scale, shift) fp32 vectors equivalent to `norm(conv + bias)` in eval mode.
+    BatchNorm eval: (x-mean)/sqrt(var+eps)*gamma+beta (reference numerics)."""
+    scale = torch.ones(channels, dtype=torch.float64)
+    shift = torch.zeros(channels, dtype=torch.float64)
+    if conv_bias is not None:
+        shift = conv_bias.detach().double().cpu().clone()
+    if norm is None or isinstance(norm, nn.Identity):
+        pass
+    elif isinstance(norm, nn.modules.batchnorm._BatchNorm):
+        if norm.running_mean is None or norm.running_var is None:
+            raise Unsupported("BatchNorm without running stats")
+        if norm.num_features != channels:
+            raise RuntimeError("BatchNorm has %d features, conv produces %d" % (norm.num_features, channels))
+        inv = 1.0 / torch.sqrt(norm.running_var.detach().double().cpu() + norm.eps)
+        g = norm.weight.detach().double().cpu() if norm.weight is not None else torch.ones(channels, dtype=torch.float64)
+        b = norm.bias.detach().double().cpu() if norm.bias is not None else torch.zeros(channels, dtype=torch.float64)
+        s = g * inv
+        shift = (shift - norm.running_mean.detach().double().cpu()) * s + b
+        scale = s
+    else:
+        raise Unsupported("norm %s" % _cls_name(norm))
+    return scale.float(), shift.float()
+
+
+def _triple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+def _conv_out(i, k, s, p):
+    return (i + 2 * p - k) // s + 1
+
+
+def check_conv3d(conv):
+    if not isinstance(conv, nn.Conv3d):
+        raise Unsupported("%s is not nn.Conv3d" % _cls_name(conv))
+    if tuple(conv.dilation) != (1, 1, 1):
+        raise Unsupported("dilated conv")
+    if conv.padding_mode != "zeros" or isinstance(conv.padding, str):
+        raise Unsupported("padding mode")
+    depthwise = conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1
+    if conv.groups != 1 and not depthwise:
+        raise Unsupported("grouped conv (groups=%d)" % conv.groups)
+    return depthwise
+
+
+def is_add_fusion(fn):
+    """The reference passes `lambda x, y: x + y` / `_trivial_sum`; probe it."""
+    if fn is None:
+        return False
+    try:
+        a, b = torch.tensor([1.5, -2.0]), torch.tensor([0.25, 4.0])
+        return bool(torch.equal(fn(a, b), a + b))
+    except Exception:
+        return False
+
+
+# --------------------------------------------------------------------------- conv family
+def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=None, a_act=L.ACT_NONE,
+              out=None, y_f32=False, label="conv"):
+    """Dense Conv3d (+BN +bias +residual +act) -> pv_conv3d, or depthwise -> pv_dwconv3d."""
+    depthwise = check_conv3d(conv)
+    if depthwise:
+        if residual is not None or a_gate is not None or a_act != L.ACT_NONE or y_f32:
+            raise Unsupported("fusion on a depthwise conv")
+        return emit_dwconv(sess, conv, x, norm, act, out=out, label=label)
+    if conv.in_channels != x.C:
+        raise RuntimeError("conv expects %d input channels, got %d" % (conv.in_channels, x.C))
+    kt, kh, kw = conv.kernel_size
+    st, sh, sw = conv.stride
+    pt, ph, pw = _triple(conv.padding)
+    To, Ho, Wo = _conv_out(x.T, kt, st, pt), _conv_out(x.H, kh, sh, ph), _conv_out(x.W, kw, sw, pw)
+    if min(To, Ho, Wo) <= 0:
+        raise RuntimeError("conv output would be empty")
+    cout, cin_p = conv.out_channels, pad8(x.C)
+    if x.ld < cin_p:
+        raise Unsupported("input row narrower than padded channels")
+    y = out if out is not None else sess.alloc_act(x.B, To, Ho, Wo, cout, f32=y_f32)
+    if (y.B, y.T, y.H, y.W) != (x.B, To, Ho, Wo) or y.C != cout:
+        raise RuntimeError("conv output buffer geometry mismatch")
+    # pack [cout][taps][cin_p]
+    w = conv.weight.detach().float().cpu()  # [cout, cin, kt, kh, kw]
+    wp = torch.zeros(cout, kt * kh * kw, cin_p, dtype=torch.float32)
+    wp[:, :, : x.C] = w.permute(0, 2, 3, 4, 1).reshape(cout, kt * kh * kw, x.C)
+    wp = wp.to(sess.dtype)
+    scale, shift = fold_norm(norm, cout, conv.bias)
+    has_affine = norm is not None and not isinstance(norm, nn.Identity)
+    f = dict(
+        x=x.ptr, w=sess.add_weight(wp), y=y.ptr,
+        scale=sess.add_weight(scale) if has_affine else None,
+        shift=sess.add_weight(shift) if (has_affine or conv.bias is not None) else None,
+        residual=residual.ptr if residual is not None else None,
+        a_gate=a_gate,
+        x_bs=x.bs, y_bs=y.bs, r_bs=residual.bs if residual is not None else 0,
+        ldx=x.ld, ldy=y.ld, ldr=residual.ld if residual is not None else 0,
+        B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, cin=cin_p, To=To, Ho=Ho, Wo=Wo, cout=cout,
+        kt=kt, kh=kh, kw=kw, st=st, sh=sh, sw=sw, pt=pt, ph=ph, pw=pw,
+        act=act, a_act=a_act, dtype=sess.pv_dtype, y_f32=1 if y_f32 else 0,
+    )
+    if residual is not None and ((residual.B, residual.T, residual.H, residual.W) != (y.B, y.T, y.H, y.W)
+                                 or residual.C != cout):
+        raise RuntimeError("residual geometry mismatch")
+    vox_in, vox_out = x.B * x.voxels, y.B * y.voxels
+    taps = kt * kh * kw
+    reads = vox_out * cin_p if taps == 1 else vox_in * cin_p  # each input voxel once
+    alg = sess.itemsize * (reads + cout * taps * cin_p + (vox_out * pad8(cout) if residual is not None else 0)) \
+        + (4 if y_f32 else sess.itemsize) * vox_out * pad8(cout)
+    flops = 2 * vox_out * cout * taps * x.C
+    sess.add_op(L.OP_CONV3D, f, label=label, alg_bytes=alg, flops=flops)
+    return y
+
+
+def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=None, w_mod=0, label="dwconv"):
+    """Depthwise Conv3d (+BN +act [+SE partial sums]) -> pv_dwconv3d.  Returns y or (y, psum, nblk)."""
+    if not w_mod:
+        if not check_conv3d(conv):
+            raise Unsupported("not depthwise")
+        if conv.in_channels != x.C:
+            raise RuntimeError("depthwise conv expects %d channels, got %d" % (conv.in_channels, x.C))
+    kt, kh, kw = conv.kernel_size
+    st, sh, sw = conv.stride
+    pt, ph, pw = _triple(conv.padding)
+    To, Ho, Wo = _conv_out(x.T, kt, st, pt), _conv_out(x.H, kh, sh, ph), _conv_out(x.W, kw, sw, pw)
+    if min(To, Ho, Wo) <= 0:
+        raise RuntimeError("conv output would be empty")
+    Cc = x.C
+    wc = w_mod if w_mod else Cc
+    w = conv.weight.detach().float().cpu().reshape(wc, kt * kh * kw)
+    wp = torch.zeros(kt * kh * kw, pad8(wc), dtype=torch.float32)
+    wp[:, :wc] = w.t()
+    y = out if out is not None else sess.alloc_act(x.B, To, Ho, Wo, Cc)
+    has_affine = norm is not None and not isinstance(norm, nn.Identity)
+    scale, shift = fold_norm(norm, Cc, conv.bias if not w_mod else None)
+    f = dict(
+        x=x.ptr, w=sess.add_weight(wp), y=y.ptr,
+        scale=sess.add_weight(scale) if has_affine else None,
+        shift=sess.add_weight(shift) if (has_affine or conv.bias is not None) else None,
+        psum=None, x_bs=x.bs, y_bs=y.bs, ldx=x.ld, ldy=y.ld,
+        B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, C=Cc, To=To, Ho=Ho, Wo=Wo,
+        kt=kt, kh=kh, kw=kw, st=st, sh=sh, sw=sw, pt=pt, ph=ph, pw=pw,
+        w_mod=w_mod, act=act, dtype=sess.pv_dtype,
+    )
+    psum = nblk = None
+    if want_psum:
+        d = L.DwConv3dDesc()
+        for k, v in f.items():
+            if not hasattr(v, "space") and v is not None:
+                setattr(d, k, v)
+        nblk = L.lib().pv_dwconv3d_psum_blocks(C.byref(d))
+        if nblk <= 0:
+            raise Unsupported("depthwise geometry")
+        psum = sess.alloc_raw(4 * x.B * nblk * pad8(Cc))
+        f["psum"] = psum
+    alg = sess.itemsize * (x.B * x.voxels + y.B * y.voxels) * pad8(Cc)
+    sess.add_op(L.OP_DWCONV3D, f, label=label, alg_bytes=alg, flops=2 * y.B * y.voxels * Cc * kt * kh * kw)
+    if want_psum:
+        return y, psum, nblk
+    return y
+
+
+def emit_se_gate(sess, se, psum, nblk, B, Cc, count):
+    """fvcore-style SqueezeExcitation -> gate[B][pad8(C)] (the multiply happens in the consumer)."""
+    blk = getattr(se, "block", None)
+    if blk is None or len(blk) != 4 or not isinstance(blk[0], nn.Conv3d) or not isinstance(blk[2], nn.Conv3d) \
+            or not isinstance(blk[1], nn.ReLU) or not isinstance(blk[3], nn.Sigmoid):
+        raise Unsupported("squeeze-excitation structure")
+    c1, c2 = blk[0], blk[2]
+    if c1.in_channels != Cc or c2.out_channels != Cc or c1.kernel_size != (1, 1, 1) or c2.kernel_size != (1, 1, 1):
+        raise Unsupported("squeeze-excitation shape")
+    cr = c1.out_channels
+    gate = sess.alloc_raw(4 * B * pad8(Cc))
+    f = dict(
+        psum=psum, gate=gate,
+        w1=sess.add_weight(c1.weight.detach().float().reshape(cr, Cc)),
+        b1=sess.add_weight(c1.bias.detach().float()) if c1.bias is not None else None,
+        w2=sess.add_weight(c2.weight.detach().float().reshape(Cc, cr)),
+        b2=sess.add_weight(c2.bias.detach().float()) if c2.bias is not None else None,
+        B=B, C=Cc, c_p=pad8(Cc), cr=cr, nblk=nblk, inv_count=1.0 / float(count),
+    )
+    sess.add_op(L.OP_SE_GATE, f, label="se_gate", alg_bytes=4 * B * nblk * pad8(Cc))
+    return gate
+
+
+def emit_pool(sess, pool, x, n_prefix=0, label="pool"):
+    """nn.MaxPool3d / nn.AvgPool3d / nn.AdaptiveAvgPool3d(1) -> pv_pool3d."""
+    if isinstance(pool, nn.AdaptiveAvgPool3d):
+        osz = _triple(pool.output_size)
+        if any(o not in (1, None) for o in osz):
+            raise Unsupported("adaptive pool to %s" % (osz,))
+        k = (x.T if osz[0] == 1 else 1, x.H if osz[1] == 1 else 1, x.W if osz[2] == 1 else 1)
+        s, p, mode = k, (0, 0, 0), L.POOL_AVG
+    elif isinstance(pool, (nn.MaxPool3d, nn.AvgPool3d)):
+        k = _triple(pool.kernel_size)
+        s = _triple(pool.stride if pool.stride is not None else pool.kernel_size)
+        p = _triple(pool.padding)
+        if getattr(pool, "ceil_mode", False):
+            raise Unsupported("ceil_mode pooling")
+        if isinstance(pool, nn.MaxPool3d):
+            if _triple(pool.dilation) != (1, 1, 1) or pool.return_indices:
+                raise Unsupported("max pool options")
+            mode = L.POOL_MAX
+        else:
+            if not pool.count_include_pad or pool.divisor_override is not None:
+                raise Unsupported("avg pool options")
+            mode = L.POOL_AVG
+    else:
+        raise Unsupported("pool %s" % _cls_name(pool))
+    k = tuple(int(v) for v in k)
+    To, Ho, Wo = (_conv_out(x.T, k[0], s[0], p[0]), _conv_out(x.H, k[1], s[1], p[1]),
+                  _conv_out(x.W, k[2], s[2], p[2]))
+    if min(To, Ho, Wo) <= 0:
+        raise RuntimeError("pool output would be empty")
+    return emit_pool_raw(sess, x, k, s, p, mode, n_prefix=n_prefix, label=label)
+
+
+def emit_pool_raw(sess, x, k, s, p, mode, n_prefix=0, out=None, label="pool"):
+    To, Ho, Wo = (_conv_out(x.T, k[0], s[0], p[0]), _conv_out(x.H, k[1], s[1], p[1]),
+                  _conv_out(x.W, k[2], s[2], p[2]))
+    if out is None:
+        if n_prefix:
+            y = sess.alloc_act(x.B, 1, 1, To * Ho * Wo + n_prefix, x.C)
+        else:
+            y = sess.alloc_act(x.B, To, Ho, Wo, x.C)
+    else:
+        y = out
+    f = dict(x=x.ptr, y=y.ptr, x_bs=x.bs, y_bs=y.bs, ldx=x.ld, ldy=y.ld,
+             B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, C=x.C, To=To, Ho=Ho, Wo=Wo,
+             kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2], pt=p[0], ph=p[1], pw=p[2],
+             mode=mode, n_prefix=n_prefix, dtype=sess.pv_dtype)
+    alg = sess.itemsize * pad8(x.C) * x.B * (x.voxels + To * Ho * Wo)
+    sess.add_op(L.OP_POOL3D, f, label=label, alg_bytes=alg)
+    return y
+
+
+# --------------------------------------------------------------------------- blocks
+def _split_norm_b(norm_b):
+    """X3D wraps conv_b's norm as Sequential(BN|Identity, SE|Identity) (x3d.py:199-206)."""
+    if isinstance(norm_b, nn.Sequential):
+        if len(norm_b) != 2:
+            raise Unsupported("norm_b Sequential of length %d" % len(norm_b))
+        bn, se = norm_b[0], norm_b[1]
+        if isinstance(se, nn.Identity):
+            se = None
+        elif _cls_name(se) != "SqueezeExcitation":
+            raise Unsupported("norm_b[1] is %s" % _cls_name(se))
+        return (None if isinstance(bn, nn.Identity) else bn), se
+    return norm_b, None
+
+
+def emit_conv_b(sess, conv_b, x, norm_b, act_b):
+    """conv_b + norm_b + act_b of a bottleneck.  Returns (y, gate_ptr_or_None, deferred_act):
+    with squeeze-excitation the activation is deferred to the consumer's load."""
+    bn, se = _split_norm_b(norm_b)
+    act = act_code(act_b)
+    if _cls_name(conv_b) == "Conv2plus1d":
+        first, second = (conv_b.conv_xy, conv_b.conv_t) if conv_b.conv_xy_first else (conv_b.conv_t, conv_b.conv_xy)
+        if se is not None:
+            raise Unsupported("SE after Conv2plus1d")
+        mid = emit_conv(sess, first, x, conv_b.norm, act_code(conv_b.activation), label="conv_b.0")
+        y = emit_conv(sess, second, mid, bn, act, label="conv_b.1")
+        sess.release(mid)
+        return y, None, L.ACT_NONE
+    depthwise = check_conv3d(conv_b)
+    if se is not None:
+        if not depthwise:
+            raise Unsupported("SE after a dense conv_b")
+        if getattr(se, "is_3d", True) is not True:
+            raise Unsupported("2-D squeeze-excitation")
+        y, psum, nblk = emit_dwconv(sess, conv_b, x, bn, L.ACT_NONE, want_psum=True, label="conv_b.dw+se")
+        gate = emit_se_gate(sess, se, psum, nblk, x.B, x.C, y.voxels)
+        sess.release(psum)
+        return y, gate, act
+    y = emit_conv(sess, conv_b, x, bn, act, label="conv_b")
+    return y, None, L.ACT_NONE
+
+
+def emit_bottleneck(sess, bb, x, residual=None, final_act=L.ACT_NONE):
+    """BottleneckBlock.forward (resnet.py:1345-1365) with the block's residual join and
+    final activation fused into conv_c's epilogue."""
+    for name in ("conv_a", "conv_b", "conv_c"):
+        if getattr(bb, name, None) is None:
+            raise Unsupported("bottleneck without %s" % name)
+    a = emit_conv(sess, bb.conv_a, x, bb.norm_a, act_code(bb.act_a), label="conv_a")
+    b, gate, deferred = emit_conv_b(sess, bb.conv_b, a, bb.norm_b, bb.act_b)
+    sess.release(a)
+    check_conv3d(bb.conv_c)
+    if (gate is not None or deferred != L.ACT_NONE) and \
+            (bb.conv_c.kernel_size != (1, 1, 1) or bb.conv_c.stride != (1, 1, 1) or _triple(bb.conv_c.padding) != (0, 0, 0)):
+        raise Unsupported("SE block whose conv_c is not pointwise")
+    c = emit_conv(sess, bb.conv_c, b, bb.norm_c, final_act, residual=residual, a_gate=gate, a_act=deferred,
+                  label="conv_c")
+    sess.release(b)
+    if gate is not None:
+        sess.release(gate)
+    return c
+
+
+def emit_res_block(sess, rb, x):
+    """ResBlock.forward (resnet.py:1179-1189): act(shortcut + branch2(x))."""
+    if not is_add_fusion(rb.branch_fusion):
+        raise Unsupported("branch_fusion is not a sum")
+    if _cls_name(rb.branch2) != "BottleneckBlock":
+        raise Unsupported("branch2 is %s" % _cls_name(rb.branch2))
+    if rb.branch1_conv is None:
+        shortcut = x
+    else:
+        shortcut = emit_conv(sess, rb.branch1_conv, x, rb.branch1_norm, L.ACT_NONE, label="shortcut")
+    y = emit_bottleneck(sess, rb.branch2, x, residual=shortcut, final_act=act_code(rb.activation))
+    if shortcut is not x:
+        sess.release(shortcut)
+    return y
+
+
+def emit_res_stage(sess, stage, x):
+    cur = x
+    for blk in stage.res_blocks:
+        if _cls_name(blk) != "ResBlock":
+            raise Unsupported("stage element %s" % _cls_name(blk))
+        nxt = emit_res_block(sess, blk, cur)
+        if cur is not x:
+            sess.release(cur)
+        cur = nxt
+    return cur
+
+
+def emit_stem(sess, stem, x):
+    """ResNetBasicStem.forward (stem.py:252-260); conv may be Conv3d or X3D's Conv2plus1d."""
+    act = act_code(stem.activation)
+    conv = stem.conv
+    if _cls_name(conv) == "Conv2plus1d":
+        first, second = (conv.conv_xy, conv.conv_t) if conv.conv_xy_first else (conv.conv_t, conv.conv_xy)
+        mid = emit_conv(sess, first, x, conv.norm, act_code(conv.activation), label="stem.conv0")
+        y = emit_conv(sess, second, mid, stem.norm, act, label="stem.conv1")
+        sess.release(mid)
+    else:
+        y = emit_conv(sess, conv, x, stem.norm, act, label="stem.conv")
+    if stem.pool is not None:
+        p = emit_pool(sess, stem.pool, y, label="stem.pool")
+        sess.release(y)
+        y = p
+    return y
+
+
+def _emit_linear_rows(sess, lin, x, act=L.ACT_NONE, y_f32=False, label="linear"):
+    """nn.Linear on the channel dim of a channels-last activation = pointwise conv."""
+    if not isinstance(lin, nn.Linear):
+        raise Unsupported("%s is not nn.Linear" % _cls_name(lin))
+    if lin.in_features != x.C:
+        raise RuntimeError("Linear expects %d features, got %d" % (lin.in_features, x.C))
+    conv = nn.Conv3d(lin.in_features, lin.out_features, 1, bias=lin.bias is not None)
+    conv.weight.data = lin.weight.detach().reshape(lin.out_features, lin.in_features, 1, 1, 1)
+    if lin.bias is not None:
+        conv.bias.data = lin.bias.detach()
+    return emit_conv(sess, conv, x, None, act, y_f32=y_f32, label=label)
+
+
+def emit_projected_pool(sess, pp, x):
+    """ProjectedPool.forward (x3d.py:791-806)."""
+    a = emit_conv(sess, pp.pre_conv, x, pp.pre_norm, act_code(pp.pre_act), label="head.pre_conv")
+    p = emit_pool(sess, pp.pool, a, label="head.pool")
+    sess.release(a)
+    y = emit_conv(sess, pp.post_conv, p, pp.post_norm, act_code(pp.post_act), label="head.post_conv")
+    sess.release(p)
+    return y
+
+
+def emit_res_head(sess, head, x):
+    """ResNetBasicHead.forward (head.py:371-391).  Returns an fp32 [B, classes] row tensor
+    when the head ends in the global average, else the (B,T,H,W,classes) activation."""
+    cur = x
+    if head.pool is not None:
+        if _cls_name(head.pool) == "ProjectedPool":
+            cur = emit_projected_pool(sess, head.pool, x)
+        else:
+            cur = emit_pool(sess, head.pool, x, label="head.pool")
+    # dropout is the identity in eval
+    if head.dropout is not None and not isinstance(head.dropout, nn.Dropout):
+        raise Unsupported("head dropout %s" % _cls_name(head.dropout))
+    logits = _emit_linear_rows(sess, head.proj, cur, y_f32=True, label="head.proj")
+    if cur is not x:
+        sess.release(cur)
+    a = head.activation
+    if a is not None:
+        rows = logits.B * logits.voxels
+        if isinstance(a, nn.Softmax):
+            if a.dim != 1:
+                raise Unsupported("softmax over dim %s" % a.dim)
+            f = dict(x=logits.ptr, y=logits.ptr, gamma=None, beta=None, rows=rows, C=logits.C,
+                     ldx=logits.ld, ldy=logits.ld, rows_per_batch=0, eps=0.0, dtype=L.PV_F32)
+            sess.add_op(L.OP_SOFTMAX_ROWS, f, label="head.softmax")
+        elif isinstance(a, nn.Sigmoid):
+            raise Unsupported("sigmoid head activation")  # TODO: fold into proj epilogue
+        else:
+            raise Unsupported("head activation %s" % _cls_name(a))
+    if head.output_pool is None:
+        return logits
+    if not isinstance(head.output_pool, nn.AdaptiveAvgPool3d) or _triple(head.output_pool.output_size) != (1, 1, 1):
+        raise Unsupported("head output pool")
+    out = sess.alloc_act(logits.B, 1, 1, 1, logits.C, f32=True)
+    f = dict(x=logits.ptr, y=out.ptr, gamma=None, beta=None, rows=logits.B * logits.voxels, C=logits.C,
+             ldx=logits.ld, ldy=out.ld, rows_per_batch=logits.voxels, eps=0.0, dtype=L.PV_F32)
+    sess.add_op(L.OP_MEAN_ROWS, f, label="head.mean")
+    sess.release(logits)
+    return out
+
+
+# --------------------------------------------------------------------------- dispatch
+def emit_module(sess, m, x):
+    """Emit any supported single-input/single-output conv-family module."""
+    n = _cls_name(m)
+    if n == "ResNetBasicStem":
+        return emit_stem(sess, m, x)
+    if n == "ResStage":
+        return emit_res_stage(sess, m, x)
+    if n == "ResBlock":
+        return emit_res_block(sess, m, x)
+    if n == "ResNetBasicHead":
+        return emit_res_head(sess, m, x)
+    if isinstance(m, (nn.MaxPool3d, nn.AvgPool3d, nn.AdaptiveAvgPool3d)):
+        return emit_pool(sess, m, x)
+    raise Unsupported("no emitter for %s" % n)

@@ -1,0 +1,62 @@
+"""Build libpv_mi355x.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m pytorchvideo_amd.csrc.build [--force]
+
+Objects are rebuilt only when their source (or a header) is newer.  hipcc cross-compiles
+without a GPU, so this also runs in the CPU-only build container.
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+INCLUDE = os.path.join(ROOT, "include")
+OUT_DIR = os.path.join(os.path.dirname(HERE), "_lib")
+LIB = os.path.join(OUT_DIR, "libpv_mi355x.so")
+SOURCES = ["pv_conv.hip", "pv_dwconv.hip", "pv_misc.hip", "pv_attn.hip", "pv_plan.hip"]
+HEADERS = [os.path.join(HERE, "pv_common.h"), os.path.join(INCLUDE, "pv_mi355x.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", HERE,
+         "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, force):
+    obj = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+    path = os.path.join(HERE, src)
+    if force or _stale(obj, [path] + HEADERS):
+        cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        return obj, True
+    return obj, False
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    objs = [o for o, _ in results]
+    if force or any(changed for _, changed in results) or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("built", LIB)
+    elif verbose:
+        print("up to date:", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,89 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA, bf16/f32 8-element chunks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pv_mi355x.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define PV_WAVE 64
+
+int pv_set_hip_error(hipError_t e, const char* what);  // pv_plan.cpp
+#define PV_HIP_CHECK(expr)                                   \
+  do {                                                       \
+    hipError_t _e = (expr);                                  \
+    if (_e != hipSuccess) return pv_set_hip_error(_e, #expr); \
+  } while (0)
+#define PV_LAUNCH_CHECK() PV_HIP_CHECK(hipGetLastError())
+
+// ---- an 8-channel chunk: the unit every kernel moves (16 B of bf16, 32 B of f32) ----
+template <typename T> struct Chunk8;
+template <> struct alignas(16) Chunk8<bf16_t> {
+  bf16x8 v;
+  __device__ __forceinline__ void zero() {
+    v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<bf16x8*>(p) = v; }
+  __device__ __forceinline__ void to_f32(float (&f)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+  }
+  __device__ __forceinline__ void from_f32(const float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16_t)f[i];
+  }
+};
+template <> struct alignas(16) Chunk8<float> {
+  f32x4 lo, hi;
+  __device__ __forceinline__ void zero() {
+    lo = f32x4{0.f, 0.f, 0.f, 0.f};
+    hi = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void load(const float* p) {
+    lo = *reinterpret_cast<const f32x4*>(p);
+    hi = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    *reinterpret_cast<f32x4*>(p) = lo;
+    *reinterpret_cast<f32x4*>(p + 4) = hi;
+  }
+  __device__ __forceinline__ void to_f32(float (&f)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = lo[i]; f[4 + i] = hi[i]; }
+  }
+  __device__ __forceinline__ void from_f32(const float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { lo[i] = f[i]; hi[i] = f[4 + i]; }
+  }
+};
+
+__device__ __forceinline__ float pv_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float pv_apply_act(float v, int act) {
+  switch (act) {
+    case PV_ACT_RELU: return fmaxf(v, 0.0f);
+    case PV_ACT_SWISH: return v * pv_sigmoid(v);
+    case PV_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case PV_ACT_SIGMOID: return pv_sigmoid(v);
+    default: return v;
+  }
+}
+
+__host__ __device__ __forceinline__ int pv_round_up(int v, int m) { return (v + m - 1) / m * m; }
+__host__ __device__ __forceinline__ long pv_ceil_div(long a, long b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float pv_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float pv_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,555 @@
+// Small HBM-bound kernels of the forward path: squeeze-excitation gate, pooling, layout
+// ingest/egress, LayerNorm, row softmax / mean, positional-encoding add, residual add.
+// All of them move 8-channel chunks (16 B of bf16) with lanes running over channels first.
+#include <float.h>
+#include "pv_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// --------------------------------------------------------------------- SE gate
+// one block per batch item; psum[b][blk][c_p] -> gate[b][c_p]
+__global__ __launch_bounds__(kThreads) void se_gate_kernel(const pv_se_gate_desc d) {
+  extern __shared__ float s[];
+  float* s_mean = s;            // [c_p]
+  float* s_hid = s + d.c_p;     // [cr]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* ps = d.psum + (long)b * d.nblk * d.c_p;
+  for (int c = tid; c < d.c_p; c += kThreads) {
+    float a = 0.f;
+    for (int k = 0; k < d.nblk; ++k) a += ps[(long)k * d.c_p + c];
+    s_mean[c] = a * d.inv_count;
+  }
+  __syncthreads();
+  // fc1 + relu: one wave per hidden unit
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int r = wave; r < d.cr; r += kThreads / 64) {
+    float a = 0.f;
+    for (int c = lane; c < d.C; c += 64) a += d.w1[(long)r * d.C + c] * s_mean[c];
+    a = pv_wave_sum(a);
+    if (lane == 0) s_hid[r] = fmaxf(a + (d.b1 ? d.b1[r] : 0.f), 0.f);
+  }
+  __syncthreads();
+  for (int c = tid; c < d.c_p; c += kThreads) {
+    float g = 0.f;
+    if (c < d.C) {
+      float a = d.b2 ? d.b2[c] : 0.f;
+      for (int r = 0; r < d.cr; ++r) a += d.w2[(long)c * d.cr + r] * s_hid[r];
+      g = pv_sigmoid(a);
+    }
+    d.gate[(long)b * d.c_p + c] = g;
+  }
+}
+
+// --------------------------------------------------------------------- pooling
+// small windows: one thread per (output voxel, chunk)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pool_direct_kernel(const pv_pool3d_desc d, long total) {
+  const int CG = pv_round_up(d.C, 8) / 8;
+  const long id = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (id >= total) return;
+  const int cg = (int)(id % CG);
+  long v = id / CG;
+  const int wo = (int)(v % d.Wo); v /= d.Wo;
+  const int ho = (int)(v % d.Ho); v /= d.Ho;
+  const int to = (int)(v % d.To);
+  const int b = (int)(v / d.To);
+  const T* X = static_cast<const T*>(d.x) + (long)b * d.x_bs + (long)d.n_prefix * d.ldx + cg * 8;
+  float a[8];
+  const bool is_max = d.mode == PV_POOL_MAX;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = is_max ? -FLT_MAX : 0.f;
+  for (int dt = 0; dt < d.kt; ++dt) {
+    const int ti = to * d.st - d.pt + dt;
+    if ((unsigned)ti >= (unsigned)d.Ti) continue;
+    for (int dh = 0; dh < d.kh; ++dh) {
+      const int hi = ho * d.sh - d.ph + dh;
+      if ((unsigned)hi >= (unsigned)d.Hi) continue;
+      for (int dw = 0; dw < d.kw; ++dw) {
+        const int wi = wo * d.sw - d.pw + dw;
+        if ((unsigned)wi >= (unsigned)d.Wi) continue;
+        Chunk8<T> c;
+        c.load(X + ((long)(ti * d.Hi + hi) * d.Wi + wi) * d.ldx);
+        float f[8];
+        c.to_f32(f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = is_max ? fmaxf(a[j], f[j]) : a[j] + f[j];
+      }
+    }
+  }
+  if (!is_max) {
+    const float inv = 1.f / (float)(d.kt * d.kh * d.kw);  // count_include_pad=True
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] *= inv;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (cg * 8 + j >= d.C) a[j] = 0.f;
+  Chunk8<T> o;
+  o.from_f32(a);
+  o.store(static_cast<T*>(d.y) + (long)b * d.y_bs + (long)d.n_prefix * d.ldy +
+          ((long)(to * d.Ho + ho) * d.Wo + wo) * d.ldy + cg * 8);
+}
+
+// large windows: one block per output voxel (and chunk slab), taps split over threads
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pool_reduce_kernel(const pv_pool3d_desc d, int cgb) {
+  __shared__ float s_red[kThreads * 8];
+  const int CG = pv_round_up(d.C, 8) / 8;
+  const int tid = threadIdx.x;
+  const int splits = kThreads / cgb;
+  const int cgl = tid % cgb, sp = tid / cgb;
+  const int cg = blockIdx.y * cgb + cgl;
+  long v = blockIdx.x;
+  const int wo = (int)(v % d.Wo); v /= d.Wo;
+  const int ho = (int)(v % d.Ho); v /= d.Ho;
+  const int to = (int)(v % d.To);
+  const int b = (int)(v / d.To);
+  const bool is_max = d.mode == PV_POOL_MAX;
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = is_max ? -FLT_MAX : 0.f;
+  const int taps = d.kt * d.kh * d.kw;
+  if (cg < CG && sp < splits) {
+    const T* X = static_cast<const T*>(d.x) + (long)b * d.x_bs + (long)d.n_prefix * d.ldx + cg * 8;
+    for (int t = sp; t < taps; t += splits) {
+      const int dt = t / (d.kh * d.kw);
+      const int r = t - dt * d.kh * d.kw;
+      const int dh = r / d.kw, dw = r - dh * d.kw;
+      const int ti = to * d.st - d.pt + dt, hi = ho * d.sh - d.ph + dh, wi = wo * d.sw - d.pw + dw;
+      if ((unsigned)ti >= (unsigned)d.Ti || (unsigned)hi >= (unsigned)d.Hi || (unsigned)wi >= (unsigned)d.Wi)
+        continue;
+      Chunk8<T> c;
+      c.load(X + ((long)(ti * d.Hi + hi) * d.Wi + wi) * d.ldx);
+      float f[8];
+      c.to_f32(f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = is_max ? fmaxf(a[j], f[j]) : a[j] + f[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s_red[tid * 8 + j] = a[j];
+  __syncthreads();
+  if (sp == 0 && cg < CG) {
+    for (int s2 = 1; s2 < splits; ++s2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float o = s_red[(s2 * cgb + cgl) * 8 + j];
+        a[j] = is_max ? fmaxf(a[j], o) : a[j] + o;
+      }
+    }
+    if (!is_max) {
+      const float inv = 1.f / (float)taps;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] *= inv;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (cg * 8 + j >= d.C) a[j] = 0.f;
+    Chunk8<T> o;
+    o.from_f32(a);
+    o.store(static_cast<T*>(d.y) + (long)b * d.y_bs + (long)d.n_prefix * d.ldy +
+            ((long)(to * d.Ho + ho) * d.Wo + wo) * d.ldy + cg * 8);
+  }
+}
+
+// copy the n_prefix leading rows (cls token) of every batch item
+template <typename T>
+__global__ void pool_prefix_kernel(const pv_pool3d_desc d) {
+  const int CG = pv_round_up(d.C, 8) / 8;
+  const int total = d.B * d.n_prefix * CG;
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= total) return;
+  const int cg = id % CG;
+  const int r = (id / CG) % d.n_prefix;
+  const int b = id / (CG * d.n_prefix);
+  Chunk8<T> c;
+  c.load(static_cast<const T*>(d.x) + (long)b * d.x_bs + (long)r * d.ldx + cg * 8);
+  c.store(static_cast<T*>(d.y) + (long)b * d.y_bs + (long)r * d.ldy + cg * 8);
+}
+
+// --------------------------------------------------------------------- layout
+template <typename S> __device__ __forceinline__ float ld_as_f32(const S* p) { return (float)*p; }
+
+// NCDHW (contiguous) -> NDHWC padded.  Thread = (voxel fastest, chunk).
+template <typename S, typename T>
+__global__ __launch_bounds__(kThreads) void ingest_kernel(const pv_layout_desc d, long nvox) {
+  const int CG = d.c_p / 8;
+  const long id = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (id >= nvox * CG) return;
+  const long vox = id % nvox;
+  const int cg = (int)(id / nvox);
+  const long S3 = (long)d.T * d.H * d.W;
+  const int b = (int)(vox / S3);
+  const long sp = vox - (long)b * S3;
+  const S* src = static_cast<const S*>(d.src) + (long)b * d.C * S3 + sp;
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    f[j] = c < d.C ? ld_as_f32(src + (long)c * S3) : 0.f;
+  }
+  Chunk8<T> o;
+  o.from_f32(f);
+  o.store(static_cast<T*>(d.dst) + (long)b * d.bs + sp * d.ld + cg * 8);
+}
+
+template <typename T, typename S>
+__global__ __launch_bounds__(kThreads) void egress_kernel(const pv_layout_desc d, long nvox) {
+  const int CG = d.c_p / 8;
+  const long id = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (id >= nvox * CG) return;
+  const long vox = id % nvox;
+  const int cg = (int)(id / nvox);
+  const long S3 = (long)d.T * d.H * d.W;
+  const int b = (int)(vox / S3);
+  const long sp = vox - (long)b * S3;
+  Chunk8<T> c;
+  c.load(static_cast<const T*>(d.src) + (long)b * d.bs + sp * d.ld + cg * 8);
+  float f[8];
+  c.to_f32(f);
+  S* dst = static_cast<S*>(d.dst) + (long)b * d.C * S3 + sp;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = cg * 8 + j;
+    if (ch < d.C) dst[(long)ch * S3] = (S)f[j];
+  }
+}
+
+// --------------------------------------------------------------------- row ops
+// LayerNorm: one wave per row, two-pass statistics in registers (C <= 64*8*MAXC).
+template <typename T, int MAXC>
+__global__ __launch_bounds__(kThreads) void layernorm_kernel(const pv_rows_desc d) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (row >= d.rows) return;
+  const int CG = pv_round_up(d.C, 8) / 8;
+  const T* x = static_cast<const T*>(d.x) + row * d.ldx;
+  float f[MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int cg = lane + i * 64;
+    if (cg < CG) {
+      Chunk8<T> c;
+      c.load(x + cg * 8);
+      c.to_f32(f[i]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[i][j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += f[i][j];  // padding channels are zero
+  }
+  const float mean = pv_wave_sum(s) / (float)d.C;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = (lane + i * 64) * 8 + j;
+      const float dlt = (c < d.C) ? f[i][j] - mean : 0.f;
+      v += dlt * dlt;
+    }
+  }
+  const float rstd = rsqrtf(pv_wave_sum(v) / (float)d.C + d.eps);
+  T* y = static_cast<T*>(d.y) + row * d.ldy;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int cg = lane + i * 64;
+    if (cg < CG) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        o[j] = (c < d.C) ? (f[i][j] - mean) * rstd * (d.gamma ? d.gamma[c] : 1.f) + (d.beta ? d.beta[c] : 0.f) : 0.f;
+      }
+      Chunk8<T> oc;
+      oc.from_f32(o);
+      oc.store(y + cg * 8);
+    }
+  }
+}
+
+// softmax over channels of each row (head activation); one wave per row, generic C
+template <typename T>
+__global__ __launch_bounds__(kThreads) void softmax_rows_kernel(const pv_rows_desc d) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (row >= d.rows) return;
+  const T* x = static_cast<const T*>(d.x) + row * d.ldx;
+  T* y = static_cast<T*>(d.y) + row * d.ldy;
+  float mx = -FLT_MAX;
+  for (int c = lane; c < d.C; c += 64) mx = fmaxf(mx, (float)x[c]);
+  mx = pv_wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < d.C; c += 64) s += __expf((float)x[c] - mx);
+  s = pv_wave_sum(s);
+  const float inv = 1.f / s;
+  for (int c = lane; c < d.C; c += 64) y[c] = (T)(__expf((float)x[c] - mx) * inv);
+}
+
+// y[b][c] = mean over rows_per_batch rows (fp32 out); thread per (b, c)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void mean_rows_kernel(const pv_rows_desc d, int nb) {
+  const long id = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (id >= (long)nb * d.C) return;
+  const int c = (int)(id % d.C);
+  const int b = (int)(id / d.C);
+  const T* x = static_cast<const T*>(d.x) + (long)b * d.rows_per_batch * d.ldx + c;
+  float s = 0.f;
+  for (int r = 0; r < d.rows_per_batch; ++r) s += (float)x[(long)r * d.ldx];
+  static_cast<float*>(d.y)[(long)b * d.ldy + c] = s / (float)d.rows_per_batch;
+}
+
+// tokens[b][0] = cls + pos_class ; tokens[b][1+t*HW+s] += pos_spatial[s] + pos_temporal[t]
+template <typename T>
+__global__ __launch_bounds__(kThreads) void posenc_kernel(const pv_posenc_desc d, long total) {
+  const int c_p = pv_round_up(d.C, 8);
+  const int CG = c_p / 8;
+  const long id = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (id >= total) return;
+  const int cg = (int)(id % CG);
+  long r = id / CG;
+  const int has_cls = d.cls_token != nullptr;
+  const long rows = (long)d.T * d.HW + has_cls;
+  const int b = (int)(r / rows);
+  const long n = r - (long)b * rows;
+  T* x = static_cast<T*>(d.x) + ((long)b * rows + n) * d.ld + cg * 8;
+  float f[8];
+  if (has_cls && n == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cg * 8 + j;
+      float v = 0.f;
+      if (c < d.C) {
+        v = d.cls_token[c];
+        if (d.pos_temporal != nullptr) { if (d.pos_class) v += d.pos_class[c]; }
+        else v += d.pos_spatial[c];  // full table: row 0 belongs to cls
+      }
+      f[j] = v;
+    }
+  } else {
+    Chunk8<T> cch;
+    cch.load(x);
+    cch.to_f32(f);
+    const long g = n - has_cls;
+    const int t = (int)(g / d.HW), s = (int)(g - (long)t * d.HW);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cg * 8 + j;
+      if (c < d.C) {
+        if (d.pos_temporal != nullptr)
+          f[j] += d.pos_spatial[(long)s * d.C + c] + d.pos_temporal[(long)t * d.C + c];
+        else
+          f[j] += d.pos_spatial[(g + has_cls) * d.C + c];
+      }
+    }
+  }
+  Chunk8<T> o;
+  o.from_f32(f);
+  o.store(x);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void add_act_kernel(const pv_add_desc d, long total) {
+  const int CG = pv_round_up(d.C, 8) / 8;
+  const long id = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (id >= total) return;
+  const int cg = (int)(id % CG);
+  const long r = id / CG;
+  Chunk8<T> a, b;
+  a.load(static_cast<const T*>(d.a) + r * d.lda + cg * 8);
+  b.load(static_cast<const T*>(d.b) + r * d.ldb + cg * 8);
+  float fa[8], fb[8];
+  a.to_f32(fa);
+  b.to_f32(fb);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    fa[j] = pv_apply_act(fa[j] + fb[j], d.act);
+    if (cg * 8 + j >= d.C) fa[j] = 0.f;
+  }
+  a.from_f32(fa);
+  a.store(static_cast<T*>(d.y) + r * d.ldy + cg * 8);
+}
+
+inline unsigned blocks_for(long total) { return (unsigned)pv_ceil_div(total, kThreads); }
+
+}  // namespace
+
+// ======================================================================= C ABI
+extern "C" int pv_se_gate(const pv_se_gate_desc* d, pv_stream_t stream) {
+  if (!d || !d->psum || !d->gate || !d->w1 || !d->w2) return PV_ERR_INVALID;
+  if (d->B <= 0 || d->C <= 0 || d->cr <= 0 || d->nblk <= 0 || d->c_p < d->C || d->c_p % 8) return PV_ERR_INVALID;
+  const size_t lds = sizeof(float) * (d->c_p + d->cr);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(d->B), dim3(kThreads), lds, static_cast<hipStream_t>(stream), *d);
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
+template <typename T> static int pool_launch(const pv_pool3d_desc& d, hipStream_t s) {
+  const int CG = pv_round_up(d.C, 8) / 8;
+  const int taps = d.kt * d.kh * d.kw;
+  const long nvox = (long)d.B * d.To * d.Ho * d.Wo;
+  if (taps >= 64) {
+    const int cgb = CG < kThreads ? CG : kThreads;
+    if (nvox > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)nvox, (unsigned)pv_ceil_div(CG, cgb));
+    hipLaunchKernelGGL(pool_reduce_kernel<T>, grid, dim3(kThreads), 0, s, d, cgb);
+  } else {
+    const long total = nvox * CG;
+    hipLaunchKernelGGL(pool_direct_kernel<T>, dim3(blocks_for(total)), dim3(kThreads), 0, s, d, total);
+  }
+  PV_LAUNCH_CHECK();
+  if (d.n_prefix > 0) {
+    const int total = d.B * d.n_prefix * CG;
+    hipLaunchKernelGGL(pool_prefix_kernel<T>, dim3(blocks_for(total)), dim3(kThreads), 0, s, d);
+    PV_LAUNCH_CHECK();
+  }
+  return PV_OK;
+}
+
+extern "C" int pv_pool3d(const pv_pool3d_desc* dp, pv_stream_t stream) {
+  if (!dp || !dp->x || !dp->y) return PV_ERR_INVALID;
+  const pv_pool3d_desc& d = *dp;
+  if (d.B <= 0 || d.C <= 0 || d.To <= 0 || d.Ho <= 0 || d.Wo <= 0) return PV_ERR_INVALID;
+  if (d.ldx % 8 || d.ldy % 8 || d.x_bs % 8 || d.y_bs % 8) return PV_ERR_INVALID;
+  if (d.kt < 1 || d.kh < 1 || d.kw < 1 || d.st < 1 || d.sh < 1 || d.sw < 1) return PV_ERR_INVALID;
+  if ((d.Ti + 2 * d.pt - d.kt) / d.st + 1 != d.To || (d.Hi + 2 * d.ph - d.kh) / d.sh + 1 != d.Ho ||
+      (d.Wi + 2 * d.pw - d.kw) / d.sw + 1 != d.Wo)
+    return PV_ERR_INVALID;
+  if (d.mode != PV_POOL_MAX && d.mode != PV_POOL_AVG) return PV_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d.dtype == PV_BF16) return pool_launch<bf16_t>(d, s);
+  if (d.dtype == PV_F32) return pool_launch<float>(d, s);
+  return PV_ERR_UNSUPPORTED;
+}
+
+static int layout_check(const pv_layout_desc* d) {
+  if (!d || !d->src || !d->dst) return PV_ERR_INVALID;
+  if (d->B <= 0 || d->C <= 0 || d->T <= 0 || d->H <= 0 || d->W <= 0) return PV_ERR_INVALID;
+  if (d->c_p % 8 || d->c_p < d->C || d->ld % 8 || d->ld < d->c_p || d->bs % 8) return PV_ERR_INVALID;
+  return PV_OK;
+}
+
+extern "C" int pv_ingest_ncdhw(const pv_layout_desc* d, pv_stream_t stream) {
+  const int v = layout_check(d);
+  if (v != PV_OK) return v;
+  const long nvox = (long)d->B * d->T * d->H * d->W;
+  const long total = nvox * (d->c_p / 8);
+  dim3 grid(blocks_for(total)), block(kThreads);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d->src_dtype == PV_F32 && d->dst_dtype == PV_F32)
+    hipLaunchKernelGGL((ingest_kernel<float, float>), grid, block, 0, s, *d, nvox);
+  else if (d->src_dtype == PV_F32 && d->dst_dtype == PV_BF16)
+    hipLaunchKernelGGL((ingest_kernel<float, bf16_t>), grid, block, 0, s, *d, nvox);
+  else if (d->src_dtype == PV_BF16 && d->dst_dtype == PV_BF16)
+    hipLaunchKernelGGL((ingest_kernel<bf16_t, bf16_t>), grid, block, 0, s, *d, nvox);
+  else if (d->src_dtype == PV_BF16 && d->dst_dtype == PV_F32)
+    hipLaunchKernelGGL((ingest_kernel<bf16_t, float>), grid, block, 0, s, *d, nvox);
+  else
+    return PV_ERR_UNSUPPORTED;
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
+extern "C" int pv_egress_ncdhw(const pv_layout_desc* d, pv_stream_t stream) {
+  const int v = layout_check(d);
+  if (v != PV_OK) return v;
+  const long nvox = (long)d->B * d->T * d->H * d->W;
+  const long total = nvox * (d->c_p / 8);
+  dim3 grid(blocks_for(total)), block(kThreads);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // src = NDHWC side (src_dtype), dst = NCDHW side (dst_dtype)
+  if (d->src_dtype == PV_F32 && d->dst_dtype == PV_F32)
+    hipLaunchKernelGGL((egress_kernel<float, float>), grid, block, 0, s, *d, nvox);
+  else if (d->src_dtype == PV_BF16 && d->dst_dtype == PV_F32)
+    hipLaunchKernelGGL((egress_kernel<bf16_t, float>), grid, block, 0, s, *d, nvox);
+  else if (d->src_dtype == PV_BF16 && d->dst_dtype == PV_BF16)
+    hipLaunchKernelGGL((egress_kernel<bf16_t, bf16_t>), grid, block, 0, s, *d, nvox);
+  else if (d->src_dtype == PV_F32 && d->dst_dtype == PV_BF16)
+    hipLaunchKernelGGL((egress_kernel<float, bf16_t>), grid, block, 0, s, *d, nvox);
+  else
+    return PV_ERR_UNSUPPORTED;
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
+static int rows_check(const pv_rows_desc* d) {
+  if (!d || !d->x || !d->y || d->rows <= 0 || d->C <= 0) return PV_ERR_INVALID;
+  return PV_OK;
+}
+
+extern "C" int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream) {
+  int v = rows_check(d);
+  if (v != PV_OK) return v;
+  if (d->ldx % 8 || d->ldy % 8) return PV_ERR_INVALID;
+  const int CG = pv_round_up(d->C, 8) / 8;
+  dim3 grid((unsigned)pv_ceil_div(d->rows, kThreads / 64)), block(kThreads);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define PV_LN(T, MAXC) hipLaunchKernelGGL((layernorm_kernel<T, MAXC>), grid, block, 0, s, *d)
+  if (d->dtype == PV_BF16) {
+    if (CG <= 64) PV_LN(bf16_t, 1); else if (CG <= 128) PV_LN(bf16_t, 2); else if (CG <= 256) PV_LN(bf16_t, 4);
+    else return PV_ERR_UNSUPPORTED;
+  } else if (d->dtype == PV_F32) {
+    if (CG <= 64) PV_LN(float, 1); else if (CG <= 128) PV_LN(float, 2); else if (CG <= 256) PV_LN(float, 4);
+    else return PV_ERR_UNSUPPORTED;
+  } else return PV_ERR_UNSUPPORTED;
+#undef PV_LN
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
+extern "C" int pv_softmax_rows(const pv_rows_desc* d, pv_stream_t stream) {
+  int v = rows_check(d);
+  if (v != PV_OK) return v;
+  dim3 grid((unsigned)pv_ceil_div(d->rows, kThreads / 64)), block(kThreads);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d->dtype == PV_BF16) hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, block, 0, s, *d);
+  else if (d->dtype == PV_F32) hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, block, 0, s, *d);
+  else return PV_ERR_UNSUPPORTED;
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
+extern "C" int pv_mean_rows(const pv_rows_desc* d, pv_stream_t stream) {
+  int v = rows_check(d);
+  if (v != PV_OK) return v;
+  if (d->rows_per_batch <= 0 || d->rows % d->rows_per_batch) return PV_ERR_INVALID;
+  const int nb = (int)(d->rows / d->rows_per_batch);
+  dim3 grid(blocks_for((long)nb * d->C)), block(kThreads);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d->dtype == PV_BF16) hipLaunchKernelGGL(mean_rows_kernel<bf16_t>, grid, block, 0, s, *d, nb);
+  else if (d->dtype == PV_F32) hipLaunchKernelGGL(mean_rows_kernel<float>, grid, block, 0, s, *d, nb);
+  else return PV_ERR_UNSUPPORTED;
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
+extern "C" int pv_add_posenc(const pv_posenc_desc* d, pv_stream_t stream) {
+  if (!d || !d->x || !d->pos_spatial) return PV_ERR_INVALID;
+  if (d->B <= 0 || d->T <= 0 || d->HW <= 0 || d->C <= 0 || d->ld % 8) return PV_ERR_INVALID;
+  const long rows = (long)d->T * d->HW + (d->cls_token ? 1 : 0);
+  const long total = (long)d->B * rows * (pv_round_up(d->C, 8) / 8);
+  dim3 grid(blocks_for(total)), block(kThreads);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d->dtype == PV_BF16) hipLaunchKernelGGL(posenc_kernel<bf16_t>, grid, block, 0, s, *d, total);
+  else if (d->dtype == PV_F32) hipLaunchKernelGGL(posenc_kernel<float>, grid, block, 0, s, *d, total);
+  else return PV_ERR_UNSUPPORTED;
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
+extern "C" int pv_add_act(const pv_add_desc* d, pv_stream_t stream) {
+  if (!d || !d->a || !d->b || !d->y || d->rows <= 0 || d->C <= 0) return PV_ERR_INVALID;
+  if (d->lda % 8 || d->ldb % 8 || d->ldy % 8) return PV_ERR_INVALID;
+  const long total = d->rows * (pv_round_up(d->C, 8) / 8);
+  dim3 grid(blocks_for(total)), block(kThreads);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d->dtype == PV_BF16) hipLaunchKernelGGL(add_act_kernel<bf16_t>, grid, block, 0, s, *d, total);
+  else if (d->dtype == PV_F32) hipLaunchKernelGGL(add_act_kernel<float>, grid, block, 0, s, *d, total);
+  else return PV_ERR_UNSUPPORTED;
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}

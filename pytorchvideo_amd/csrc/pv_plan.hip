@@ -1,0 +1,171 @@
+// Library bookkeeping + the execution plan: a deploy-form model is a fixed list of kernel
+// launches (it is specialised to one input size), so the host side records the descriptors
+// once and replays them from C++ -- eagerly, or as one captured hipGraph.
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "pv_common.h"
+
+namespace {
+thread_local std::string g_last_error;
+constexpr int kAbiVersion = 1;
+}  // namespace
+
+int pv_set_hip_error(hipError_t e, const char* what) {
+  char buf[512];
+  snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+  g_last_error = buf;
+  return PV_ERR_HIP;
+}
+
+extern "C" int pv_version(void) { return kAbiVersion; }
+extern "C" const char* pv_last_error(void) { return g_last_error.c_str(); }
+extern "C" int pv_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+struct pv_plan {
+  struct Op {
+    int kind;
+    std::vector<unsigned char> desc;
+  };
+  std::vector<Op> ops;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+namespace {
+
+size_t desc_size(int kind) {
+  switch (kind) {
+    case PV_OP_CONV3D: return sizeof(pv_conv3d_desc);
+    case PV_OP_DWCONV3D: return sizeof(pv_dwconv3d_desc);
+    case PV_OP_SE_GATE: return sizeof(pv_se_gate_desc);
+    case PV_OP_POOL3D: return sizeof(pv_pool3d_desc);
+    case PV_OP_LAYERNORM:
+    case PV_OP_SOFTMAX_ROWS:
+    case PV_OP_MEAN_ROWS: return sizeof(pv_rows_desc);
+    case PV_OP_POSENC: return sizeof(pv_posenc_desc);
+    case PV_OP_ATTENTION: return sizeof(pv_attention_desc);
+    case PV_OP_ADD_ACT: return sizeof(pv_add_desc);
+    case PV_OP_INGEST:
+    case PV_OP_EGRESS: return sizeof(pv_layout_desc);
+    default: return 0;
+  }
+}
+
+int run_op(const pv_plan::Op& op, pv_stream_t s) {
+  const void* p = op.desc.data();
+  switch (op.kind) {
+    case PV_OP_CONV3D: return pv_conv3d(static_cast<const pv_conv3d_desc*>(p), s);
+    case PV_OP_DWCONV3D: return pv_dwconv3d(static_cast<const pv_dwconv3d_desc*>(p), s);
+    case PV_OP_SE_GATE: return pv_se_gate(static_cast<const pv_se_gate_desc*>(p), s);
+    case PV_OP_POOL3D: return pv_pool3d(static_cast<const pv_pool3d_desc*>(p), s);
+    case PV_OP_LAYERNORM: return pv_layernorm(static_cast<const pv_rows_desc*>(p), s);
+    case PV_OP_SOFTMAX_ROWS: return pv_softmax_rows(static_cast<const pv_rows_desc*>(p), s);
+    case PV_OP_MEAN_ROWS: return pv_mean_rows(static_cast<const pv_rows_desc*>(p), s);
+    case PV_OP_POSENC: return pv_add_posenc(static_cast<const pv_posenc_desc*>(p), s);
+    case PV_OP_ATTENTION: return pv_attention(static_cast<const pv_attention_desc*>(p), s);
+    case PV_OP_ADD_ACT: return pv_add_act(static_cast<const pv_add_desc*>(p), s);
+    case PV_OP_INGEST: return pv_ingest_ncdhw(static_cast<const pv_layout_desc*>(p), s);
+    case PV_OP_EGRESS: return pv_egress_ncdhw(static_cast<const pv_layout_desc*>(p), s);
+    default: return PV_ERR_INVALID;
+  }
+}
+
+void drop_graph(pv_plan* p) {
+  if (p->exec) { (void)hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+  if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+}
+
+}  // namespace
+
+extern "C" pv_plan* pv_plan_create(void) { return new pv_plan(); }
+
+extern "C" void pv_plan_destroy(pv_plan* p) {
+  if (!p) return;
+  drop_graph(p);
+  delete p;
+}
+
+extern "C" int pv_plan_add(pv_plan* p, int op_kind, const void* desc, size_t desc_bytes) {
+  if (!p || !desc) return PV_ERR_INVALID;
+  const size_t want = desc_size(op_kind);
+  if (want == 0 || want != desc_bytes) return PV_ERR_INVALID;  // ABI mismatch guard
+  pv_plan::Op op;
+  op.kind = op_kind;
+  op.desc.assign(static_cast<const unsigned char*>(desc), static_cast<const unsigned char*>(desc) + want);
+  p->ops.push_back(std::move(op));
+  drop_graph(p);
+  return (int)p->ops.size() - 1;
+}
+
+extern "C" int pv_plan_size(const pv_plan* p) { return p ? (int)p->ops.size() : PV_ERR_INVALID; }
+
+extern "C" int pv_plan_launch_range(pv_plan* p, int first, int last, pv_stream_t stream) {
+  if (!p || first < 0 || last > (int)p->ops.size() || first > last) return PV_ERR_INVALID;
+  for (int i = first; i < last; ++i) {
+    const int r = run_op(p->ops[i], stream);
+    if (r != PV_OK) return r;
+  }
+  return PV_OK;
+}
+
+extern "C" int pv_plan_launch(pv_plan* p, pv_stream_t stream) {
+  if (!p) return PV_ERR_INVALID;
+  return pv_plan_launch_range(p, 0, (int)p->ops.size(), stream);
+}
+
+extern "C" int pv_plan_graph_build(pv_plan* p, pv_stream_t stream) {
+  if (!p) return PV_ERR_INVALID;
+  drop_graph(p);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  PV_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  const int r = pv_plan_launch(p, stream);
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(s, &g);
+  if (r != PV_OK) {
+    if (g) (void)hipGraphDestroy(g);
+    return r;
+  }
+  if (e != hipSuccess) return pv_set_hip_error(e, "hipStreamEndCapture");
+  p->graph = g;
+  PV_HIP_CHECK(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+  return PV_OK;
+}
+
+extern "C" int pv_plan_graph_launch(pv_plan* p, pv_stream_t stream) {
+  if (!p || !p->exec) return PV_ERR_INVALID;
+  PV_HIP_CHECK(hipGraphLaunch(p->exec, static_cast<hipStream_t>(stream)));
+  return PV_OK;
+}
+
+extern "C" int pv_plan_profile(pv_plan* p, pv_stream_t stream, int iters, float* ms_per_op) {
+  if (!p || !ms_per_op || iters <= 0) return PV_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int n = (int)p->ops.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) PV_HIP_CHECK(hipEventCreate(&e));
+  for (int i = 0; i < n; ++i) ms_per_op[i] = 0.f;
+  int rc = PV_OK;
+  for (int it = 0; it < iters && rc == PV_OK; ++it) {
+    PV_HIP_CHECK(hipEventRecord(ev[0], s));
+    for (int i = 0; i < n; ++i) {
+      rc = run_op(p->ops[i], stream);
+      if (rc != PV_OK) break;
+      PV_HIP_CHECK(hipEventRecord(ev[i + 1], s));
+    }
+    if (rc != PV_OK) break;
+    PV_HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) {
+      float ms = 0.f;
+      PV_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+      ms_per_op[i] += ms / iters;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}

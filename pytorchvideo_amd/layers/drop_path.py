@@ -1,0 +1,22 @@
+"""Stochastic depth (reference: pytorchvideo/layers/drop_path.py). Identity in eval."""
+import torch
+import torch.nn as nn
+
+
+def drop_path(x, drop_prob=0.0, training=False):
+    if drop_prob == 0.0 or not training:
+        return x
+    keep = 1.0 - drop_prob
+    shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+    mask = keep + torch.rand(shape, dtype=x.dtype, device=x.device)
+    mask.floor_()
+    return x.div(keep) * mask
+
+
+class DropPath(nn.Module):
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        return drop_path(x, self.drop_prob, self.training)

@@ -1,0 +1,6 @@
+from .head import create_res_basic_head, create_vit_basic_head, ResNetBasicHead  # noqa
+from .net import MultiPathWayWithFuse, Net  # noqa
+from .resnet import BottleneckBlock, create_bottleneck_block, create_resnet  # noqa
+from .stem import create_conv_patch_embed, create_res_basic_stem, ResNetBasicStem  # noqa
+from .weight_init import init_net_weights  # noqa
+from .x3d import create_x3d  # noqa
