@@ -1,0 +1,187 @@
+"""Forward-throughput benchmark of the MI355X path (clips/s), one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload x3d_m|x3d_l|slowfast_r50|mvit_b_32x3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward of the hot path over one batch of synthetic clips that is already
+resident in HBM in the reference's own layout ([B,3,T,H,W], bf16); every rank processes a
+fixed per-GPU batch (weak scaling) and the step ends with the single head collective
+(all_gather of the [B_local, 400] fp32 logits).  Rank 0 prints ONE JSON line.
+
+N=1 default workload = BASELINE.json configs[1]: X3D-M, bf16, [32,3,16,224,224].
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_TFS = 2500.0    # dense bf16
+
+# algorithmic FLOPs / bytes per clip (probe of the reference op graph)
+WORKLOADS = {
+    "x3d_m": dict(batch=32, gflop=9.465, mb=365.0, desc="create_x3d(input_clip_length=16,input_crop_size=224) [B,3,16,224,224]"),
+    "x3d_l": dict(batch=32, gflop=18.325, mb=604.0, desc="create_x3d(16,224,depth_factor=5.0) [B,3,16,224,224]"),
+}
+
+
+def build_model(name, batch, device, dtype):
+    from pytorchvideo_amd.accelerator import convert_to_deployable_form, transmute_model
+    from pytorchvideo_amd.utils import randomize_norm_stats
+    torch.manual_seed(0)
+    if name == "x3d_m":
+        from pytorchvideo_amd.models import create_x3d
+        model = create_x3d(input_clip_length=16, input_crop_size=224)
+        shape = (batch, 3, 16, 224, 224)
+    elif name == "x3d_l":
+        from pytorchvideo_amd.models import create_x3d
+        model = create_x3d(input_clip_length=16, input_crop_size=224, depth_factor=5.0)
+        shape = (batch, 3, 16, 224, 224)
+    else:
+        raise SystemExit("unknown workload %s" % name)
+    randomize_norm_stats(model, 0)
+    model.eval()
+    g = torch.Generator(device="cpu").manual_seed(1234 + int(os.environ.get("RANK", "0")))
+    x = torch.randn(shape, generator=g).to(dtype).to(device)
+    transmute_model(model, "mi355x")
+    deployed = convert_to_deployable_form(model, x, dtype=dtype)
+    return model, deployed, x
+
+
+def cpu_baseline(name):
+    """The oracle (a CPU port of the reference forward) timed on this box's host cores, on a
+    bounded sample of the same workload.  Baseline, not target."""
+    from oracle import functional as OF
+    from oracle.weights import reference_style_fill
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    if name in ("x3d_m", "x3d_l"):
+        from pytorchvideo_amd.models import create_x3d
+        kw = dict(input_clip_length=16, input_crop_size=224)
+        if name == "x3d_l":
+            kw["depth_factor"] = 5.0
+        m = create_x3d(**kw)
+        reference_style_fill(m, 0).eval()
+        sd = m.state_dict()
+        b = 4
+        x = torch.randn(b, 3, 16, 224, 224)
+        fn = lambda: OF.x3d_forward(sd, x, 16, 224)  # noqa: E731
+    else:
+        return None
+    with torch.no_grad():
+        fn()
+        best = 1e30
+        for _ in range(2):
+            t0 = time.perf_counter()
+            fn()
+            best = min(best, time.perf_counter() - t0)
+    return {"value": round(b / best, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "%d clips, fp32, torch-CPU oracle (oracle/functional.py), best of 2" % b}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="x3d_m")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    from pytorchvideo_amd.parallel import gather_logits
+
+    wl = WORKLOADS[args.workload]
+    batch = args.batch or wl["batch"]
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    _, model, x = build_model(args.workload, batch, device, dtype)
+    if args.no_graph:
+        model.__dict__["_pv_use_graph"] = False
+
+    def step():
+        return gather_logits(model(x), global_batch=batch * world)
+
+    for _ in range(args.warmup):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert out.shape == (batch * world, 400) and torch.isfinite(out).all()
+
+    # per-kernel device time (HIP events on the launch stream, inside this process)
+    sess = model._pv_session
+    prof = sess.profile(iters=3)
+    agg = {}
+    for label, kind, ms, alg_bytes, flops in prof:
+        a = agg.setdefault(label.split(".")[0] if label.startswith("conv_b") else label, [0, 0.0, 0, 0])
+        a[0] += 1
+        a[1] += ms
+        a[2] += alg_bytes
+        a[3] += flops
+    total_kernel_ms = sum(v[1] for v in agg.values())
+    dom_label, dom = max(agg.items(), key=lambda kv: kv[1][1])
+    achieved = dom[2] / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        clips_s = batch * world * args.steps / elapsed
+        line = {
+            "metric": "clips/sec forward", "value": round(clips_s, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "per_gpu_batch": batch,
+                       "global_batch": batch * world, "parallelism": "dp%d (batch-sharded, logits all_gather)" % world,
+                       "weights": "random-init, randomised BN stats", "hip_graph": not args.no_graph},
+            "roofline": {
+                "bound": "hbm", "kernel": dom_label, "launches_per_step": dom[0],
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel_ms_per_step": round(dom[1], 4), "all_kernels_ms_per_step": round(total_kernel_ms, 4),
+                "model_hbm_frac": round(clips_s / world * wl["mb"] * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
+                "model_mfma_frac": round(clips_s / world * wl["gflop"] * 1e9 / (MFMA_PEAK_TFS * 1e12), 4),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        if os.environ.get("PV_BENCH_VERBOSE"):
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print("  %-16s n=%3d %8.3f ms  %8.1f GB/s  %7.2f TF/s" % (
+                    k, v[0], v[1], v[2] / max(v[1], 1e-9) / 1e6, v[3] / max(v[1], 1e-9) / 1e9), file=sys.stderr)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""CPU restatement of the reference forward path (TEST INFRASTRUCTURE -- the checker, never
+the product).  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg
+may import this module.
+
+Plain functional fp32 (or fp64) PyTorch-CPU arithmetic driven directly by a reference
+`state_dict` -- no nn.Module of this package is involved, so it is an independent check of
+the host mirror, of BN folding / weight packing and of the HIP kernels.  Every function
+cites the reference code it follows.  Pinned against golden vectors produced by the real
+reference (tests/golden/make_golden.py, run where /root/reference exists).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _bn(x, sd, p, eps=1e-5):
+    """BatchNorm3d in eval mode: (x-mean)/sqrt(var+eps)*gamma+beta (torch semantics)."""
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd.get(p + ".weight"),
+                        sd.get(p + ".bias"), training=False, eps=eps)
+
+
+def _has(sd, p):
+    return (p + ".weight") in sd
+
+
+def swish(x):
+    """x*sigmoid(x) (pytorchvideo/layers/swish.py:21-25)."""
+    return x * torch.sigmoid(x)
+
+
+def round_width(width, multiplier, min_width=8, divisor=8):
+    """pytorchvideo/layers/utils.py:19-39 (ceil=False branch)."""
+    if not multiplier:
+        return width
+    width *= multiplier
+    min_width = min_width or divisor
+    out = max(min_width, int(width + divisor / 2) // divisor * divisor)
+    if out < 0.9 * width:
+        out += divisor
+    return int(out)
+
+
+# ----------------------------------------------------------------------------- X3D
+def x3d_stem(sd, x, p="blocks.0"):
+    """create_x3d_stem (models/x3d.py:19-102) -> Conv2plus1d.forward (layers/convolutions.py:232-237)
+    -> ResNetBasicStem.forward (models/stem.py:252-260).  The slot called conv_t holds the
+    1x3x3 *spatial* conv and conv_xy the depthwise 5x1x1 *temporal* conv (x3d.py:83-88)."""
+    w = sd[p + ".conv.conv_t.weight"]
+    x = F.conv3d(x, w, stride=(1, 2, 2), padding=(0, w.shape[3] // 2, w.shape[4] // 2))
+    w = sd[p + ".conv.conv_xy.weight"]
+    x = F.conv3d(x, w, stride=1, padding=(w.shape[2] // 2, 0, 0), groups=w.shape[0])
+    return F.relu(_bn(x, sd, p + ".norm"))
+
+
+def squeeze_excite(sd, x, p):
+    """fvcore SqueezeExcitation (restated; see pytorchvideo_amd/layers/squeeze_excitation.py):
+    x * sigmoid(W2 relu(W1 mean_{T,H,W}(x) + b1) + b2)."""
+    m = x.mean(dim=[2, 3, 4], keepdim=True)
+    h = F.relu(F.conv3d(m, sd[p + ".block.0.weight"], sd[p + ".block.0.bias"]))
+    return x * torch.sigmoid(F.conv3d(h, sd[p + ".block.2.weight"], sd[p + ".block.2.bias"]))
+
+
+def x3d_res_block(sd, x, p, stride):
+    """create_x3d_res_block (x3d.py:231-324) + BottleneckBlock.forward (resnet.py:1345-1365)
+    + ResBlock.forward (resnet.py:1179-1189)."""
+    b = p + ".branch2"
+    if _has(sd, p + ".branch1_conv"):
+        sc = F.conv3d(x, sd[p + ".branch1_conv.weight"], stride=stride)
+        if _has(sd, p + ".branch1_norm"):
+            sc = _bn(sc, sd, p + ".branch1_norm")
+    else:
+        sc = x
+    y = F.relu(_bn(F.conv3d(x, sd[b + ".conv_a.weight"]), sd, b + ".norm_a"))
+    w = sd[b + ".conv_b.weight"]
+    y = F.conv3d(y, w, stride=stride, padding=[k // 2 for k in w.shape[2:]], groups=w.shape[0])
+    y = _bn(y, sd, b + ".norm_b.0")
+    if (b + ".norm_b.1.block.0.weight") in sd:
+        y = squeeze_excite(sd, y, b + ".norm_b.1")
+    y = swish(y)
+    y = _bn(F.conv3d(y, sd[b + ".conv_c.weight"]), sd, b + ".norm_c")
+    return F.relu(sc + y)
+
+
+def x3d_head(sd, x, p, pool_kernel):
+    """ProjectedPool.forward (x3d.py:791-806) + ResNetBasicHead.forward (models/head.py:371-391),
+    head_activation=None (create_x3d default, x3d.py:577)."""
+    x = F.relu(_bn(F.conv3d(x, sd[p + ".pool.pre_conv.weight"]), sd, p + ".pool.pre_norm"))
+    x = F.avg_pool3d(x, pool_kernel, stride=1)
+    x = F.relu(F.conv3d(x, sd[p + ".pool.post_conv.weight"]))
+    x = F.linear(x.permute(0, 2, 3, 4, 1), sd[p + ".proj.weight"], sd[p + ".proj.bias"]).permute(0, 4, 1, 2, 3)
+    return x.mean(dim=[2, 3, 4])
+
+
+def x3d_forward(sd, x, input_clip_length, input_crop_size, return_blocks=False):
+    """create_x3d (x3d.py:539-739) with default strides; stage depths are read off the
+    state_dict.  Returns logits (and the six block outputs)."""
+    outs = []
+    x = x3d_stem(sd, x)
+    outs.append(x)
+    for s in range(1, 5):
+        i = 0
+        while ("blocks.%d.res_blocks.%d.branch2.conv_a.weight" % (s, i)) in sd:
+            x = x3d_res_block(sd, x, "blocks.%d.res_blocks.%d" % (s, i), (1, 2, 2) if i == 0 else (1, 1, 1))
+            i += 1
+        outs.append(x)
+    side = int(math.ceil(input_crop_size / 32))
+    x = x3d_head(sd, x, "blocks.5", (input_clip_length, side, side))
+    outs.append(x)
+    return (x, outs) if return_blocks else x

@@ -58,3 +58,35 @@ def seeded_input(shape, seed=0, dist="randn"):
     if dist == "randn":
         return torch.randn(shape, generator=g)
     return torch.rand(shape, generator=g)
+
+
+@torch.no_grad()
+def reference_style_fill(model, seed=0):
+    """The reference tests' own de-degeneration: keep the factory's default conv/linear init,
+    randomise every BatchNorm with the `rand_init_bn` recipe of reference
+    tests/test_fuse_bn.py:58-63 (weight~U(0.5,1.5), bias~U(-0.5,0.5), running_var~U(0.5,1.5),
+    running_mean~U(-0.5,0.5)) and give the final Linear a non-trivial scale (std 0.05; the
+    default 0.01 makes logits ~5e-3 and an absolute tolerance vacuous).
+    Key-addressed like deterministic_fill, so it reproduces across processes."""
+    import torch.nn as nn
+    for name, mod in model.named_modules():
+        if isinstance(mod, nn.modules.batchnorm._BatchNorm):
+            g = _gen(name, seed)
+            mod.weight.copy_(_uniform(mod.weight.shape, 0.5, 1.5, g))
+            mod.bias.copy_(_uniform(mod.bias.shape, -0.5, 0.5, g))
+            mod.running_var.copy_(_uniform(mod.running_var.shape, 0.5, 1.5, g))
+            mod.running_mean.copy_(_uniform(mod.running_mean.shape, -0.5, 0.5, g))
+        elif isinstance(mod, (nn.Conv3d, nn.Linear)):
+            g = _gen(name, seed)
+            fan_out_std = None
+            if isinstance(mod, nn.Linear) and name.endswith("proj") and mod.out_features >= 100:
+                fan_out_std = 0.05
+            if isinstance(mod, nn.Conv3d):
+                # c2_msra_fill: N(0, sqrt(2/fan_out))
+                fan_out = mod.out_channels * mod.kernel_size[0] * mod.kernel_size[1] * mod.kernel_size[2] // mod.groups
+                mod.weight.copy_(torch.randn(mod.weight.shape, generator=g) * (2.0 / fan_out) ** 0.5)
+            elif fan_out_std is not None:
+                mod.weight.copy_(torch.randn(mod.weight.shape, generator=g) * fan_out_std)
+            if mod.bias is not None and isinstance(mod, nn.Conv3d):
+                mod.bias.copy_(_uniform(mod.bias.shape, -0.1, 0.1, g))
+    return model

@@ -1,0 +1,98 @@
+"""Host-side logic that needs no GPU: factory API surface (shapes, errors, state_dict keys),
+the transmuter/convert plumbing, BN folding, weight packing and the arena planner."""
+import pytest
+import torch
+import torch.nn as nn
+
+from pytorchvideo_amd.accelerator import (EFFICIENT_BLOCK_TRANSMUTER_REGISTRY, EfficientBlockBase,
+                                          transmute_model)
+from pytorchvideo_amd.accelerator.mi355x import emit as E
+from pytorchvideo_amd.accelerator.mi355x.blocks import Mi355xBlock
+from pytorchvideo_amd.accelerator.mi355x.session import Session, _Arena
+from pytorchvideo_amd.models import create_x3d
+
+
+def test_create_x3d_config1_shape_and_errors():
+    # reference tests/test_models_x3d.py:62-80,130-135
+    m = create_x3d(model_num_class=400, input_clip_length=4, input_crop_size=160).eval()
+    with torch.no_grad():
+        assert m(torch.rand(2, 3, 4, 160, 160)).shape == (2, 400)
+        with pytest.raises(RuntimeError):
+            m(torch.rand(2, 4, 4, 160, 160))  # wrong channel count
+    with pytest.raises(AssertionError):
+        create_x3d(input_clip_length=4, input_crop_size=16)
+
+
+def test_transmute_keeps_state_dict_and_original_form():
+    torch.manual_seed(0)
+    m = create_x3d(input_clip_length=4, input_crop_size=64).eval()
+    keys = list(m.state_dict().keys())
+    x = torch.rand(1, 3, 4, 64, 64)
+    with torch.no_grad():
+        want = m(x)
+    assert "mi355x" in EFFICIENT_BLOCK_TRANSMUTER_REGISTRY
+    transmute_model(m, "mi355x")
+    assert all(isinstance(b, Mi355xBlock) and isinstance(b, EfficientBlockBase) for b in m.blocks)
+    assert list(m.state_dict().keys()) == keys
+    with torch.no_grad():
+        assert torch.equal(m(x), want)  # original form = identical maths
+    # strict load of a reference-keyed checkpoint still works
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()}, strict=True)
+
+
+def test_transmuter_declines_what_it_does_not_know():
+    # unknown activation / norm -> left in place (reference convention: return None)
+    m = create_x3d(input_clip_length=4, input_crop_size=64, activation=nn.Tanh)
+    transmute_model(m, "mi355x")
+    assert not isinstance(m.blocks[0], Mi355xBlock)
+    assert not isinstance(m.blocks[1], Mi355xBlock)
+    with pytest.raises(AssertionError):
+        transmute_model(m, "no_such_device")
+
+
+def test_plan_build_without_gpu_counts_ops():
+    m = create_x3d(input_clip_length=4, input_crop_size=160).eval()
+    transmute_model(m, "mi355x")
+    sess, cur = Session(dtype=torch.bfloat16), None
+    for i, b in enumerate(m.blocks):
+        b.convert((2, 3, 4, 160, 160) if i == 0 else None, session=sess, input_ref=cur)
+        cur = b._out_ref
+    labels = [o[3] for o in sess.ops]
+    assert labels.count("conv_a") == 26 and labels.count("conv_c") == 26
+    assert labels.count("se_gate") == 15  # SE in every other block: 2+3+6+4
+    assert (cur.B, cur.C, cur.f32) == (2, 400, True)
+    with pytest.raises(AssertionError):
+        m.blocks[0].convert((2, 3, 4, 160, 160), session=sess)  # no double convert
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            sess.finalize()  # no GPU -> loud failure, never a CPU fallback
+
+
+def test_fold_norm_matches_batchnorm_eval():
+    bn = nn.BatchNorm3d(7).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5), bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.5, 0.5), bn.running_var.uniform_(0.5, 1.5)
+    bias = torch.randn(7)
+    scale, shift = E.fold_norm(bn, 7, bias)
+    x = torch.randn(2, 7, 3, 4, 5)
+    with torch.no_grad():
+        want = bn(x + bias.view(1, 7, 1, 1, 1))
+    got = x * scale.view(1, 7, 1, 1, 1) + shift.view(1, 7, 1, 1, 1)
+    assert torch.allclose(got, want, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        E.fold_norm(bn, 8)
+
+
+def test_arena_reuses_and_coalesces():
+    a = _Arena()
+    o1, o2, o3 = a.alloc(1000), a.alloc(5000), a.alloc(300)
+    assert len({o1, o2, o3}) == 3 and all(o % 256 == 0 for o in (o1, o2, o3))
+    peak = a.peak
+    a.release(o2)
+    assert a.alloc(4000) == o2            # first fit into the hole
+    a.release(o1)
+    a.release(o3)
+    assert a.peak == peak
+    big = a.alloc(2 * peak)               # must not overlap live blocks
+    assert big >= o2 + 4096 or big + 2 * peak <= o2
