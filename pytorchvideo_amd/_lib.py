@@ -125,6 +125,10 @@ def lib():
             raise PvError(
                 "libpv_mi355x.so is not built (%s). Run `python -m pytorchvideo_amd.csrc.build`; "
                 "the MI355X deploy form has no CPU fallback." % LIB_PATH)
+        # torch ships its own libamdhip64.so.7; import it FIRST so that our library binds to the
+        # HIP runtime torch already initialised (two runtimes in one process cannot share
+        # device pointers or streams).
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, res, args in _SYMBOLS:
             fn = getattr(h, name)  # AttributeError if a declared symbol is not exported

@@ -122,11 +122,21 @@ extern "C" int pv_plan_launch(pv_plan* p, pv_stream_t stream) {
 extern "C" int pv_plan_graph_build(pv_plan* p, pv_stream_t stream) {
   if (!p) return PV_ERR_INVALID;
   drop_graph(p);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  PV_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-  const int r = pv_plan_launch(p, stream);
+  // Capture on a private non-blocking stream: the caller's stream may be the legacy default
+  // stream (torch's current stream usually is), which cannot be captured.  The instantiated
+  // graph can then be launched into any stream, the default one included.
+  (void)stream;
+  hipStream_t cs = nullptr;
+  PV_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+  hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    (void)hipStreamDestroy(cs);
+    return pv_set_hip_error(e, "hipStreamBeginCapture");
+  }
+  const int r = pv_plan_launch(p, cs);
   hipGraph_t g = nullptr;
-  const hipError_t e = hipStreamEndCapture(s, &g);
+  e = hipStreamEndCapture(cs, &g);
+  (void)hipStreamDestroy(cs);
   if (r != PV_OK) {
     if (g) (void)hipGraphDestroy(g);
     return r;

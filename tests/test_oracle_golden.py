@@ -9,6 +9,7 @@ import torch
 from oracle import functional as OF
 from oracle.weights import deterministic_fill, seeded_input
 
+TOL = 1e-5  # relative to abs-max
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -34,10 +35,11 @@ def test_x3d_xs_oracle_matches_reference_golden():
     x = seeded_input(g["input_shape"], g["seed"])
     logits, blocks = OF.x3d_forward(m.state_dict(), x, g["cfg"]["input_clip_length"],
                                     g["cfg"]["input_crop_size"], return_blocks=True)
-    # same torch CPU kernels, same op order as the reference -> bit-exact
-    assert torch.equal(logits, g["logits"])
+    # same torch CPU kernels and op order as the reference: bit-exact on the machine that made
+    # the fixture, last-ulp differences on a host with another CPU (oneDNN picks other kernels)
+    assert (logits - g["logits"]).abs().max().item() <= TOL * g["logits"].abs().max().item()
     for t, fp in zip(blocks, g["blocks"]):
-        _check_fingerprint(t, fp)
+        _check_fingerprint(t, fp, TOL)
     # and the host mirror (original form) is the same function
     with torch.no_grad():
-        assert torch.equal(m(x), g["logits"])
+        assert (m(x) - g["logits"]).abs().max().item() <= TOL * g["logits"].abs().max().item()
