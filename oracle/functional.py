@@ -108,3 +108,114 @@ def x3d_forward(sd, x, input_clip_length, input_crop_size, return_blocks=False):
     x = x3d_head(sd, x, "blocks.5", (input_clip_length, side, side))
     outs.append(x)
     return (x, outs) if return_blocks else x
+
+
+# ----------------------------------------------------------------------------- ResNet family
+def _conv_same(x, w, stride, groups=1, bias=None):
+    """Conv3d with padding = kernel//2 per dim (how every builder on the path pads:
+    resnet.py:744-791, csn.py:160-170, r2plus1d.py:280-290, slowfast.py:209-229,672-694)."""
+    return F.conv3d(x, w, bias, stride=stride, padding=[k // 2 for k in w.shape[2:]], groups=groups)
+
+
+def res_basic_stem(sd, x, p, stride=(1, 2, 2), pool=True):
+    """create_res_basic_stem (models/stem.py:11-107) + ResNetBasicStem.forward (:252-260)."""
+    x = F.relu(_bn(_conv_same(x, sd[p + ".conv.weight"], stride), sd, p + ".norm"))
+    if pool:
+        x = F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    return x
+
+
+def bottleneck_res_block(sd, x, p, stride_a, stride_b):
+    """create_res_block (resnet.py:326-462) + create_bottleneck_block (:17-148) +
+    BottleneckBlock.forward (:1345-1365) + ResBlock.forward (:1179-1189).  conv_b may be
+    dense, depthwise (CSN, csn.py:169) or a Conv2plus1d (R(2+1)D, convolutions.py:232-237)."""
+    b = p + ".branch2"
+    if _has(sd, p + ".branch1_conv"):
+        s = tuple(a * c for a, c in zip(stride_a, stride_b))
+        sc = F.conv3d(x, sd[p + ".branch1_conv.weight"], stride=s)
+        if _has(sd, p + ".branch1_norm"):
+            sc = _bn(sc, sd, p + ".branch1_norm")
+    else:
+        sc = x
+    y = F.relu(_bn(_conv_same(x, sd[b + ".conv_a.weight"], stride_a), sd, b + ".norm_a"))
+    if (b + ".conv_b.conv_t.weight") in sd:  # (2+1)D: temporal conv -> BN -> ReLU -> spatial conv
+        y = _conv_same(y, sd[b + ".conv_b.conv_t.weight"], (stride_b[0], 1, 1))
+        y = F.relu(_bn(y, sd, b + ".conv_b.norm"))
+        y = _conv_same(y, sd[b + ".conv_b.conv_xy.weight"], (1, stride_b[1], stride_b[2]))
+    else:
+        w = sd[b + ".conv_b.weight"]
+        groups = y.shape[1] // w.shape[1]
+        y = _conv_same(y, w, stride_b, groups=groups)
+    y = F.relu(_bn(y, sd, b + ".norm_b"))
+    y = _bn(F.conv3d(y, sd[b + ".conv_c.weight"]), sd, b + ".norm_c")
+    return F.relu(sc + y)
+
+
+def res_stage(sd, x, p, stride_a, stride_b):
+    i = 0
+    while (p + ".res_blocks.%d.branch2.conv_a.weight" % i) in sd:
+        first = i == 0
+        x = bottleneck_res_block(sd, x, p + ".res_blocks.%d" % i, stride_a if first else (1, 1, 1),
+                                 stride_b if first else (1, 1, 1))
+        i += 1
+    return x
+
+
+def res_basic_head(sd, x, p, pool_kernel=None, softmax=False):
+    """create_res_basic_head (models/head.py:39-131) + ResNetBasicHead.forward (:371-391)."""
+    if pool_kernel is not None:
+        x = F.avg_pool3d(x, pool_kernel, stride=1)
+    x = F.linear(x.permute(0, 2, 3, 4, 1), sd[p + ".proj.weight"], sd[p + ".proj.bias"]).permute(0, 4, 1, 2, 3)
+    if softmax:
+        x = torch.softmax(x, dim=1)
+    return x.mean(dim=[2, 3, 4])
+
+
+def csn_forward(sd, x, head_pool_kernel=(1, 7, 7), spatial=(1, 2, 2, 2), temporal=(1, 2, 2, 2)):
+    """create_csn (models/csn.py:12-191): stem without pool, depthwise 3x3x3 conv_b."""
+    x = res_basic_stem(sd, x, "blocks.0", pool=False)
+    for i in range(4):
+        x = res_stage(sd, x, "blocks.%d" % (i + 1), (1, 1, 1), (temporal[i], spatial[i], spatial[i]))
+    return res_basic_head(sd, x, "blocks.5", head_pool_kernel)
+
+
+def r2plus1d_forward(sd, x, head_pool_kernel=(4, 7, 7), spatial=(2, 2, 2, 2), temporal=(1, 1, 2, 2)):
+    """create_r2plus1d (models/r2plus1d.py:123-313): stem without pool, head softmax."""
+    x = res_basic_stem(sd, x, "blocks.0", pool=False)
+    for i in range(4):
+        x = res_stage(sd, x, "blocks.%d" % (i + 1), (1, 1, 1), (temporal[i], spatial[i], spatial[i]))
+    return res_basic_head(sd, x, "blocks.5", head_pool_kernel, softmax=True)
+
+
+def slowfast_forward(sd, slow, fast, head_pool_kernels=((8, 7, 7), (32, 7, 7)), return_blocks=False):
+    """create_slowfast (models/slowfast.py:22-361) with default strides: per-pathway stems and
+    stages (MultiPathWayWithFuse.forward, models/net.py:107-122), FuseFastToSlow after the stem
+    and res2..res4 (slowfast.py:720-729; conv 7x1x1 stride (4,1,1) -> BN -> ReLU -> cat),
+    PoolConcatPathway (slowfast.py:608-620) and the basic head."""
+    outs = []
+
+    def fuse(s, f, p):
+        if (p + ".conv_fast_to_slow.weight") not in sd:
+            return s
+        w = sd[p + ".conv_fast_to_slow.weight"]
+        z = F.conv3d(f, w, stride=(4, 1, 1), padding=(w.shape[2] // 2, 0, 0))
+        z = F.relu(_bn(z, sd, p + ".norm"))
+        return torch.cat([s, z], 1)
+
+    s = res_basic_stem(sd, slow, "blocks.0.multipathway_blocks.0")
+    f = res_basic_stem(sd, fast, "blocks.0.multipathway_blocks.1")
+    s = fuse(s, f, "blocks.0.multipathway_fusion")
+    outs.append((s, f))
+    spatial = (1, 2, 2, 2)
+    for i in range(4):
+        p = "blocks.%d" % (i + 1)
+        s = res_stage(sd, s, p + ".multipathway_blocks.0", (1, 1, 1), (1, spatial[i], spatial[i]))
+        f = res_stage(sd, f, p + ".multipathway_blocks.1", (1, 1, 1), (1, spatial[i], spatial[i]))
+        s = fuse(s, f, p + ".multipathway_fusion")
+        outs.append((s, f))
+    x = torch.cat([F.avg_pool3d(s, head_pool_kernels[0], stride=1),
+                   F.avg_pool3d(f, head_pool_kernels[1], stride=1)], 1)
+    outs.append(x)
+    y = res_basic_head(sd, x, "blocks.6")
+    outs.append(y)
+    return (y, outs) if return_blocks else y

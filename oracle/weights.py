@@ -90,3 +90,20 @@ def reference_style_fill(model, seed=0):
             if mod.bias is not None and isinstance(mod, nn.Conv3d):
                 mod.bias.copy_(_uniform(mod.bias.shape, -0.1, 0.1, g))
     return model
+
+
+def quantize_like_kernels(sd, x=None):
+    """The bf16 deploy form stores dense-conv / linear weights and activations as bf16 while
+    depthwise filters, squeeze-excitation FCs, folded-BN vectors, LayerNorm parameters and
+    positional tables stay fp32.  Returns (sd', x') with exactly those tensors rounded to
+    bf16 (values kept in fp32 containers) so that the oracle evaluates *the same quantised
+    model*; what remains is the kernels' own arithmetic / activation-storage error."""
+    out = {}
+    for k, v in sd.items():
+        dense = v.dim() >= 2 and k.endswith("weight")
+        if dense and v.dim() == 5 and v.shape[1] == 1 and v.shape[0] > 1:
+            dense = False  # depthwise filter [C,1,kt,kh,kw]
+        if ".block." in k or "pos_embed" in k or "cls_token" in k:
+            dense = False  # SE FCs / positional tables stay fp32
+        out[k] = v.bfloat16().float() if dense else v
+    return (out, x.bfloat16().float()) if x is not None else out

@@ -80,6 +80,48 @@ class Mi355xBlock(EfficientBlockBase):
         return self._original_forward(*args, **kwargs)
 
 
+class Mi355xMultiPathBlock(Mi355xBlock):
+    """MultiPathWayWithFuse / PoolConcatPathway: list-of-tensors input (SlowFast)."""
+
+    def convert(self, input_blob_size, *args, session=None, input_ref=None, dtype=None, **kwargs):
+        assert self.convert_flag is False, "already converted, cannot be converted again"
+        self.eval()
+        sess = session
+        if sess is None:
+            sess = Session(dtype=dtype or torch.bfloat16)
+            self.__dict__["_owns_session"] = True
+        if input_ref is None:
+            # input_blob_size: list of (B,C,T,H,W), one per pathway
+            input_ref = [sess.alloc_act(int(s[0]), int(s[2]), int(s[3]), int(s[4]), int(s[1])) for s in input_blob_size]
+        first = len(sess.ops)
+        pre = None
+        if self._orig_cls.__name__ == "PoolConcatPathway":
+            out_ref = E.emit_pool_concat(sess, self, list(input_ref))
+            if self.retain_list:
+                out_ref = [out_ref]
+        else:
+            out_ref, pre = E.emit_multipathway(sess, self, list(input_ref))
+        self.__dict__.update(_sess=sess, _in_ref=list(input_ref), _out_ref=out_ref, _pre_ref=pre,
+                             _op_range=(first, len(sess.ops)))
+        if self._owns_session:
+            sess.finalize()
+        self.__dict__["convert_flag"] = True
+
+    def _deploy_forward(self, x):
+        assert isinstance(x, list), "input for MultiPathWayWithFuse needs to be a list of tensors"
+        sess = self._sess
+        sess.finalize()
+        for t, ref in zip(x, self._in_ref):
+            if not sess.matches(t, ref):
+                sess.ingest(t, ref)
+        sess.launch(*self._op_range)
+        if getattr(self, "inplace", False) and self._pre_ref is not None:
+            for i, r in enumerate(self._pre_ref):  # the reference overwrites the caller's list (net.py:111-118)
+                x[i] = sess.view(r)
+        out = self._out_ref
+        return [sess.view(r) for r in out] if isinstance(out, list) else sess.view(out)
+
+
 # ------------------------------------------------------------------------- transmuters
 _SINGLE_IO = ("ResNetBasicStem", "ResStage", "ResBlock", "ResNetBasicHead")
 
@@ -165,6 +207,36 @@ def transmute_single_io(module: nn.Module):
     return Mi355xBlock(module)
 
 
+def transmute_multipath(module: nn.Module):
+    """SlowFast containers: MultiPathWayWithFuse (+FuseFastToSlow | Identity) and PoolConcatPathway."""
+    if isinstance(module, EfficientBlockBase):
+        return None
+    n = type(module).__name__
+    try:
+        if n == "MultiPathWayWithFuse":
+            for b in module.multipathway_blocks:
+                if b is not None and not (type(b).__name__ in ("ResNetBasicStem", "ResStage") and _probe(b)):
+                    return None
+            f = module.multipathway_fusion
+            if f is None or isinstance(f, nn.Identity):
+                return Mi355xMultiPathBlock(module)
+            if type(f).__name__ != "FuseFastToSlow" or len(module.multipathway_blocks) != 2:
+                return None
+            if E.check_conv3d(f.conv_fast_to_slow):
+                return None
+            _check_norm(f.norm), E.act_code(f.activation)
+            return Mi355xMultiPathBlock(module)
+        if n == "PoolConcatPathway":
+            if module.pool is None or module.dim != 1:
+                return None
+            if not all(isinstance(p, (nn.AvgPool3d, nn.MaxPool3d, nn.AdaptiveAvgPool3d)) for p in module.pool):
+                return None
+            return Mi355xMultiPathBlock(module)
+    except (E.Unsupported, AttributeError):
+        return None
+    return None
+
+
 def transmute_pool(module: nn.Module):
     """Bare pooling layers that sit between blocks (e.g. create_resnet's stage1_pool)."""
     if isinstance(module, (nn.MaxPool3d, nn.AvgPool3d)) and not getattr(module, "ceil_mode", False):
@@ -172,4 +244,4 @@ def transmute_pool(module: nn.Module):
     return None
 
 
-EFFICIENT_BLOCK_TRANSMUTER_MI355X = [transmute_single_io, transmute_pool]
+EFFICIENT_BLOCK_TRANSMUTER_MI355X = [transmute_single_io, transmute_multipath, transmute_pool]

@@ -72,12 +72,14 @@ def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quant
         t0 = input_tensor if isinstance(input_tensor, torch.Tensor) else input_tensor[0]
         dtype = torch.bfloat16 if t0.dtype == torch.bfloat16 else torch.float32
     L.lib()  # fail early and loudly when the HIP library is not built
-    lut = _record_input_sizes(model, _one_clip(input_tensor))
+    lut = {}
+    if not _is_fusable_net(model):
+        lut = _record_input_sizes(model, _one_clip(input_tensor))
     converted = deepcopy(model)
     converted.eval()
     sess = Session(dtype=dtype)
     batch = _batch_of(input_tensor)
-    fused = _try_fuse_net(converted, lut, batch, sess, dtype)
+    fused = _try_fuse_net(converted, lut, batch, sess, dtype, input_tensor)
     if not fused:
         _convert_children(converted, lut, batch, "", sess, dtype,
                           dict(convert_for_quantize=convert_for_quantize,
@@ -88,31 +90,52 @@ def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quant
     return converted
 
 
+def _is_fusable_net(model):
+    from .blocks import Mi355xBlock
+    blocks = getattr(model, "blocks", None)
+    return (type(model).__name__ == "Net" and blocks is not None and len(blocks) > 0
+            and all(isinstance(b, Mi355xBlock) for b in blocks))
+
+
 # ------------------------------------------------------------------ whole-Net fusion
-def _try_fuse_net(model, lut, batch, sess, dtype):
-    """`Net` (models/net.py:11-44) whose blocks are all Mi355xBlocks taking one tensor:
-    chain them inside the plan and make forward a single replay."""
+def _try_fuse_net(model, lut, batch, sess, dtype, input_tensor=None):
+    """`Net` (models/net.py:11-44) whose blocks are all MI355X blocks: chain them inside the
+    plan (block i+1 reads block i's arena buffers directly) and make forward one replay.
+    Handles single-tensor nets (X3D, CSN, R(2+1)D, ResNet) and list-input nets (SlowFast)."""
     from .blocks import Mi355xBlock
 
     blocks = getattr(model, "blocks", None)
     if type(model).__name__ != "Net" or blocks is None or len(blocks) == 0:
         return False
-    if not all(type(b) is Mi355xBlock for b in blocks):
+    if not all(isinstance(b, Mi355xBlock) for b in blocks):
         return False
-    size = lut.get(".blocks.0")
-    if size is None or len(size) != 5:
-        return False
-    cur = None
+    multi = isinstance(input_tensor, (list, tuple))
+    if multi:
+        size = [tuple(t.shape) for t in input_tensor]
+        if any(len(s) != 5 for s in size):
+            return False
+    else:
+        size = tuple(input_tensor.shape)
+        if len(size) != 5:
+            return False
+    cur, prev_owned = None, []
     for i, blk in enumerate(blocks):
-        blk.convert((batch,) + tuple(size[1:]) if i == 0 else None, session=sess, input_ref=cur, dtype=dtype)
-        if cur is not None and cur is not blocks[0]._in_ref:
-            sess.release(cur)  # its consumer has been emitted
+        blk.convert(size if i == 0 else None, session=sess, input_ref=cur, dtype=dtype)
+        if i > 0:
+            for r in prev_owned:  # consumers of the previous block's outputs are emitted
+                sess.release(r)
         cur = blk._out_ref
+        prev_owned = list(cur) if isinstance(cur, list) else [cur]
     first_in, last = blocks[0]._in_ref, blocks[-1]
 
     def fused_forward(self, x):
         s = self._pv_session
-        if not s.matches(x, first_in):
+        if multi:
+            assert isinstance(x, list), "input for MultiPathWayWithFuse needs to be a list of tensors"
+            for t, ref in zip(x, first_in):
+                if not s.matches(t, ref):
+                    s.ingest(t, ref)
+        elif not s.matches(x, first_in):
             s.ingest(x, first_in)
         s.launch(use_graph=self._pv_use_graph)
         out = last._out_ref

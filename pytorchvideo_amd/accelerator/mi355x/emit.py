@@ -229,7 +229,7 @@ def emit_se_gate(sess, se, psum, nblk, B, Cc, count):
     return gate
 
 
-def emit_pool(sess, pool, x, n_prefix=0, label="pool"):
+def emit_pool(sess, pool, x, n_prefix=0, out=None, label="pool"):
     """nn.MaxPool3d / nn.AvgPool3d / nn.AdaptiveAvgPool3d(1) -> pv_pool3d."""
     if isinstance(pool, nn.AdaptiveAvgPool3d):
         osz = _triple(pool.output_size)
@@ -258,7 +258,7 @@ def emit_pool(sess, pool, x, n_prefix=0, label="pool"):
                   _conv_out(x.W, k[2], s[2], p[2]))
     if min(To, Ho, Wo) <= 0:
         raise RuntimeError("pool output would be empty")
-    return emit_pool_raw(sess, x, k, s, p, mode, n_prefix=n_prefix, label=label)
+    return emit_pool_raw(sess, x, k, s, p, mode, n_prefix=n_prefix, out=out, label=label)
 
 
 def emit_pool_raw(sess, x, k, s, p, mode, n_prefix=0, out=None, label="pool"):
@@ -271,6 +271,8 @@ def emit_pool_raw(sess, x, k, s, p, mode, n_prefix=0, out=None, label="pool"):
             y = sess.alloc_act(x.B, To, Ho, Wo, x.C)
     else:
         y = out
+        if not n_prefix and ((y.B, y.T, y.H, y.W) != (x.B, To, Ho, Wo) or y.C != x.C):
+            raise RuntimeError("pool output buffer geometry mismatch")
     f = dict(x=x.ptr, y=y.ptr, x_bs=x.bs, y_bs=y.bs, ldx=x.ld, ldy=y.ld,
              B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, C=x.C, To=To, Ho=Ho, Wo=Wo,
              kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2], pt=p[0], ph=p[1], pw=p[2],
@@ -322,7 +324,7 @@ def emit_conv_b(sess, conv_b, x, norm_b, act_b):
     return y, None, L.ACT_NONE
 
 
-def emit_bottleneck(sess, bb, x, residual=None, final_act=L.ACT_NONE):
+def emit_bottleneck(sess, bb, x, residual=None, final_act=L.ACT_NONE, out=None):
     """BottleneckBlock.forward (resnet.py:1345-1365) with the block's residual join and
     final activation fused into conv_c's epilogue."""
     for name in ("conv_a", "conv_b", "conv_c"):
@@ -336,14 +338,14 @@ def emit_bottleneck(sess, bb, x, residual=None, final_act=L.ACT_NONE):
             (bb.conv_c.kernel_size != (1, 1, 1) or bb.conv_c.stride != (1, 1, 1) or _triple(bb.conv_c.padding) != (0, 0, 0)):
         raise Unsupported("SE block whose conv_c is not pointwise")
     c = emit_conv(sess, bb.conv_c, b, bb.norm_c, final_act, residual=residual, a_gate=gate, a_act=deferred,
-                  label="conv_c")
+                  out=out, label="conv_c")
     sess.release(b)
     if gate is not None:
         sess.release(gate)
     return c
 
 
-def emit_res_block(sess, rb, x):
+def emit_res_block(sess, rb, x, out=None):
     """ResBlock.forward (resnet.py:1179-1189): act(shortcut + branch2(x))."""
     if not is_add_fusion(rb.branch_fusion):
         raise Unsupported("branch_fusion is not a sum")
@@ -353,37 +355,41 @@ def emit_res_block(sess, rb, x):
         shortcut = x
     else:
         shortcut = emit_conv(sess, rb.branch1_conv, x, rb.branch1_norm, L.ACT_NONE, label="shortcut")
-    y = emit_bottleneck(sess, rb.branch2, x, residual=shortcut, final_act=act_code(rb.activation))
+    y = emit_bottleneck(sess, rb.branch2, x, residual=shortcut, final_act=act_code(rb.activation), out=out)
     if shortcut is not x:
         sess.release(shortcut)
     return y
 
 
-def emit_res_stage(sess, stage, x):
+def emit_res_stage(sess, stage, x, out=None):
+    """ResStage.forward; `out` (optional) receives the last block's output, e.g. a channel
+    slice of a wider buffer so that a later torch.cat costs nothing."""
     cur = x
-    for blk in stage.res_blocks:
+    n = len(stage.res_blocks)
+    for i, blk in enumerate(stage.res_blocks):
         if _cls_name(blk) != "ResBlock":
             raise Unsupported("stage element %s" % _cls_name(blk))
-        nxt = emit_res_block(sess, blk, cur)
+        nxt = emit_res_block(sess, blk, cur, out=out if i == n - 1 else None)
         if cur is not x:
             sess.release(cur)
         cur = nxt
     return cur
 
 
-def emit_stem(sess, stem, x):
+def emit_stem(sess, stem, x, out=None):
     """ResNetBasicStem.forward (stem.py:252-260); conv may be Conv3d or X3D's Conv2plus1d."""
     act = act_code(stem.activation)
     conv = stem.conv
     if _cls_name(conv) == "Conv2plus1d":
         first, second = (conv.conv_xy, conv.conv_t) if conv.conv_xy_first else (conv.conv_t, conv.conv_xy)
         mid = emit_conv(sess, first, x, conv.norm, act_code(conv.activation), label="stem.conv0")
-        y = emit_conv(sess, second, mid, stem.norm, act, label="stem.conv1")
+        y = emit_conv(sess, second, mid, stem.norm, act, out=out if stem.pool is None else None,
+                      label="stem.conv1")
         sess.release(mid)
     else:
-        y = emit_conv(sess, conv, x, stem.norm, act, label="stem.conv")
+        y = emit_conv(sess, conv, x, stem.norm, act, out=out if stem.pool is None else None, label="stem.conv")
     if stem.pool is not None:
-        p = emit_pool(sess, stem.pool, y, label="stem.pool")
+        p = emit_pool(sess, stem.pool, y, out=out, label="stem.pool")
         sess.release(y)
         y = p
     return y
@@ -450,6 +456,98 @@ def emit_res_head(sess, head, x):
     sess.add_op(L.OP_MEAN_ROWS, f, label="head.mean")
     sess.release(logits)
     return out
+
+
+# --------------------------------------------------------------------------- SlowFast
+def out_shape(m, x):
+    """(T,H,W,C) a single-IO module will produce for input `x`, by emitting into a scratch session."""
+    from .session import Session
+    scratch = Session(dtype=torch.bfloat16)
+    xin = scratch.alloc_act(x.B, x.T, x.H, x.W, x.C)
+    y = emit_module(scratch, m, xin)
+    return y.T, y.H, y.W, y.C
+
+
+def emit_multipathway(sess, mp, xs):
+    """MultiPathWayWithFuse.forward (models/net.py:107-122) with FuseFastToSlow
+    (models/slowfast.py:720-729): the lateral conv (7x1x1, temporal stride 4) + BN + ReLU
+    writes straight into the channel slice [C_slow, C_slow + 2*beta*C) of a slow-pathway
+    buffer that was allocated wide enough, and the slow pathway's own last kernel writes
+    the slice [0, C_slow) -- `torch.cat` (a full copy of the slow tensor in the reference)
+    costs nothing.  Returns ([outputs], [pre-fusion outputs])."""
+    blocks = list(mp.multipathway_blocks)
+    if len(xs) != len(blocks):
+        raise RuntimeError("pathway count mismatch")
+    fusion = mp.multipathway_fusion
+    fuse_kind = None
+    if fusion is None or isinstance(fusion, nn.Identity):
+        fuse_kind = "none"
+    elif _cls_name(fusion) == "FuseFastToSlow":
+        if len(blocks) != 2 or blocks[0] is None or blocks[1] is None:
+            raise Unsupported("FuseFastToSlow needs two live pathways")
+        fuse_kind = "fast_to_slow"
+    else:
+        raise Unsupported("fusion %s" % _cls_name(fusion))
+
+    if fuse_kind == "none":
+        outs = [emit_module(sess, b, x) if b is not None else x for b, x in zip(blocks, xs)]
+        return outs, outs
+
+    fast = emit_module(sess, blocks[1], xs[1])
+    conv = fusion.conv_fast_to_slow
+    check_conv3d(conv)
+    t_s, h_s, w_s, c_s = out_shape(blocks[0], xs[0])
+    c_f = conv.out_channels
+    if c_s % 8:
+        raise Unsupported("slow width %d not a multiple of 8 (channel-slice concat)" % c_s)
+    wide = sess.alloc_act(xs[0].B, t_s, h_s, w_s, c_s + c_f)
+    slow_slice = wide.channel_slice(0, c_s)
+    emit_module_out(sess, blocks[0], xs[0], slow_slice)
+    emit_conv(sess, conv, fast, fusion.norm, act_code(fusion.activation), out=wide.channel_slice(c_s, c_f),
+              label="lateral_fuse")
+    return [wide, fast], [slow_slice, fast]
+
+
+def emit_module_out(sess, m, x, out):
+    n = _cls_name(m)
+    if n == "ResNetBasicStem":
+        return emit_stem(sess, m, x, out=out)
+    if n == "ResStage":
+        return emit_res_stage(sess, m, x, out=out)
+    if n == "ResBlock":
+        return emit_res_block(sess, m, x, out=out)
+    raise Unsupported("no out= emitter for %s" % n)
+
+
+def emit_pool_concat(sess, pc, xs):
+    """PoolConcatPathway.forward (models/slowfast.py:608-620): every pathway's pool writes its
+    channel slice of one output buffer."""
+    if pc.dim != 1:
+        raise Unsupported("concat dim %d" % pc.dim)
+    live = [(i, x) for i, x in enumerate(xs) if x is not None]
+    shapes = []
+    for i, x in live:
+        pool = pc.pool[i] if pc.pool is not None else None
+        if pool is None:
+            shapes.append((x.T, x.H, x.W, x.C))
+        else:
+            shapes.append(out_shape(pool, x))
+    if len({s[:3] for s in shapes}) != 1:
+        raise RuntimeError("Sizes of tensors must match except in dimension 1")
+    total = sum(s[3] for s in shapes)
+    T, H, W = shapes[0][:3]
+    y = sess.alloc_act(live[0][1].B, T, H, W, total)
+    c0 = 0
+    for (i, x), shp in zip(live, shapes):
+        if c0 % 8:
+            raise Unsupported("concat offset %d not a multiple of 8" % c0)
+        pool = pc.pool[i] if pc.pool is not None else None
+        dst = y.channel_slice(c0, shp[3])
+        if pool is None:
+            raise Unsupported("concat without pooling")
+        emit_pool(sess, pool, x, out=dst, label="head.pool")
+        c0 += shp[3]
+    return y
 
 
 # --------------------------------------------------------------------------- dispatch

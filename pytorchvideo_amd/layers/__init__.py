@@ -3,3 +3,5 @@ from .drop_path import DropPath  # noqa
 from .squeeze_excitation import SqueezeExcitation  # noqa
 from .swish import Swish  # noqa
 from .utils import round_repeats, round_width, set_attributes  # noqa
+from .attention import Mlp, MultiScaleAttention, MultiScaleBlock  # noqa
+from .positional_encoding import SpatioTemporalClsPositionalEncoding  # noqa

@@ -4,3 +4,7 @@ from .resnet import BottleneckBlock, create_bottleneck_block, create_resnet  # n
 from .stem import create_conv_patch_embed, create_res_basic_stem, ResNetBasicStem  # noqa
 from .weight_init import init_net_weights  # noqa
 from .x3d import create_x3d  # noqa
+from .csn import create_csn  # noqa
+from .r2plus1d import create_r2plus1d  # noqa
+from .slowfast import create_slowfast  # noqa
+from .vision_transformers import create_multiscale_vision_transformers  # noqa

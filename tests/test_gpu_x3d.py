@@ -15,17 +15,13 @@ import torch
 import torch.nn.functional as F
 
 from oracle import functional as OF
-from oracle.weights import deterministic_fill, reference_style_fill, seeded_input
+from oracle.weights import deterministic_fill, quantize_like_kernels, reference_style_fill, seeded_input
 
 pytestmark = pytest.mark.gpu
 
 
 def _rel(got, want):
     return (got.float().cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
-
-
-def _bf16_sd(sd):
-    return {k: (v.bfloat16().float() if v.dim() >= 2 else v) for k, v in sd.items()}
 
 
 def _deploy(model, x, dtype):
@@ -61,7 +57,7 @@ def test_x3d_xs_bf16_matches_quantised_oracle():
     m = create_x3d(model_num_class=400, input_clip_length=4, input_crop_size=160)
     deterministic_fill(m, 0).eval()
     x = seeded_input((2, 3, 4, 160, 160), 0)
-    want_q = OF.x3d_forward(_bf16_sd(m.state_dict()), x.bfloat16().float(), 4, 160)
+    want_q = OF.x3d_forward(*quantize_like_kernels(m.state_dict(), x), 4, 160)
     dm = _deploy(m, x, torch.bfloat16)
     got = dm(x.cuda().bfloat16())
     assert _rel(got, want_q) <= 1e-2
@@ -89,7 +85,7 @@ def test_x3d_m_shape_bf16_sanity_and_determinism():
     m = create_x3d(input_clip_length=16, input_crop_size=224)
     reference_style_fill(m, 0).eval()
     x = seeded_input((2, 3, 16, 224, 224), 0)
-    want_q = OF.x3d_forward(_bf16_sd(m.state_dict()), x.bfloat16().float(), 16, 224)
+    want_q = OF.x3d_forward(*quantize_like_kernels(m.state_dict(), x), 16, 224)
     dm = _deploy(m, x, torch.bfloat16)
     a = dm(x.cuda().bfloat16()).clone()
     b = dm(x.cuda().bfloat16()).clone()
