@@ -1,6 +1,8 @@
-// placeholder until the fused attention kernel lands (same ABI)
+// Fused pooled attention (placeholder while the kernel is being written).
 #include "pv_common.h"
+
 extern "C" int pv_attention(const pv_attention_desc* d, pv_stream_t stream) {
-  (void)d; (void)stream;
+  (void)stream;
+  if (!d || !d->q || !d->k || !d->v || !d->o) return PV_ERR_INVALID;
   return PV_ERR_UNSUPPORTED;
 }
