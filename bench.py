@@ -29,29 +29,58 @@ MFMA_PEAK_TFS = 2500.0    # dense bf16
 
 # algorithmic FLOPs / bytes per clip (probe of the reference op graph)
 WORKLOADS = {
-    "x3d_m": dict(batch=32, gflop=9.465, mb=365.0, desc="create_x3d(input_clip_length=16,input_crop_size=224) [B,3,16,224,224]"),
-    "x3d_l": dict(batch=32, gflop=18.325, mb=604.0, desc="create_x3d(16,224,depth_factor=5.0) [B,3,16,224,224]"),
+    "x3d_m": dict(batch=32, gflop=9.465, mb=365.0, bound="hbm",
+                  desc="create_x3d(input_clip_length=16,input_crop_size=224) [B,3,16,224,224]"),
+    "x3d_l": dict(batch=32, gflop=18.325, mb=604.0, bound="hbm",
+                  desc="create_x3d(16,224,depth_factor=5.0) [B,3,16,224,224]"),
+    "slowfast_r50": dict(batch=16, gflop=131.42, mb=740.0, bound="mfma",
+                         desc="create_slowfast(model_depth=50) slow [B,3,8,256,256] + fast [B,3,32,256,256]"),
+    "mvit_b_32x3": dict(batch=8, gflop=339.92, mb=1465.0, bound="mfma",
+                        desc="create_multiscale_vision_transformers(**mvit_video_base_32x3_config) [B,3,32,224,224]"),
 }
+
+
+def make_model(name):
+    """(original-form model, input shape(s), oracle forward) of a workload."""
+    from oracle import functional as OF  # only used by the cpu_baseline leg
+    if name in ("x3d_m", "x3d_l"):
+        from pytorchvideo_amd.models import create_x3d
+        kw = dict(input_clip_length=16, input_crop_size=224)
+        if name == "x3d_l":
+            kw["depth_factor"] = 5.0
+        return create_x3d(**kw), (3, 16, 224, 224), lambda sd, x: OF.x3d_forward(sd, x, 16, 224)
+    if name == "slowfast_r50":
+        from pytorchvideo_amd.models import create_slowfast
+        return (create_slowfast(model_depth=50), [(3, 8, 256, 256), (3, 32, 256, 256)],
+                lambda sd, x: OF.slowfast_forward(sd, x[0], x[1]))
+    if name == "mvit_b_32x3":
+        from pytorchvideo_amd.models import create_multiscale_vision_transformers
+        from pytorchvideo_amd.models.hub import mvit_video_base_32x3_config as cfg
+        return (create_multiscale_vision_transformers(**cfg), (3, 32, 224, 224),
+                lambda sd, x: OF.mvit_forward(sd, x, cfg))
+    raise SystemExit("unknown workload %s" % name)
+
+
+def synth_input(shape, batch, seed):
+    """Synthetic clips; SlowFast's slow pathway is the temporally subsampled fast pathway
+    (PackPathway: uniform_temporal_subsample, transforms/functional.py:134-160)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    if isinstance(shape, list):
+        fast = torch.randn((batch,) + tuple(shape[1]), generator=g)
+        idx = torch.linspace(0, shape[1][1] - 1, shape[0][1]).long()
+        return [fast[:, :, idx].contiguous(), fast]
+    return torch.randn((batch,) + tuple(shape), generator=g)
 
 
 def build_model(name, batch, device, dtype):
     from pytorchvideo_amd.accelerator import convert_to_deployable_form, transmute_model
     from pytorchvideo_amd.utils import randomize_norm_stats
     torch.manual_seed(0)
-    if name == "x3d_m":
-        from pytorchvideo_amd.models import create_x3d
-        model = create_x3d(input_clip_length=16, input_crop_size=224)
-        shape = (batch, 3, 16, 224, 224)
-    elif name == "x3d_l":
-        from pytorchvideo_amd.models import create_x3d
-        model = create_x3d(input_clip_length=16, input_crop_size=224, depth_factor=5.0)
-        shape = (batch, 3, 16, 224, 224)
-    else:
-        raise SystemExit("unknown workload %s" % name)
+    model, shape, _ = make_model(name)
     randomize_norm_stats(model, 0)
     model.eval()
-    g = torch.Generator(device="cpu").manual_seed(1234 + int(os.environ.get("RANK", "0")))
-    x = torch.randn(shape, generator=g).to(dtype).to(device)
+    x = synth_input(shape, batch, 1234 + int(os.environ.get("RANK", "0")))
+    x = [t.to(dtype).to(device) for t in x] if isinstance(x, list) else x.to(dtype).to(device)
     transmute_model(model, "mi355x")
     deployed = convert_to_deployable_form(model, x, dtype=dtype)
     return model, deployed, x
@@ -60,29 +89,20 @@ def build_model(name, batch, device, dtype):
 def cpu_baseline(name):
     """The oracle (a CPU port of the reference forward) timed on this box's host cores, on a
     bounded sample of the same workload.  Baseline, not target."""
-    from oracle import functional as OF
     from oracle.weights import reference_style_fill
     # big hosts (256 hw threads) run torch-CPU slower when oversubscribed: cap the thread count
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    if name in ("x3d_m", "x3d_l"):
-        from pytorchvideo_amd.models import create_x3d
-        kw = dict(input_clip_length=16, input_crop_size=224)
-        if name == "x3d_l":
-            kw["depth_factor"] = 5.0
-        m = create_x3d(**kw)
-        reference_style_fill(m, 0).eval()
-        sd = m.state_dict()
-        b = 2
-        x = torch.randn(b, 3, 16, 224, 224)
-        fn = lambda: OF.x3d_forward(sd, x, 16, 224)  # noqa: E731
-    else:
-        return None
+    m, shape, oracle_fn = make_model(name)
+    reference_style_fill(m, 0).eval()
+    sd = m.state_dict()
+    b = {"x3d_m": 2, "x3d_l": 2, "slowfast_r50": 1, "mvit_b_32x3": 1}[name]
+    x = synth_input(shape, b, 7)
     with torch.no_grad():
         best = 1e30
         for _ in range(2):
             t0 = time.perf_counter()
-            fn()
+            oracle_fn(sd, x)
             best = min(best, time.perf_counter() - t0)
     return {"value": round(b / best, 3), "unit": "clips/s", "cores": cores, "kind": "port",
             "sample": "%d clips, fp32, torch-CPU oracle (oracle/functional.py), %d threads, best of 2" % (b, cores)}
@@ -118,7 +138,7 @@ def main():
         model.__dict__["_pv_use_graph"] = False
 
     def step():
-        return gather_logits(model(x), global_batch=batch * world)
+        return gather_logits(model(list(x) if isinstance(x, list) else x), global_batch=batch * world)
 
     for _ in range(args.warmup):
         out = step()
@@ -150,7 +170,11 @@ def main():
         a[3] += flops
     total_kernel_ms = sum(v[1] for v in agg.values())
     dom_label, dom = max(agg.items(), key=lambda kv: kv[1][1])
-    achieved = dom[2] / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
+    # the dominant kernel's roofline: HBM when its arithmetic intensity is below the ridge
+    # (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B), MFMA otherwise
+    dom_gbs = dom[2] / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
+    dom_tfs = dom[3] / (dom[1] * 1e-3) / 1e12 if dom[1] > 0 else 0.0
+    mfma_bound = dom[2] > 0 and dom[3] / dom[2] > MFMA_PEAK_TFS * 1e12 / (HBM_PEAK_GBS * 1e9)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -164,9 +188,10 @@ def main():
                        "global_batch": batch * world, "parallelism": "dp%d (batch-sharded, logits all_gather)" % world,
                        "weights": "random-init, randomised BN stats", "hip_graph": not args.no_graph},
             "roofline": {
-                "bound": "hbm", "kernel": dom_label, "launches_per_step": dom[0],
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bound": "mfma" if mfma_bound else "hbm", "kernel": dom_label, "launches_per_step": dom[0],
+                "achieved": round(dom_tfs if mfma_bound else dom_gbs, 1),
+                "peak": MFMA_PEAK_TFS if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                "frac": round(dom_tfs / MFMA_PEAK_TFS if mfma_bound else dom_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel_ms_per_step": round(dom[1], 4), "all_kernels_ms_per_step": round(total_kernel_ms, 4),
                 "model_hbm_frac": round(clips_s / world * wl["mb"] * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
                 "model_mfma_frac": round(clips_s / world * wl["gflop"] * 1e9 / (MFMA_PEAK_TFS * 1e12), 4),

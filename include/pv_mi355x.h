@@ -110,6 +110,8 @@ typedef struct pv_dwconv3d_desc {
   int32_t w_mod;             /* 0, or weights indexed by (c % w_mod)             */
   int32_t act;
   int32_t dtype;
+  int32_t n_prefix;          /* rows before the grid in each batch item (the cls    */
+                             /* token of layers/attention.py:185-186) copied verbatim */
 } pv_dwconv3d_desc;
 int pv_dwconv3d(const pv_dwconv3d_desc* d, pv_stream_t stream);
 int pv_dwconv3d_psum_blocks(const pv_dwconv3d_desc* d);

@@ -219,3 +219,147 @@ def slowfast_forward(sd, slow, fast, head_pool_kernels=((8, 7, 7), (32, 7, 7)), 
     y = res_basic_head(sd, x, "blocks.6")
     outs.append(y)
     return (y, outs) if return_blocks else y
+
+
+# ----------------------------------------------------------------------------- MViT
+def _ln(x, sd, p, eps=1e-6):
+    """nn.LayerNorm(eps=1e-6) as built at models/vision_transformers.py:333-335."""
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def mvit_schedule(cfg):
+    """Per-block (heads, kernel_q, stride_q, kernel_kv, stride_kv) of
+    create_multiscale_vision_transformers (models/vision_transformers.py:394-445)."""
+    depth = cfg.get("depth", 16)
+    head_mul = [1.0] * (depth + 1)
+    for i, m in cfg.get("atten_head_mul") or []:
+        head_mul[i] = m
+    kq = [None] * depth
+    sq = [None] * depth
+    kkv = [None] * depth
+    skv = [None] * depth
+    fixed = cfg.get("pool_kvq_kernel")
+    for e in cfg.get("pool_q_stride_size") or []:
+        sq[e[0]] = list(e[1:])
+        kq[e[0]] = list(fixed) if fixed is not None else [s + 1 if s > 1 else s for s in e[1:]]
+    kv_sizes = cfg.get("pool_kv_stride_size")
+    if cfg.get("pool_kv_stride_adaptive") is not None:
+        cur = list(cfg["pool_kv_stride_adaptive"])
+        kv_sizes = []
+        for i in range(depth):
+            if sq[i]:
+                cur = [max(cur[d] // sq[i][d], 1) for d in range(3)]
+            kv_sizes.append([i] + cur)
+    for e in kv_sizes or []:
+        skv[e[0]] = list(e[1:])
+        kkv[e[0]] = list(fixed) if fixed is not None else [s + 1 if s > 1 else s for s in e[1:]]
+    heads, out = cfg.get("num_heads", 1), []
+    for i in range(depth):
+        heads = round_width(heads, head_mul[i], min_width=1, divisor=1)
+        out.append((heads, kq[i], sq[i], kkv[i], skv[i]))
+    return out
+
+
+def _attention_pool(sd, t, thw, p, kernel, stride, has_cls, norm_p=None, pool_fn=None):
+    """_AttentionPool.forward (layers/attention.py:162-212) for (B, heads, N, C) tokens and a
+    depthwise conv pool shared over heads (or `pool_fn` for the skip-path max pool)."""
+    if kernel is None:
+        return t, thw
+    if kernel is not None and stride is not None and math.prod(kernel) == 1 and math.prod(stride) == 1:
+        return t, thw
+    cls_tok = None
+    if has_cls:
+        cls_tok, t = t[:, :, :1, :], t[:, :, 1:, :]
+    B, N, L, C = t.shape
+    T, H, W = thw
+    g = t.reshape(B * N, T, H, W, C).permute(0, 4, 1, 2, 3).contiguous()
+    if pool_fn is not None:
+        g = pool_fn(g)
+    else:
+        w = sd[p + ".weight"]
+        g = F.conv3d(g, w, None, stride=stride, padding=[k // 2 for k in kernel], groups=w.shape[0])
+    thw = [g.shape[2], g.shape[3], g.shape[4]]
+    t = g.reshape(B, N, C, -1).transpose(2, 3)
+    if cls_tok is not None:
+        t = torch.cat((cls_tok, t), dim=2)
+    if norm_p is not None:
+        t = _ln(t, sd, norm_p)
+    return t, thw
+
+
+def multiscale_block(sd, x, thw, p, heads, kq, sq, kkv, skv, has_cls=True, residual_pool=False,
+                     dim_mul_in_att=False):
+    """MultiScaleBlock.forward (layers/attention.py:729-757) with MultiScaleAttention.forward
+    (:501-544), pool_mode="conv", depthwise, separate q/k/v, layernorm."""
+    B, N, _ = x.shape
+    xn = _ln(x, sd, p + ".norm1")
+    a = p + ".attn"
+
+    def heads_of(t):
+        return t.reshape(B, N, heads, -1).permute(0, 2, 1, 3)
+
+    q = heads_of(F.linear(xn, sd[a + ".q.weight"], sd.get(a + ".q.bias")))
+    k = heads_of(F.linear(xn, sd[a + ".k.weight"], sd.get(a + ".k.bias")))
+    v = heads_of(F.linear(xn, sd[a + ".v.weight"], sd.get(a + ".v.bias")))
+    q, q_thw = _attention_pool(sd, q, thw, a + ".pool_q", kq, sq, has_cls, a + ".norm_q")
+    k, _ = _attention_pool(sd, k, thw, a + ".pool_k", kkv, skv, has_cls, a + ".norm_k")
+    v, _ = _attention_pool(sd, v, thw, a + ".pool_v", kkv, skv, has_cls, a + ".norm_v")
+    hd = q.shape[-1]
+    attn = torch.softmax((q * hd ** -0.5) @ k.transpose(-2, -1), dim=-1)
+    o = attn @ v
+    if residual_pool:
+        o = o + q
+    o = o.transpose(1, 2).reshape(B, -1, heads * hd)
+    x_block = F.linear(o, sd[a + ".proj.weight"], sd.get(a + ".proj.bias"))
+    widen = (p + ".proj.weight") in sd
+    if dim_mul_in_att and widen:
+        x = F.linear(xn, sd[p + ".proj.weight"], sd.get(p + ".proj.bias"))
+    if sq is not None and math.prod(sq) > 1:
+        ks = [s + 1 if s > 1 else s for s in sq]
+        x_res, _ = _attention_pool(sd, x.unsqueeze(1), thw, None, ks, sq, has_cls,
+                                   pool_fn=lambda g: F.max_pool3d(g, ks, sq, [k_ // 2 for k_ in ks]))
+        x_res = x_res.squeeze(1)
+    else:
+        x_res = x
+    x = x_res + x_block
+    xn = _ln(x, sd, p + ".norm2")
+    h = F.gelu(F.linear(xn, sd[p + ".mlp.fc1.weight"], sd.get(p + ".mlp.fc1.bias")))
+    x_mlp = F.linear(h, sd[p + ".mlp.fc2.weight"], sd.get(p + ".mlp.fc2.bias"))
+    if (not dim_mul_in_att) and widen:
+        x = F.linear(xn, sd[p + ".proj.weight"], sd.get(p + ".proj.bias"))
+    return x + x_mlp, q_thw
+
+
+def mvit_forward(sd, x, cfg, return_blocks=False):
+    """MultiscaleVisionTransformers.forward (models/vision_transformers.py:172-182) as built by
+    create_multiscale_vision_transformers(**cfg) with layernorm, conv pooling, cls token."""
+    stride = cfg.get("conv_patch_embed_stride", (2, 4, 4))
+    pad = cfg.get("conv_patch_embed_padding", (1, 3, 3))
+    has_cls = cfg.get("cls_embed_on", True)
+    # PatchEmbed.forward (models/stem.py:289-292)
+    y = F.conv3d(x, sd["patch_embed.patch_model.weight"], sd.get("patch_embed.patch_model.bias"),
+                 stride=stride, padding=pad)
+    thw = [y.shape[2], y.shape[3], y.shape[4]]
+    y = y.flatten(2).transpose(1, 2)
+    # SpatioTemporalClsPositionalEncoding.forward (layers/positional_encoding.py:112-136)
+    c = "cls_positional_encoding"
+    if has_cls:
+        y = torch.cat((sd[c + ".cls_token"].expand(y.shape[0], -1, -1), y), dim=1)
+    if cfg.get("sep_pos_embed", True):
+        pos = sd[c + ".pos_embed_spatial"].repeat(1, thw[0], 1) + torch.repeat_interleave(
+            sd[c + ".pos_embed_temporal"], thw[1] * thw[2], dim=1)
+        if has_cls:
+            pos = torch.cat([sd[c + ".pos_embed_class"], pos], 1)
+        y = y + pos
+    else:
+        y = y + sd[c + ".pos_embed"]
+    outs = []
+    for i, (heads, kq, sq, kkv, skv) in enumerate(mvit_schedule(cfg)):
+        y, thw = multiscale_block(sd, y, thw, "blocks.%d" % i, heads, kq, sq, kkv, skv, has_cls,
+                                  cfg.get("residual_pool", False), cfg.get("dim_mul_in_att", False))
+        outs.append(y)
+    y = _ln(y, sd, "norm_embed")
+    # VisionTransformerBasicHead.forward (models/head.py:521-535), dropout = identity in eval
+    y = y[:, 0] if has_cls else y.mean(1)
+    y = F.linear(y, sd["head.proj.weight"], sd["head.proj.bias"])
+    return (y, outs) if return_blocks else y

@@ -39,7 +39,7 @@ DwConv3dDesc = _struct("DwConv3dDesc", [
     ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("psum", _p),
     ("x_bs", _i64), ("y_bs", _i64)]
     + _ints("ldx", "ldy", "B", "Ti", "Hi", "Wi", "C", "To", "Ho", "Wo",
-            "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "w_mod", "act", "dtype"))
+            "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "w_mod", "act", "dtype", "n_prefix"))
 
 SeGateDesc = _struct("SeGateDesc", [
     ("psum", _p), ("gate", _p), ("w1", _p), ("b1", _p), ("w2", _p), ("b2", _p)]
@@ -107,7 +107,7 @@ _SYMBOLS = [
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 

@@ -245,3 +245,67 @@ def transmute_pool(module: nn.Module):
 
 
 EFFICIENT_BLOCK_TRANSMUTER_MI355X = [transmute_single_io, transmute_multipath, transmute_pool]
+
+
+# ------------------------------------------------------------------------- MViT
+class Mi355xMViTBlock(Mi355xBlock):
+    """MultiScaleBlock (layers/attention.py:578-757): forward(x, thw) -> (x', thw').  The
+    token tensor (B, N, C) lives in the arena as a channels-last activation with W = N."""
+
+    def convert(self, input_blob_size, *args, session=None, input_ref=None, dtype=None, thw=None, **kwargs):
+        from . import emit_mvit as EM
+        assert self.convert_flag is False, "already converted, cannot be converted again"
+        self.eval()
+        sess = session
+        if sess is None:
+            sess = Session(dtype=dtype or torch.bfloat16)
+            self.__dict__["_owns_session"] = True
+        if input_ref is None:
+            if thw is None:
+                raise L.PvError("MultiScaleBlock.convert needs thw=(T,H,W) of the token grid")
+            B, N, Cc = [int(v) for v in input_blob_size]
+            input_ref = sess.alloc_act(B, 1, 1, N, Cc)
+            input_ref.thw, input_ref.has_cls = tuple(int(v) for v in thw), bool(self.has_cls_embed)
+        first = len(sess.ops)
+        out_ref = EM.emit_multiscale_block(sess, self, input_ref)
+        self.__dict__.update(_sess=sess, _in_ref=input_ref, _out_ref=out_ref, _op_range=(first, len(sess.ops)))
+        if self._owns_session:
+            sess.finalize()
+        self.__dict__["convert_flag"] = True
+
+    def _deploy_forward(self, x, thw_shape=None):
+        sess = self._sess
+        sess.finalize()
+        ref = self._in_ref
+        if thw_shape is not None and tuple(int(v) for v in thw_shape) != tuple(ref.thw):
+            raise L.PvError("deploy form was converted for grid %s, got %s" % (tuple(ref.thw), tuple(thw_shape)))
+        sess.ingest_rows(x, ref)
+        sess.launch(*self._op_range)
+        out = self._out_ref
+        return sess.view_rows(out), list(out.thw)
+
+
+def _probe_mvit_block(module):
+    """Structural check of a MultiScaleBlock by dry-emitting it into a scratch session."""
+    from . import emit_mvit as EM
+    try:
+        scratch = Session(dtype=torch.bfloat16)
+        T, H, W = 2, 8, 8
+        cls = 1 if module.has_cls_embed else 0
+        x = scratch.alloc_act(1, 1, 1, T * H * W + cls, module.dim)
+        x.thw, x.has_cls = (T, H, W), bool(cls)
+        EM.emit_multiscale_block(scratch, module, x)
+        return True
+    except (E.Unsupported, AttributeError, RuntimeError):
+        return False
+
+
+def transmute_mvit_block(module: nn.Module):
+    if isinstance(module, EfficientBlockBase) or type(module).__name__ != "MultiScaleBlock":
+        return None
+    if not _probe_mvit_block(module):
+        return None
+    return Mi355xMViTBlock(module)
+
+
+EFFICIENT_BLOCK_TRANSMUTER_MI355X.append(transmute_mvit_block)

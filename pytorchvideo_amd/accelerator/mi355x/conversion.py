@@ -29,6 +29,8 @@ def _record_input_sizes(model, sample):
         def hook(_m, _in, _out):
             if len(_in) > 0 and isinstance(_in[0], torch.Tensor):
                 lut[name] = tuple(_in[0].size())
+                if len(_in) > 1 and isinstance(_in[1], (list, tuple)) and len(_in[1]) == 3:
+                    lut[name + "#thw"] = tuple(int(v) for v in _in[1])  # MultiScaleBlock(x, thw)
         handles.append(module.register_forward_hook(hook))
         for child_name, child in module.named_children():
             add(child, f"{name}.{child_name}")
@@ -57,7 +59,10 @@ def _convert_children(module, lut, batch, name, sess, dtype, kwargs):
         size = lut.get(name)
         if size is not None:
             size = (batch,) + tuple(size[1:])
-        module.convert(size, session=sess, dtype=dtype, **kwargs)
+        extra = dict(kwargs)
+        if (name + "#thw") in lut:
+            extra["thw"] = lut[name + "#thw"]
+        module.convert(size, session=sess, dtype=dtype, **extra)
         return
     for child_name, child in module.named_children():
         _convert_children(child, lut, batch, f"{name}.{child_name}", sess, dtype, kwargs)
@@ -73,13 +78,20 @@ def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quant
         dtype = torch.bfloat16 if t0.dtype == torch.bfloat16 else torch.float32
     L.lib()  # fail early and loudly when the HIP library is not built
     lut = {}
-    if not _is_fusable_net(model):
+    if not _is_fusable_net(model) and not _is_fusable_mvit(model, input_tensor):
         lut = _record_input_sizes(model, _one_clip(input_tensor))
     converted = deepcopy(model)
     converted.eval()
     sess = Session(dtype=dtype)
     batch = _batch_of(input_tensor)
     fused = _try_fuse_net(converted, lut, batch, sess, dtype, input_tensor)
+    if not fused and _is_fusable_mvit(converted, input_tensor):
+        fused = _try_fuse_mvit(converted, sess, dtype, input_tensor)
+        if not fused:  # a piece outside the blocks is unsupported: per-block conversion needs sizes
+            sess = Session(dtype=dtype)
+            converted = deepcopy(model)
+            converted.eval()
+            lut = _record_input_sizes(model, _one_clip(input_tensor))
     if not fused:
         _convert_children(converted, lut, batch, "", sess, dtype,
                           dict(convert_for_quantize=convert_for_quantize,
@@ -142,6 +154,53 @@ def _try_fuse_net(model, lut, batch, sess, dtype, input_tensor=None):
         if out.T == out.H == out.W == 1 and out.f32:
             return s.view_rows(out)[:, 0, :]
         return s.view(out)
+
+    model.forward = types.MethodType(fused_forward, model)
+    return True
+
+
+# ------------------------------------------------------------------ whole-MViT fusion
+def _is_fusable_mvit(model, input_tensor):
+    from .blocks import Mi355xMViTBlock
+    blocks = getattr(model, "blocks", None)
+    return (type(model).__name__ == "MultiscaleVisionTransformers" and blocks is not None and len(blocks) > 0
+            and all(isinstance(b, Mi355xMViTBlock) for b in blocks)
+            and isinstance(input_tensor, torch.Tensor) and input_tensor.dim() == 5
+            and type(model.patch_embed).__name__ == "PatchEmbed")
+
+
+def _try_fuse_mvit(model, sess, dtype, input_tensor):
+    """MultiscaleVisionTransformers (models/vision_transformers.py:172-182) whose blocks are all
+    MI355X blocks: patch embedding, cls/pos encoding, the blocks, the final norm and the head
+    become one launch plan; forward = ingest + one replay."""
+    from . import emit as E
+    from . import emit_mvit as EM
+    from ... import _lib as L
+
+    B, Cc, T, H, W = [int(v) for v in input_tensor.shape]
+    first_in = sess.alloc_act(B, T, H, W, Cc)
+    n_ops = len(sess.ops)
+    try:
+        if not isinstance(model.pos_drop, (nn.Identity, nn.Dropout)):
+            raise E.Unsupported("pos_drop")
+        cur = EM.emit_patch_embed_and_pos(sess, model.patch_embed, model.cls_positional_encoding, first_in)
+        # first_in stays live: it is re-filled by every forward
+        for blk in model.blocks:
+            blk.convert(None, session=sess, input_ref=cur, dtype=dtype)
+            sess.release(cur)
+            cur = blk._out_ref
+        out = EM.emit_vit_head(sess, model.norm_embed, model.head, cur)
+        sess.release(cur)
+    except E.Unsupported:
+        del sess.ops[n_ops:]
+        return False
+
+    def fused_forward(self, x):
+        s = self._pv_session
+        if not s.matches(x, first_in):
+            s.ingest(x, first_in)
+        s.launch(use_graph=self._pv_use_graph)
+        return s.view_rows(out)[:, 0, :]
 
     model.forward = types.MethodType(fused_forward, model)
     return True

@@ -158,8 +158,11 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
     return y
 
 
-def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=None, w_mod=0, label="dwconv"):
-    """Depthwise Conv3d (+BN +act [+SE partial sums]) -> pv_dwconv3d.  Returns y or (y, psum, nblk)."""
+def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=None, w_mod=0, label="dwconv",
+                grid=None, n_prefix=0):
+    """Depthwise Conv3d (+BN +act [+SE partial sums]) -> pv_dwconv3d.  Returns y or (y, psum, nblk).
+    With `grid=(T,H,W)` the input is a token tensor (B, n_prefix + T*H*W, C) convolved on its
+    grid, the n_prefix leading rows (cls token) being copied through (attention.py:185-200)."""
     if not w_mod:
         if not check_conv3d(conv):
             raise Unsupported("not depthwise")
@@ -168,7 +171,10 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
     kt, kh, kw = conv.kernel_size
     st, sh, sw = conv.stride
     pt, ph, pw = _triple(conv.padding)
-    To, Ho, Wo = _conv_out(x.T, kt, st, pt), _conv_out(x.H, kh, sh, ph), _conv_out(x.W, kw, sw, pw)
+    Ti, Hi, Wi = grid if grid is not None else (x.T, x.H, x.W)
+    if grid is not None and x.voxels != n_prefix + Ti * Hi * Wi:
+        raise RuntimeError("token count %d does not match grid %s" % (x.voxels, (Ti, Hi, Wi)))
+    To, Ho, Wo = _conv_out(Ti, kt, st, pt), _conv_out(Hi, kh, sh, ph), _conv_out(Wi, kw, sw, pw)
     if min(To, Ho, Wo) <= 0:
         raise RuntimeError("conv output would be empty")
     Cc = x.C
@@ -176,7 +182,13 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
     w = conv.weight.detach().float().cpu().reshape(wc, kt * kh * kw)
     wp = torch.zeros(kt * kh * kw, pad8(wc), dtype=torch.float32)
     wp[:, :wc] = w.t()
-    y = out if out is not None else sess.alloc_act(x.B, To, Ho, Wo, Cc)
+    if out is not None:
+        y = out
+    elif grid is not None:
+        y = sess.alloc_act(x.B, 1, 1, n_prefix + To * Ho * Wo, Cc)
+        y.thw, y.has_cls = (To, Ho, Wo), n_prefix > 0
+    else:
+        y = sess.alloc_act(x.B, To, Ho, Wo, Cc)
     has_affine = norm is not None and not isinstance(norm, nn.Identity)
     scale, shift = fold_norm(norm, Cc, conv.bias if not w_mod else None)
     f = dict(
@@ -184,9 +196,9 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
         scale=sess.add_weight(scale) if has_affine else None,
         shift=sess.add_weight(shift) if (has_affine or conv.bias is not None) else None,
         psum=None, x_bs=x.bs, y_bs=y.bs, ldx=x.ld, ldy=y.ld,
-        B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, C=Cc, To=To, Ho=Ho, Wo=Wo,
+        B=x.B, Ti=Ti, Hi=Hi, Wi=Wi, C=Cc, To=To, Ho=Ho, Wo=Wo,
         kt=kt, kh=kh, kw=kw, st=st, sh=sh, sw=sw, pt=pt, ph=ph, pw=pw,
-        w_mod=w_mod, act=act, dtype=sess.pv_dtype,
+        w_mod=w_mod, act=act, dtype=sess.pv_dtype, n_prefix=n_prefix,
     )
     psum = nblk = None
     if want_psum:
@@ -199,8 +211,9 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
             raise Unsupported("depthwise geometry")
         psum = sess.alloc_raw(4 * x.B * nblk * pad8(Cc))
         f["psum"] = psum
-    alg = sess.itemsize * (x.B * x.voxels + y.B * y.voxels) * pad8(Cc)
-    sess.add_op(L.OP_DWCONV3D, f, label=label, alg_bytes=alg, flops=2 * y.B * y.voxels * Cc * kt * kh * kw)
+    vin, vout = x.B * Ti * Hi * Wi, x.B * To * Ho * Wo
+    alg = sess.itemsize * (min(vin, vout * kt * kh * kw) + vout) * pad8(Cc)
+    sess.add_op(L.OP_DWCONV3D, f, label=label, alg_bytes=alg, flops=2 * vout * Cc * kt * kh * kw)
     if want_psum:
         return y, psum, nblk
     return y
@@ -261,23 +274,30 @@ def emit_pool(sess, pool, x, n_prefix=0, out=None, label="pool"):
     return emit_pool_raw(sess, x, k, s, p, mode, n_prefix=n_prefix, out=out, label=label)
 
 
-def emit_pool_raw(sess, x, k, s, p, mode, n_prefix=0, out=None, label="pool"):
-    To, Ho, Wo = (_conv_out(x.T, k[0], s[0], p[0]), _conv_out(x.H, k[1], s[1], p[1]),
-                  _conv_out(x.W, k[2], s[2], p[2]))
+def emit_pool_raw(sess, x, k, s, p, mode, n_prefix=0, out=None, label="pool", grid=None):
+    """`grid=(T,H,W)`: x is a token tensor (B, n_prefix + T*H*W, C) pooled on its grid."""
+    Ti, Hi, Wi = grid if grid is not None else (x.T, x.H, x.W)
+    if grid is not None and x.voxels != n_prefix + Ti * Hi * Wi:
+        raise RuntimeError("token count %d does not match grid %s" % (x.voxels, (Ti, Hi, Wi)))
+    To, Ho, Wo = (_conv_out(Ti, k[0], s[0], p[0]), _conv_out(Hi, k[1], s[1], p[1]),
+                  _conv_out(Wi, k[2], s[2], p[2]))
+    if min(To, Ho, Wo) <= 0:
+        raise RuntimeError("pool output would be empty")
     if out is None:
-        if n_prefix:
+        if grid is not None:
             y = sess.alloc_act(x.B, 1, 1, To * Ho * Wo + n_prefix, x.C)
+            y.thw, y.has_cls = (To, Ho, Wo), n_prefix > 0
         else:
             y = sess.alloc_act(x.B, To, Ho, Wo, x.C)
     else:
         y = out
-        if not n_prefix and ((y.B, y.T, y.H, y.W) != (x.B, To, Ho, Wo) or y.C != x.C):
+        if grid is None and ((y.B, y.T, y.H, y.W) != (x.B, To, Ho, Wo) or y.C != x.C):
             raise RuntimeError("pool output buffer geometry mismatch")
     f = dict(x=x.ptr, y=y.ptr, x_bs=x.bs, y_bs=y.bs, ldx=x.ld, ldy=y.ld,
-             B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, C=x.C, To=To, Ho=Ho, Wo=Wo,
+             B=x.B, Ti=Ti, Hi=Hi, Wi=Wi, C=x.C, To=To, Ho=Ho, Wo=Wo,
              kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2], pt=p[0], ph=p[1], pw=p[2],
              mode=mode, n_prefix=n_prefix, dtype=sess.pv_dtype)
-    alg = sess.itemsize * pad8(x.C) * x.B * (x.voxels + To * Ho * Wo)
+    alg = sess.itemsize * pad8(x.C) * x.B * (Ti * Hi * Wi + To * Ho * Wo)
     sess.add_op(L.OP_POOL3D, f, label=label, alg_bytes=alg)
     return y
 

@@ -1,0 +1,333 @@
+"""Emitters for the MViT path: PatchEmbed, cls/pos encoding, MultiScaleBlock, final norm, head.
+
+Token tensors (B, N, C) are channels-last activations with T=H=1, W=N, i.e. they already are
+the NDHWC layout of their (T,H,W) grid (plus the cls row in front): the reference's
+permute + contiguous around every pooling conv (layers/attention.py:185-200) and the
+(B,N,h*d) <-> (B,h,N,d) head shuffles (:425-451, :537) cost nothing here.
+
+Launch list of one MultiScaleBlock (reference layers/attention.py:729-757):
+  LN(norm1) -> one GEMM for q|k|v (weights concatenated, reads x_norm once)
+  -> depthwise pooling conv on the token grid per q/k/v (weights shared over heads, cls row
+     copied through) -> LN(head_dim) per (token, head), in place
+  -> fused softmax(q k^T) v -> proj GEMM with bias + (max-pooled) skip in its epilogue
+  -> LN(norm2) -> fc1 GEMM + bias + GELU -> fc2 GEMM + bias + residual
+     (residual = block.proj(x_norm) when the width changes, :754-755).
+"""
+import torch
+import torch.nn as nn
+
+from ... import _lib as L
+from . import emit as E
+from .emit import Unsupported, _cls_name
+from .session import pad8
+
+
+# --------------------------------------------------------------------------- helpers
+def _linear_from(weight, bias):
+    lin = nn.Linear(weight.shape[1], weight.shape[0], bias=bias is not None)
+    lin.weight.data = weight.detach().float()
+    if bias is not None:
+        lin.bias.data = bias.detach().float()
+    return lin
+
+
+def emit_linear(sess, lin, x, act=L.ACT_NONE, residual=None, y_f32=False, label="linear"):
+    """nn.Linear over the channel dim of a token tensor (+bias +act +residual) -> pv_conv3d."""
+    if not isinstance(lin, nn.Linear):
+        raise Unsupported("%s is not nn.Linear" % _cls_name(lin))
+    if lin.in_features != x.C:
+        raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (Linear expects %d features, got %d)"
+                           % (lin.in_features, x.C))
+    conv = nn.Conv3d(lin.in_features, lin.out_features, 1, bias=lin.bias is not None)
+    conv.weight.data = lin.weight.detach().reshape(lin.out_features, lin.in_features, 1, 1, 1)
+    if lin.bias is not None:
+        conv.bias.data = lin.bias.detach()
+    y = E.emit_conv(sess, conv, x, None, act, residual=residual, y_f32=y_f32, label=label)
+    y.thw, y.has_cls = x.thw, x.has_cls
+    return y
+
+
+def emit_layernorm(sess, norm, x, out=None, rows=None, ldx=None, label="layernorm"):
+    """nn.LayerNorm over the last dim.  Default: every row of the token tensor; `rows`/`ldx`
+    select a strided subset (e.g. only the cls row of every batch item)."""
+    if not isinstance(norm, nn.LayerNorm):
+        raise Unsupported("norm %s" % _cls_name(norm))
+    if len(norm.normalized_shape) != 1 or norm.normalized_shape[0] != x.C:
+        raise RuntimeError("LayerNorm over %s applied to %d channels" % (tuple(norm.normalized_shape), x.C))
+    if x.bs != x.voxels * x.ld:
+        raise Unsupported("LayerNorm on a non-dense token tensor")
+    y = out if out is not None else sess.alloc_act(x.B, x.T, x.H, x.W, x.C)
+    y.thw, y.has_cls = x.thw, x.has_cls
+    n_rows = x.B * x.voxels if rows is None else rows
+    f = dict(x=x.ptr, y=y.ptr,
+             gamma=sess.add_weight(norm.weight.detach().float()) if norm.weight is not None else None,
+             beta=sess.add_weight(norm.bias.detach().float()) if norm.bias is not None else None,
+             rows=n_rows, C=x.C, ldx=x.ld if ldx is None else ldx, ldy=y.ld if ldx is None else y.ld,
+             rows_per_batch=0, eps=float(norm.eps), dtype=sess.pv_dtype)
+    sess.add_op(L.OP_LAYERNORM, f, label=label, alg_bytes=2 * sess.itemsize * n_rows * pad8(x.C))
+    return y
+
+
+def emit_head_layernorm(sess, norm, x, heads, label="pool.norm"):
+    """LayerNorm(head_dim) applied to every (token, head) of a dense (B, N, heads*head_dim)
+    tensor, in place (reference: _AttentionPool norm after pool, attention.py:202-205)."""
+    if not isinstance(norm, nn.LayerNorm):
+        raise Unsupported("attention norm %s" % _cls_name(norm))
+    hd = x.C // heads
+    if len(norm.normalized_shape) != 1 or norm.normalized_shape[0] != hd:
+        raise RuntimeError("attention LayerNorm over %s, head dim %d" % (tuple(norm.normalized_shape), hd))
+    if hd % 8 or x.ld != x.C or x.bs != x.voxels * x.ld:
+        raise Unsupported("per-head LayerNorm needs a dense tensor and head_dim % 8 == 0")
+    n_rows = x.B * x.voxels * heads
+    f = dict(x=x.ptr, y=x.ptr,
+             gamma=sess.add_weight(norm.weight.detach().float()) if norm.weight is not None else None,
+             beta=sess.add_weight(norm.bias.detach().float()) if norm.bias is not None else None,
+             rows=n_rows, C=hd, ldx=hd, ldy=hd, rows_per_batch=0, eps=float(norm.eps), dtype=sess.pv_dtype)
+    sess.add_op(L.OP_LAYERNORM, f, label=label, alg_bytes=2 * sess.itemsize * n_rows * hd)
+    return x
+
+
+def _pool_params(pool):
+    if not isinstance(pool, (nn.MaxPool3d, nn.AvgPool3d)):
+        raise Unsupported("pool %s" % _cls_name(pool))
+    if getattr(pool, "ceil_mode", False):
+        raise Unsupported("ceil_mode pooling")
+    k = E._triple(pool.kernel_size)
+    s = E._triple(pool.stride if pool.stride is not None else pool.kernel_size)
+    p = E._triple(pool.padding)
+    if isinstance(pool, nn.MaxPool3d):
+        if E._triple(pool.dilation) != (1, 1, 1) or pool.return_indices:
+            raise Unsupported("max pool options")
+        return k, s, p, L.POOL_MAX
+    if not pool.count_include_pad or pool.divisor_override is not None:
+        raise Unsupported("avg pool options")
+    return k, s, p, L.POOL_AVG
+
+
+def emit_attention_pool(sess, ap, x, heads, label):
+    """_AttentionPool.forward (attention.py:162-212) on a token tensor whose channel dim is
+    heads*head_dim.  Returns a new dense tensor, or `x` itself when the module has no pool."""
+    if not ap.has_pool:
+        return x
+    if x.thw is None:
+        raise Unsupported("token tensor without a grid")
+    if ap.has_norm and ap.norm_before_pool:
+        raise Unsupported("BatchNorm3d+GELU before pooling")
+    n_prefix = 1 if ap.has_cls_embed else 0
+    pool = ap.pool
+    if isinstance(pool, nn.Conv3d):
+        hd = x.C // heads
+        if pool.groups != pool.in_channels or pool.in_channels != pool.out_channels:
+            raise Unsupported("dense pooling conv")
+        if pool.in_channels != hd:
+            raise RuntimeError("pooling conv has %d channels, head dim is %d" % (pool.in_channels, hd))
+        if pool.bias is not None or tuple(pool.dilation) != (1, 1, 1) or pool.padding_mode != "zeros":
+            raise Unsupported("pooling conv options")
+        if hd % 8:
+            raise Unsupported("head_dim % 8 != 0")
+        y = E.emit_dwconv(sess, pool, x, None, L.ACT_NONE, w_mod=hd if heads > 1 else 0, grid=x.thw,
+                          n_prefix=n_prefix, label=label)
+    else:
+        k, s, p, mode = _pool_params(pool)
+        y = E.emit_pool_raw(sess, x, k, s, p, mode, n_prefix=n_prefix, grid=x.thw, label=label)
+    if ap.has_norm:
+        emit_head_layernorm(sess, ap.norm, y, heads, label=label + ".norm")
+    return y
+
+
+def emit_attention_core(sess, q, k, v, heads, scale, residual_q, label="attention"):
+    hd = q.C // heads
+    if hd not in (32, 64, 96, 128):
+        raise Unsupported("head_dim %d" % hd)
+    o = sess.alloc_act(q.B, 1, 1, q.voxels, q.C)
+    o.thw, o.has_cls = q.thw, q.has_cls
+    f = dict(q=q.ptr, k=k.ptr, v=v.ptr, o=o.ptr, q_bs=q.bs, k_bs=k.bs, v_bs=v.bs, o_bs=o.bs,
+             ldq=q.ld, ldk=k.ld, ldv=v.ld, ldo=o.ld, B=q.B, heads=heads, head_dim=hd,
+             Nq=q.voxels, Nk=k.voxels, scale=float(scale), residual_q=1 if residual_q else 0,
+             dtype=sess.pv_dtype)
+    alg = sess.itemsize * q.B * q.C * (2 * q.voxels + 2 * k.voxels)
+    flops = 4 * q.B * heads * q.voxels * k.voxels * hd
+    sess.add_op(L.OP_ATTENTION, f, label=label, alg_bytes=alg, flops=flops)
+    return o
+
+
+# --------------------------------------------------------------------------- modules
+def emit_multiscale_attention(sess, attn, xn, residual, label="attn"):
+    """MultiScaleAttention.forward (attention.py:501-544) + the block's residual join fused into
+    proj's epilogue.  Returns the (B, Nq, dim_out) token tensor."""
+    heads = attn.num_heads
+    if attn.dropout_rate > 0.0 and not isinstance(attn.proj_drop, (nn.Dropout, nn.Identity)):
+        raise Unsupported("proj_drop")
+    owned = []
+    if attn.pool_first:
+        if xn.C % heads:
+            raise RuntimeError("dim %d not divisible by %d heads" % (xn.C, heads))
+        qp = emit_attention_pool(sess, attn._attention_pool_q, xn, heads, label + ".pool_q")
+        kp = emit_attention_pool(sess, attn._attention_pool_k, xn, heads, label + ".pool_k")
+        vp = emit_attention_pool(sess, attn._attention_pool_v, xn, heads, label + ".pool_v")
+        q = emit_linear(sess, attn.q, qp, label=label + ".q")
+        k = emit_linear(sess, attn.k, kp, label=label + ".k")
+        v = emit_linear(sess, attn.v, vp, label=label + ".v")
+        for t in (qp, kp, vp):
+            if t is not xn:
+                sess.release(t)
+        owned += [q, k, v]
+    else:
+        if attn.separate_qkv:
+            ws = [attn.q.weight, attn.k.weight, attn.v.weight]
+            bs = [attn.q.bias, attn.k.bias, attn.v.bias]
+            bias = None if bs[0] is None else torch.cat([b.detach() for b in bs])
+            lin = _linear_from(torch.cat([w.detach() for w in ws]), bias)
+        else:
+            lin = attn.qkv
+        if lin.out_features != 3 * attn.dim_out or attn.dim_out % 8:
+            raise Unsupported("qkv width")
+        qkv = emit_linear(sess, lin, xn, label=label + ".qkv")
+        parts = []
+        for i in range(3):
+            t = qkv.channel_slice(i * attn.dim_out, attn.dim_out)
+            t.thw, t.has_cls = xn.thw, xn.has_cls
+            parts.append(t)
+        q = emit_attention_pool(sess, attn._attention_pool_q, parts[0], heads, label + ".pool_q")
+        k = emit_attention_pool(sess, attn._attention_pool_k, parts[1], heads, label + ".pool_k")
+        v = emit_attention_pool(sess, attn._attention_pool_v, parts[2], heads, label + ".pool_v")
+        owned += [t for t, p in zip((q, k, v), parts) if t is not p]
+        owned.append(qkv)
+    o = emit_attention_core(sess, q, k, v, heads, attn.scale, attn.residual_pool, label=label + ".core")
+    q_thw = q.thw
+    for t in owned:
+        sess.release(t)
+    y = emit_linear(sess, attn.proj, o, residual=residual, label=label + ".proj")
+    sess.release(o)
+    y.thw = q_thw
+    return y
+
+
+def emit_multiscale_block(sess, blk, x):
+    """MultiScaleBlock.forward (attention.py:729-757).  Consumes nothing: the caller releases x."""
+    if blk.norm1_is_batchnorm_1d or blk.norm2_is_batchnorm_1d:
+        raise Unsupported("BatchNorm1d block norm")
+    if not isinstance(blk.drop_path, nn.Identity) and _cls_name(blk.drop_path) != "DropPath":
+        raise Unsupported("drop_path %s" % _cls_name(blk.drop_path))
+    act = E.act_code(blk.mlp.act)
+    widen = blk.dim != blk.dim_out
+    xn = emit_layernorm(sess, blk.norm1, x, label="norm1")
+    skip_src = x
+    if blk.dim_mul_in_att and widen:
+        skip_src = emit_linear(sess, blk.proj, xn, label="proj_dim")
+    if blk._attention_pool.has_pool:
+        k, s, p, mode = _pool_params(blk._attention_pool.pool)
+        x_res = E.emit_pool_raw(sess, skip_src, k, s, p, mode, n_prefix=1 if blk.has_cls_embed else 0,
+                                grid=skip_src.thw, label="pool_skip")
+    else:
+        x_res = skip_src
+    x1 = emit_multiscale_attention(sess, blk.attn, xn, residual=x_res)
+    sess.release(xn)
+    if x_res is not skip_src:
+        sess.release(x_res)
+    if skip_src is not x:
+        sess.release(skip_src)
+    xn2 = emit_layernorm(sess, blk.norm2, x1, label="norm2")
+    hmid = emit_linear(sess, blk.mlp.fc1, xn2, act=act, label="mlp.fc1")
+    if (not blk.dim_mul_in_att) and widen:
+        res2 = emit_linear(sess, blk.proj, xn2, label="proj_dim")
+    else:
+        res2 = x1
+    sess.release(xn2)
+    y = emit_linear(sess, blk.mlp.fc2, hmid, residual=res2, label="mlp.fc2")
+    sess.release(hmid)
+    if res2 is not x1:
+        sess.release(res2)
+    sess.release(x1)
+    return y
+
+
+def emit_patch_embed_and_pos(sess, patch_embed, cls_pos, x):
+    """PatchEmbed.forward (models/stem.py:289-292) + SpatioTemporalClsPositionalEncoding.forward
+    (layers/positional_encoding.py:112-136): the conv writes straight into rows [1, 1+T*H*W) of
+    the token buffer; one kernel then writes the cls row and adds the position tables."""
+    if _cls_name(patch_embed) != "PatchEmbed":
+        raise Unsupported("patch embed %s" % _cls_name(patch_embed))
+    conv = patch_embed.patch_model
+    if not isinstance(conv, nn.Conv3d):
+        raise Unsupported("2-D patch embedding")
+    if E.check_conv3d(conv):
+        raise Unsupported("depthwise patch embedding")
+    T, H, W = cls_pos.patch_embed_shape()
+    has_cls = bool(cls_pos.cls_embed_on)
+    Cc = conv.out_channels
+    tok = sess.alloc_act(x.B, 1, 1, T * H * W + (1 if has_cls else 0), Cc)
+    tok.thw, tok.has_cls = (T, H, W), has_cls
+    grid = (tok.row_offset(1) if has_cls else tok).as_grid(T, H, W)
+    grid.C = Cc
+    E.emit_conv(sess, conv, x, None, L.ACT_NONE, out=grid, label="patch_embed")
+    sep = bool(cls_pos.sep_pos_embed)
+
+    def flat(p):
+        return sess.add_weight(p.detach().float().reshape(-1, Cc))
+
+    f = dict(x=tok.ptr, cls_token=flat(cls_pos.cls_token) if has_cls else None,
+             pos_spatial=flat(cls_pos.pos_embed_spatial if sep else cls_pos.pos_embed),
+             pos_temporal=flat(cls_pos.pos_embed_temporal) if sep else None,
+             pos_class=flat(cls_pos.pos_embed_class) if (sep and has_cls) else None,
+             B=x.B, T=T, HW=H * W, C=Cc, ld=tok.ld, dtype=sess.pv_dtype)
+    sess.add_op(L.OP_POSENC, f, label="pos_encoding", alg_bytes=2 * sess.itemsize * x.B * tok.voxels * pad8(Cc))
+    return tok
+
+
+def emit_vit_head(sess, norm_embed, head, x):
+    """final LayerNorm + VisionTransformerBasicHead.forward (models/head.py:521-535).  With cls
+    pooling only the cls row of each clip is normalised (LayerNorm is row-wise)."""
+    if _cls_name(head) != "VisionTransformerBasicHead":
+        raise Unsupported("head %s" % _cls_name(head))
+    if head.dropout is not None and not isinstance(head.dropout, nn.Dropout):
+        raise Unsupported("head dropout")
+    sp = head.sequence_pool
+    if sp is None or _cls_name(sp) != "SequencePool":
+        raise Unsupported("head without sequence pooling")
+    if sp.mode == "cls":
+        pooled = sess.alloc_act(x.B, 1, 1, 1, x.C)
+        if isinstance(norm_embed, nn.Identity):
+            raise Unsupported("cls pooling without final norm")
+        emit_layernorm(sess, norm_embed, x, out=pooled, rows=x.B, ldx=x.bs, label="norm_embed")
+    elif sp.mode == "mean":
+        xn = x if isinstance(norm_embed, nn.Identity) else emit_layernorm(sess, norm_embed, x, label="norm_embed")
+        pooled32 = sess.alloc_act(x.B, 1, 1, 1, x.C, f32=True)
+        f = dict(x=xn.ptr, y=pooled32.ptr, gamma=None, beta=None, rows=x.B * x.voxels, C=x.C, ldx=xn.ld,
+                 ldy=pooled32.ld, rows_per_batch=x.voxels, eps=0.0, dtype=sess.pv_dtype)
+        sess.add_op(L.OP_MEAN_ROWS, f, label="head.seq_mean")
+        if xn is not x:
+            sess.release(xn)
+        if sess.pv_dtype != L.PV_F32:
+            raise Unsupported("mean sequence pooling in bf16")  # TODO: bf16 mean output
+        pooled = pooled32
+        pooled.f32 = False
+    else:
+        raise Unsupported("sequence pool %s" % sp.mode)
+    logits = emit_linear(sess, head.proj, pooled, y_f32=True, label="head.proj")
+    sess.release(pooled)
+    a = head.activation
+    if a is not None:
+        if isinstance(a, nn.Softmax) and a.dim == 1:
+            f = dict(x=logits.ptr, y=logits.ptr, gamma=None, beta=None, rows=logits.B, C=logits.C,
+                     ldx=logits.ld, ldy=logits.ld, rows_per_batch=0, eps=0.0, dtype=L.PV_F32)
+            sess.add_op(L.OP_SOFTMAX_ROWS, f, label="head.softmax")
+        else:
+            raise Unsupported("head activation %s" % _cls_name(a))
+    return logits
+
+
+def emit_mvit(sess, model, x):
+    """MultiscaleVisionTransformers.forward (models/vision_transformers.py:172-182)."""
+    if not isinstance(model.pos_drop, (nn.Identity, nn.Dropout)):
+        raise Unsupported("pos_drop")
+    cur = emit_patch_embed_and_pos(sess, model.patch_embed, model.cls_positional_encoding, x)
+    for blk in model.blocks:
+        if _cls_name(blk) != "MultiScaleBlock":
+            raise Unsupported("block %s" % _cls_name(blk))
+        nxt = emit_multiscale_block(sess, blk, cur)
+        sess.release(cur)
+        cur = nxt
+    out = emit_vit_head(sess, model.norm_embed, model.head, cur)
+    sess.release(cur)
+    return out

@@ -278,6 +278,18 @@ class Session:
         d.dst_dtype = self.pv_dtype
         L.check(lib.pv_ingest_ncdhw(C.byref(d), self._stream()), "ingest")
 
+    def ingest_rows(self, x, ref):
+        """Copy a (B, N, C) token tensor into the arena buffer `ref` (no-op when `x` already is it)."""
+        v = self.view_rows(ref)
+        if tuple(x.shape) != tuple(v.shape):
+            raise L.PvError("deploy form was converted for tokens %s, got %s" % (tuple(v.shape), tuple(x.shape)))
+        if x.is_cuda and x.data_ptr() == v.data_ptr() and x.stride() == v.stride() and x.dtype == v.dtype:
+            return
+        v.copy_(x.to(self.device, non_blocking=True))
+        if ref.ld > ref.C:  # padding channels of the row must stay zero
+            full = self.arena_t[ref.off: ref.off + ref.B * ref.bs * ref.itemsize].view(v.dtype)
+            full.view(ref.B, -1, ref.ld)[:, :, ref.C:].zero_()
+
     def __del__(self):
         try:
             if self.plan is not None:

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kThreads) void dwconv_kernel(const pv_dwconv3d_desc
     ho = (int)(r % d.Ho);
     to = (int)(r / d.Ho);
     wo0 = wg * NWc;
-    const T* __restrict__ X = static_cast<const T*>(d.x) + (long)b * d.x_bs + c0;
+    const T* __restrict__ X = static_cast<const T*>(d.x) + (long)b * d.x_bs + (long)d.n_prefix * d.ldx + c0;
     const int t0 = to * d.st - d.pt, h0 = ho * d.sh - d.ph;
     if constexpr (KW == 0) {
       const int w0 = wo0 * d.sw - d.pw;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kThreads) void dwconv_kernel(const pv_dwconv3d_desc
 #pragma unroll
   for (int j = 0; j < 8; ++j) ps[j] = 0.f;
   if (active) {
-    T* __restrict__ Y = static_cast<T*>(d.y) + (long)b * d.y_bs + c0;
+    T* __restrict__ Y = static_cast<T*>(d.y) + (long)b * d.y_bs + (long)d.n_prefix * d.ldy + c0;
 #pragma unroll
     for (int n = 0; n < NWc; ++n) {
       const int wo = wo0 + n;
@@ -158,6 +158,21 @@ __global__ __launch_bounds__(kThreads) void dwconv_kernel(const pv_dwconv3d_desc
       d.psum[((long)b * gridDim.x + blockIdx.x) * c_p + c] = s;
     }
   }
+}
+
+// copy the n_prefix leading rows (cls token) of every batch item verbatim
+template <typename T>
+__global__ void dw_prefix_kernel(const pv_dwconv3d_desc d) {
+  const int CG = pv_round_up(d.C, 8) / 8;
+  const int total = d.B * d.n_prefix * CG;
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= total) return;
+  const int cg = id % CG;
+  const int r = (id / CG) % d.n_prefix;
+  const int b = id / (CG * d.n_prefix);
+  Chunk8<T> c;
+  c.load(static_cast<const T*>(d.x) + (long)b * d.x_bs + (long)r * d.ldx + cg * 8);
+  c.store(static_cast<T*>(d.y) + (long)b * d.y_bs + (long)r * d.ldy + cg * 8);
 }
 
 struct DwGeom {
@@ -202,6 +217,11 @@ int launch_variant(const pv_dwconv3d_desc& d, const DwGeom& g, hipStream_t s) {
 }
 
 template <typename T> int launch_dw(const pv_dwconv3d_desc& d, const DwGeom& g, hipStream_t s) {
+  if (d.n_prefix > 0) {
+    const int total = d.B * d.n_prefix * (pv_round_up(d.C, 8) / 8);
+    hipLaunchKernelGGL(dw_prefix_kernel<T>, dim3((unsigned)pv_ceil_div(total, kThreads)), dim3(kThreads), 0, s, d);
+    PV_LAUNCH_CHECK();
+  }
   if (d.kw == 3 && d.sw == 1) return launch_variant<T, 3, 1, 4>(d, g, s);
   if (d.kw == 3 && d.sw == 2) return launch_variant<T, 3, 2, 4>(d, g, s);
   if (d.kw == 1 && d.sw == 1) return launch_variant<T, 1, 1, 4>(d, g, s);
@@ -218,6 +238,7 @@ int validate(const pv_dwconv3d_desc& d) {
       (d.Wi + 2 * d.pw - d.kw) / d.sw + 1 != d.Wo)
     return PV_ERR_INVALID;
   if (d.B > 65535) return PV_ERR_UNSUPPORTED;
+  if (d.n_prefix < 0 || (d.n_prefix > 0 && d.psum)) return PV_ERR_INVALID;
   return PV_OK;
 }
 

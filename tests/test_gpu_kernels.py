@@ -1,0 +1,185 @@
+"""Kernel-level parity on the MI355X: each C-ABI entry point against a plain PyTorch fp32
+reference of the same op on the same seeded inputs, including ragged / odd sizes.
+
+Tolerances (relative to the reference abs-max): fp32 kernels 1e-3 (in practice ~1e-6), bf16
+kernels 1e-2 against the fp32 reference evaluated on the same bf16-rounded inputs.
+"""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pytorchvideo_amd import _lib as L
+from gpu_util import call, pv_dtype, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2}
+
+
+def _rand(shape, seed, dtype, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).cuda()
+
+
+def _attention_ref(q, k, v, heads, scale, residual_q):
+    B, Nq, Cw = q.shape
+    hd = Cw // heads
+    qh = q.float().reshape(B, Nq, heads, hd).permute(0, 2, 1, 3)
+    kh = k.float().reshape(B, -1, heads, hd).permute(0, 2, 1, 3)
+    vh = v.float().reshape(B, -1, heads, hd).permute(0, 2, 1, 3)
+    a = torch.softmax((qh * scale) @ kh.transpose(-2, -1), dim=-1)
+    o = a @ vh
+    if residual_q:
+        o = o + qh
+    return o.permute(0, 2, 1, 3).reshape(B, Nq, Cw)
+
+
+def _run_attention(q, k, v, heads, scale, residual_q, pad=0):
+    """q/k/v: (B, N, heads*hd) device tensors, possibly channel slices of a wider buffer."""
+    B, Nq, Cw = q.shape
+    o = torch.full((B, Nq, Cw + pad), 7.0, dtype=q.dtype, device="cuda")
+    d = L.AttentionDesc()
+    d.q, d.k, d.v, d.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+    d.q_bs, d.k_bs, d.v_bs, d.o_bs = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(1), k.stride(1), v.stride(1), o.stride(1)
+    d.B, d.heads, d.head_dim, d.Nq, d.Nk = B, heads, Cw // heads, Nq, k.shape[1]
+    d.scale, d.residual_q, d.dtype = scale, int(residual_q), pv_dtype(q)
+    call("pv_attention", d)
+    if pad:
+        assert torch.all(o[:, :, Cw:] == 7.0)  # never writes outside its channels
+    return o[:, :, :Cw]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,heads,hd,Nq,Nk,res", [
+    (2, 2, 96, 785, 785, False),     # MViT-B block 15 geometry
+    (1, 1, 96, 1000, 197, False),    # many q blocks, ragged key tail
+    (2, 4, 96, 129, 65, True),       # one row past a q block / one key past a tile, residual_pool
+    (1, 8, 96, 33, 3137, False),     # long key loop
+    (3, 1, 32, 7, 5, False),         # smaller than one tile
+    (1, 2, 64, 200, 130, True),
+    (1, 1, 128, 140, 70, False),
+])
+def test_attention_matches_reference(dtype, B, heads, hd, Nq, Nk, res):
+    Cw = heads * hd
+    q, k, v = _rand((B, Nq, Cw), 1, dtype), _rand((B, Nk, Cw), 2, dtype), _rand((B, Nk, Cw), 3, dtype)
+    scale = hd ** -0.5
+    want = _attention_ref(q, k, v, heads, scale, res)
+    got = _run_attention(q, k, v, heads, scale, res, pad=8)
+    assert rel_err(got, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_on_channel_slices_of_a_fused_qkv_buffer(dtype):
+    B, heads, hd, N = 2, 2, 96, 300
+    Cw = heads * hd
+    qkv = _rand((B, N, 3 * Cw), 5, dtype)
+    q, k, v = qkv[:, :, :Cw], qkv[:, :, Cw:2 * Cw], qkv[:, :, 2 * Cw:]
+    want = _attention_ref(q, k, v, heads, hd ** -0.5, False)
+    got = _run_attention(q, k, v, heads, hd ** -0.5, False)
+    assert rel_err(got, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_online_softmax_rescale_branch(dtype):
+    """A key late in the sequence dominates one query: the running max jumps by ~60 in the
+    exp2 domain at a chosen tile, so every earlier tile's contribution must be rescaled away."""
+    B, heads, hd, Nq, Nk = 1, 1, 96, 64, 400
+    q, k, v = _rand((B, Nq, hd), 11, dtype, 0.5), _rand((B, Nk, hd), 12, dtype, 0.5), _rand((B, Nk, hd), 13, dtype)
+    k[0, 333] = (q[0, 17].float() * 8.0).to(dtype)   # spike: score(q17, k333) >> all others
+    k[0, 2] = (q[0, 40].float() * 8.0).to(dtype)     # and one in the very first tile
+    want = _attention_ref(q, k, v, heads, hd ** -0.5, False)
+    got = _run_attention(q, k, v, heads, hd ** -0.5, False)
+    assert rel_err(got, want) <= TOL[dtype]
+    assert rel_err(got[0, 17], v[0, 333].float()) <= 2e-2  # the spiked row is (almost) a copy of v[333]
+
+
+def test_attention_rejects_bad_descriptors():
+    lib = L.lib()
+    d = L.AttentionDesc()
+    assert lib.pv_attention(C.byref(d), None) == L.PV_ERR_INVALID
+    q = torch.zeros(1, 8, 40, device="cuda")
+    d.q = d.k = d.v = d.o = q.data_ptr()
+    d.B, d.heads, d.head_dim, d.Nq, d.Nk = 1, 1, 40, 8, 8
+    d.ldq = d.ldk = d.ldv = d.ldo = 40
+    d.q_bs = d.k_bs = d.v_bs = d.o_bs = 320
+    d.dtype = L.PV_F32
+    assert lib.pv_attention(C.byref(d), None) == L.PV_ERR_UNSUPPORTED  # head_dim 40
+
+
+# ------------------------------------------------------------------ depthwise conv on tokens
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("heads,thw,stride,cls", [
+    (2, (4, 14, 14), (1, 2, 2), 1), (1, (2, 16, 16), (1, 8, 8), 1), (4, (4, 7, 7), (1, 1, 1), 1),
+    (2, (4, 8, 8), (2, 2, 2), 0),
+])
+def test_token_pooling_conv_with_shared_weights_and_cls_prefix(dtype, heads, thw, stride, cls):
+    """MViT's pool_q/k/v (layers/attention.py:185-200): depthwise 3x3x3 conv over the token grid,
+    weights shared across heads, cls row copied through."""
+    hd, B = 96, 2
+    T, H, W = thw
+    Cw = heads * hd
+    x = _rand((B, cls + T * H * W, Cw), 21, dtype)
+    w = _rand((hd, 1, 3, 3, 3), 22, torch.float32, 0.3)
+    grid = x[:, cls:].float().reshape(B, T, H, W, heads, hd).permute(0, 4, 5, 1, 2, 3).reshape(B * heads, hd, T, H, W)
+    ref = F.conv3d(grid, w, None, stride=stride, padding=1, groups=hd)
+    To, Ho, Wo = ref.shape[2:]
+    ref = ref.reshape(B, heads, hd, To * Ho * Wo).permute(0, 3, 1, 2).reshape(B, To * Ho * Wo, Cw)
+    if cls:
+        ref = torch.cat([x[:, :1].float(), ref], 1)
+    y = torch.zeros(B, cls + To * Ho * Wo, Cw, dtype=dtype, device="cuda")
+    wp = w.reshape(hd, 27).t().contiguous()
+    d = L.DwConv3dDesc()
+    d.x, d.w, d.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
+    d.x_bs, d.y_bs, d.ldx, d.ldy = x.stride(0), y.stride(0), Cw, Cw
+    d.B, d.Ti, d.Hi, d.Wi, d.C, d.To, d.Ho, d.Wo = B, T, H, W, Cw, To, Ho, Wo
+    d.kt = d.kh = d.kw = 3
+    d.st, d.sh, d.sw = stride
+    d.pt = d.ph = d.pw = 1
+    d.w_mod, d.act, d.dtype, d.n_prefix = (hd if heads > 1 else 0), L.ACT_NONE, pv_dtype(x), cls
+    call("pv_dwconv3d", d)
+    assert rel_err(y, ref) <= TOL[dtype]
+
+
+# ------------------------------------------------------------------ row ops
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,Cc", [(1000, 96), (77, 768), (5, 1536), (130, 192)])
+def test_layernorm_rows(dtype, rows, Cc):
+    x = _rand((rows, Cc), 31, dtype, 2.0) + 0.5
+    g, b = _rand((Cc,), 32, torch.float32), _rand((Cc,), 33, torch.float32)
+    want = F.layer_norm(x.float(), (Cc,), g, b, 1e-6)
+    y = torch.zeros_like(x)
+    d = L.RowsDesc()
+    d.x, d.y, d.gamma, d.beta = x.data_ptr(), y.data_ptr(), g.data_ptr(), b.data_ptr()
+    d.rows, d.C, d.ldx, d.ldy, d.eps, d.dtype = rows, Cc, Cc, Cc, 1e-6, pv_dtype(x)
+    call("pv_layernorm", d)
+    assert rel_err(y, want) <= TOL[dtype]
+
+
+# ------------------------------------------------------------------ GEMM (linear) shapes of MViT
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N,act,res", [
+    (785 * 2, 768, 3072, L.ACT_GELU, False), (3137, 384, 1152, L.ACT_NONE, False),
+    (1001, 96, 288, L.ACT_NONE, True), (785, 3072, 768, L.ACT_NONE, True), (50, 768, 400, L.ACT_NONE, False),
+])
+def test_linear_as_pointwise_conv(dtype, M, K, N, act, res):
+    x = _rand((1, M, K), 41, dtype)
+    w = _rand((N, K), 42, dtype, K ** -0.5)
+    bias = _rand((N,), 43, torch.float32)
+    r = _rand((1, M, N), 44, dtype) if res else None
+    want = F.linear(x.float(), w.float(), bias)
+    if res:
+        want = want + r.float()
+    if act == L.ACT_GELU:
+        want = F.gelu(want)
+    y = torch.zeros(1, M, N, dtype=dtype, device="cuda")
+    d = L.Conv3dDesc()
+    d.x, d.w, d.y, d.shift = x.data_ptr(), w.data_ptr(), y.data_ptr(), bias.data_ptr()
+    d.residual = r.data_ptr() if res else None
+    d.x_bs, d.y_bs, d.r_bs, d.ldx, d.ldy, d.ldr = M * K, M * N, M * N, K, N, N
+    d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = 1, 1, 1, M, K, 1, 1, M, N
+    d.kt = d.kh = d.kw = d.st = d.sh = d.sw = 1
+    d.act, d.a_act, d.dtype, d.y_f32 = act, L.ACT_NONE, pv_dtype(x), 0
+    call("pv_conv3d", d)
+    assert rel_err(y, want) <= TOL[dtype]

@@ -1,0 +1,116 @@
+"""Whole-model GPU parity (MI355X): the deploy form of every model family on the path against
+the CPU oracle (which is pinned to the reference's golden vectors by test_oracle_golden.py).
+
+fp32 kernels <= 1e-3, bf16 kernels <= 1e-2 (relative to the oracle output's abs-max; bf16
+against the oracle evaluated on the same bf16-rounded weights and input)."""
+import os
+
+import pytest
+import torch
+
+from oracle import functional as OF
+from oracle.weights import deterministic_fill, quantize_like_kernels, seeded_input
+from gpu_util import rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DTYPES = [(torch.float32, 1e-3), (torch.bfloat16, 1e-2)]
+
+
+def _deploy(model, x, dtype):
+    from pytorchvideo_amd.accelerator import convert_to_deployable_form, transmute_model
+    transmute_model(model, "mi355x")
+    xd = [t.cuda().to(dtype) for t in x] if isinstance(x, list) else x.cuda().to(dtype)
+    return convert_to_deployable_form(model, xd, dtype=dtype), xd
+
+
+def _golden_case(name, factory):
+    g = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    m = factory(**g["cfg"])
+    deterministic_fill(m, g["seed"]).eval()
+    shapes = g["input_shape"]
+    if isinstance(shapes[0], (tuple, list)):
+        fast = seeded_input(shapes[1], g["seed"])
+        idx = torch.linspace(0, shapes[1][2] - 1, shapes[0][2]).long()
+        x = [fast[:, :, idx].clone(), fast]
+    else:
+        x = seeded_input(shapes, g["seed"])
+    return g, m, x
+
+
+def _oracle(sd, x, dtype, fn):
+    if dtype == torch.bfloat16:
+        if isinstance(x, list):
+            sd = quantize_like_kernels(sd)
+            x = [t.bfloat16().float() for t in x]
+        else:
+            sd, x = quantize_like_kernels(sd, x)
+    return fn(sd, x)
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("name", ["mvit_b_small", "mvit_v2ish_small"])
+def test_mvit_matches_oracle(name, dtype, tol):
+    from pytorchvideo_amd.models import create_multiscale_vision_transformers
+    g, m, x = _golden_case(name, create_multiscale_vision_transformers)
+    want = _oracle(m.state_dict(), x, dtype, lambda sd, xx: OF.mvit_forward(sd, xx, g["cfg"]))
+    if dtype == torch.float32:
+        assert rel_err(want, g["logits"]) <= 1e-5  # oracle == reference fixture
+    dm, xd = _deploy(m, x, dtype)
+    assert type(dm.blocks[0]).__name__ == "Mi355xMViTBlock" and dm.blocks[0].convert_flag
+    got = dm(xd)
+    assert got.shape == want.shape
+    assert rel_err(got, want) <= tol
+    assert torch.equal(dm(xd), got)  # graph replay, no atomics: bitwise reproducible
+
+
+def test_mvit_block_standalone_fp32():
+    """One deployed MultiScaleBlock on its own (token ingest) equals the oracle block output."""
+    from pytorchvideo_amd.models import create_multiscale_vision_transformers
+    g, m, x = _golden_case("mvit_b_small", create_multiscale_vision_transformers)
+    sd = m.state_dict()
+    _, outs = OF.mvit_forward(sd, x, g["cfg"], return_blocks=True)
+    dm, xd = _deploy(m, x, torch.float32)
+    dm(xd)
+    sched = OF.mvit_schedule(g["cfg"])
+    thw = [2, 16, 16]
+    for i in (1, 2):  # block 1 pools q, block 2 widens
+        heads, kq, sq, kkv, skv = sched[i]
+        grid = list(thw) if i == 1 else [2, 8, 8]
+        y, thw_new = dm.blocks[i](outs[i - 1].cuda(), grid)
+        assert rel_err(y, outs[i]) <= 1e-3
+        assert list(thw_new) == [2, 8, 8]
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("name", ["slowfast_r18_small", "slowfast_r50_small"])
+def test_slowfast_matches_oracle(name, dtype, tol):
+    from pytorchvideo_amd.models import create_slowfast
+    g, m, x = _golden_case(name, create_slowfast)
+    pools = g["cfg"]["head_pool_kernel_sizes"]
+    want = _oracle(m.state_dict(), x, dtype,
+                   lambda sd, xx: OF.slowfast_forward(sd, xx[0], xx[1], head_pool_kernels=pools))
+    dm, xd = _deploy(m, x, dtype)
+    got = dm(list(xd))
+    assert got.shape == want.shape
+    assert rel_err(got, want) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+def test_csn_matches_oracle(dtype, tol):
+    from pytorchvideo_amd.models import create_csn
+    g, m, x = _golden_case("csn_r50_small", create_csn)
+    k = g["cfg"]["head_pool_kernel_size"]
+    want = _oracle(m.state_dict(), x, dtype, lambda sd, xx: OF.csn_forward(sd, xx, head_pool_kernel=k))
+    dm, xd = _deploy(m, x, dtype)
+    assert rel_err(dm(xd), want) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+def test_r2plus1d_matches_oracle(dtype, tol):
+    from pytorchvideo_amd.models import create_r2plus1d
+    g, m, x = _golden_case("r2plus1d_r50_small", create_r2plus1d)
+    k = g["cfg"]["head_pool_kernel_size"]
+    want = _oracle(m.state_dict(), x, dtype, lambda sd, xx: OF.r2plus1d_forward(sd, xx, head_pool_kernel=k))
+    dm, xd = _deploy(m, x, dtype)
+    assert rel_err(dm(xd), want) <= tol
