@@ -85,7 +85,8 @@ typedef struct pv_conv3d_desc {
   int32_t act;           /* pv_act applied last                                  */
   int32_t a_act;         /* pv_act applied to x (after a_gate) on load           */
   int32_t dtype;         /* pv_dtype of x, w, residual                           */
-  int32_t y_f32;         /* 1: y is fp32 regardless of dtype (logits)            */
+  int32_t y_f32;         /* 1: y is fp32 regardless of dtype (logits, residual stream) */
+  int32_t r_f32;         /* 1: residual is fp32 regardless of dtype              */
 } pv_conv3d_desc;
 int pv_conv3d(const pv_conv3d_desc* d, pv_stream_t stream);
 
@@ -181,6 +182,7 @@ typedef struct pv_rows_desc {
   int32_t rows_per_batch;                 /* mean_rows only */
   float eps;
   int32_t dtype;                          /* of x; y same except mean_rows (fp32) */
+  int32_t x_f32;                          /* layernorm: 1 = x is fp32 while y is `dtype` */
 } pv_rows_desc;
 int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream);
 int pv_softmax_rows(const pv_rows_desc* d, pv_stream_t stream);

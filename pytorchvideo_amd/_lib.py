@@ -33,7 +33,7 @@ Conv3dDesc = _struct("Conv3dDesc", [
     ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("residual", _p), ("a_gate", _p),
     ("x_bs", _i64), ("y_bs", _i64), ("r_bs", _i64)]
     + _ints("ldx", "ldy", "ldr", "B", "Ti", "Hi", "Wi", "cin", "To", "Ho", "Wo", "cout",
-            "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "act", "a_act", "dtype", "y_f32"))
+            "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "act", "a_act", "dtype", "y_f32", "r_f32"))
 
 DwConv3dDesc = _struct("DwConv3dDesc", [
     ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("psum", _p),
@@ -56,7 +56,7 @@ LayoutDesc = _struct("LayoutDesc", [
 
 RowsDesc = _struct("RowsDesc", [
     ("x", _p), ("y", _p), ("gamma", _p), ("beta", _p), ("rows", _i64)]
-    + _ints("C", "ldx", "ldy", "rows_per_batch") + [("eps", _f32), ("dtype", _i32)])
+    + _ints("C", "ldx", "ldy", "rows_per_batch") + [("eps", _f32), ("dtype", _i32), ("x_f32", _i32)])
 
 PosencDesc = _struct("PosencDesc", [
     ("x", _p), ("cls_token", _p), ("pos_spatial", _p), ("pos_temporal", _p), ("pos_class", _p)]
@@ -107,7 +107,7 @@ _SYMBOLS = [
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

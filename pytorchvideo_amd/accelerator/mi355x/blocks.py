@@ -264,7 +264,7 @@ class Mi355xMViTBlock(Mi355xBlock):
             if thw is None:
                 raise L.PvError("MultiScaleBlock.convert needs thw=(T,H,W) of the token grid")
             B, N, Cc = [int(v) for v in input_blob_size]
-            input_ref = sess.alloc_act(B, 1, 1, N, Cc)
+            input_ref = sess.alloc_act(B, 1, 1, N, Cc, f32=True)  # the residual stream is fp32
             input_ref.thw, input_ref.has_cls = tuple(int(v) for v in thw), bool(self.has_cls_embed)
         first = len(sess.ops)
         out_ref = EM.emit_multiscale_block(sess, self, input_ref)
@@ -292,7 +292,7 @@ def _probe_mvit_block(module):
         scratch = Session(dtype=torch.bfloat16)
         T, H, W = 2, 8, 8
         cls = 1 if module.has_cls_embed else 0
-        x = scratch.alloc_act(1, 1, 1, T * H * W + cls, module.dim)
+        x = scratch.alloc_act(1, 1, 1, T * H * W + cls, module.dim, f32=True)
         x.thw, x.has_cls = (T, H, W), bool(cls)
         EM.emit_multiscale_block(scratch, module, x)
         return True

@@ -144,6 +144,7 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
         B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, cin=cin_p, To=To, Ho=Ho, Wo=Wo, cout=cout,
         kt=kt, kh=kh, kw=kw, st=st, sh=sh, sw=sw, pt=pt, ph=ph, pw=pw,
         act=act, a_act=a_act, dtype=sess.pv_dtype, y_f32=1 if y_f32 else 0,
+        r_f32=1 if (residual is not None and residual.f32) else 0,
     )
     if residual is not None and ((residual.B, residual.T, residual.H, residual.W) != (y.B, y.T, y.H, y.W)
                                  or residual.C != cout):
@@ -151,7 +152,8 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
     vox_in, vox_out = x.B * x.voxels, y.B * y.voxels
     taps = kt * kh * kw
     reads = vox_out * cin_p if taps == 1 else vox_in * cin_p  # each input voxel once
-    alg = sess.itemsize * (reads + cout * taps * cin_p + (vox_out * pad8(cout) if residual is not None else 0)) \
+    alg = sess.itemsize * (reads + cout * taps * cin_p) \
+        + (residual.itemsize * vox_out * pad8(cout) if residual is not None else 0) \
         + (4 if y_f32 else sess.itemsize) * vox_out * pad8(cout)
     flops = 2 * vox_out * cout * taps * x.C
     sess.add_op(L.OP_CONV3D, f, label=label, alg_bytes=alg, flops=flops)
@@ -285,10 +287,10 @@ def emit_pool_raw(sess, x, k, s, p, mode, n_prefix=0, out=None, label="pool", gr
         raise RuntimeError("pool output would be empty")
     if out is None:
         if grid is not None:
-            y = sess.alloc_act(x.B, 1, 1, To * Ho * Wo + n_prefix, x.C)
+            y = sess.alloc_act(x.B, 1, 1, To * Ho * Wo + n_prefix, x.C, f32=x.f32)
             y.thw, y.has_cls = (To, Ho, Wo), n_prefix > 0
         else:
-            y = sess.alloc_act(x.B, To, Ho, Wo, x.C)
+            y = sess.alloc_act(x.B, To, Ho, Wo, x.C, f32=x.f32)
     else:
         y = out
         if grid is None and ((y.B, y.T, y.H, y.W) != (x.B, To, Ho, Wo) or y.C != x.C):
@@ -296,8 +298,10 @@ def emit_pool_raw(sess, x, k, s, p, mode, n_prefix=0, out=None, label="pool", gr
     f = dict(x=x.ptr, y=y.ptr, x_bs=x.bs, y_bs=y.bs, ldx=x.ld, ldy=y.ld,
              B=x.B, Ti=Ti, Hi=Hi, Wi=Wi, C=x.C, To=To, Ho=Ho, Wo=Wo,
              kt=k[0], kh=k[1], kw=k[2], st=s[0], sh=s[1], sw=s[2], pt=p[0], ph=p[1], pw=p[2],
-             mode=mode, n_prefix=n_prefix, dtype=sess.pv_dtype)
-    alg = sess.itemsize * pad8(x.C) * x.B * (Ti * Hi * Wi + To * Ho * Wo)
+             mode=mode, n_prefix=n_prefix, dtype=L.PV_F32 if x.f32 else sess.pv_dtype)
+    if y.f32 != x.f32:
+        raise Unsupported("pool between buffers of different precision")
+    alg = x.itemsize * pad8(x.C) * x.B * (Ti * Hi * Wi + To * Ho * Wo)
     sess.add_op(L.OP_POOL3D, f, label=label, alg_bytes=alg)
     return y
 

@@ -12,6 +12,12 @@ Launch list of one MultiScaleBlock (reference layers/attention.py:729-757):
   -> fused softmax(q k^T) v -> proj GEMM with bias + (max-pooled) skip in its epilogue
   -> LN(norm2) -> fc1 GEMM + bias + GELU -> fc2 GEMM + bias + residual
      (residual = block.proj(x_norm) when the width changes, :754-755).
+
+Precision of the bf16 deploy form: the residual stream (block inputs/outputs, the skip path)
+is kept in fp32 -- LayerNorm reads fp32 and writes the bf16 GEMM operand, the proj / fc2
+epilogues add an fp32 residual and write fp32 -- so that 16 blocks of bf16 roundings do not
+pile up on the stream; every MFMA operand (x_norm, q/k/v, P, attention output, MLP hidden)
+is bf16.
 """
 import torch
 import torch.nn as nn
@@ -57,14 +63,17 @@ def emit_layernorm(sess, norm, x, out=None, rows=None, ldx=None, label="layernor
     if x.bs != x.voxels * x.ld:
         raise Unsupported("LayerNorm on a non-dense token tensor")
     y = out if out is not None else sess.alloc_act(x.B, x.T, x.H, x.W, x.C)
+    if y.f32 and sess.pv_dtype != L.PV_F32:
+        raise Unsupported("LayerNorm with an fp32 output in a bf16 session")
     y.thw, y.has_cls = x.thw, x.has_cls
     n_rows = x.B * x.voxels if rows is None else rows
     f = dict(x=x.ptr, y=y.ptr,
              gamma=sess.add_weight(norm.weight.detach().float()) if norm.weight is not None else None,
              beta=sess.add_weight(norm.bias.detach().float()) if norm.bias is not None else None,
              rows=n_rows, C=x.C, ldx=x.ld if ldx is None else ldx, ldy=y.ld if ldx is None else y.ld,
-             rows_per_batch=0, eps=float(norm.eps), dtype=sess.pv_dtype)
-    sess.add_op(L.OP_LAYERNORM, f, label=label, alg_bytes=2 * sess.itemsize * n_rows * pad8(x.C))
+             rows_per_batch=0, eps=float(norm.eps), dtype=sess.pv_dtype,
+             x_f32=1 if (x.f32 and sess.pv_dtype != L.PV_F32) else 0)
+    sess.add_op(L.OP_LAYERNORM, f, label=label, alg_bytes=(x.itemsize + sess.itemsize) * n_rows * pad8(x.C))
     return y
 
 
@@ -82,7 +91,8 @@ def emit_head_layernorm(sess, norm, x, heads, label="pool.norm"):
     f = dict(x=x.ptr, y=x.ptr,
              gamma=sess.add_weight(norm.weight.detach().float()) if norm.weight is not None else None,
              beta=sess.add_weight(norm.bias.detach().float()) if norm.bias is not None else None,
-             rows=n_rows, C=hd, ldx=hd, ldy=hd, rows_per_batch=0, eps=float(norm.eps), dtype=sess.pv_dtype)
+             rows=n_rows, C=hd, ldx=hd, ldy=hd, rows_per_batch=0, eps=float(norm.eps), dtype=sess.pv_dtype,
+             x_f32=0)
     sess.add_op(L.OP_LAYERNORM, f, label=label, alg_bytes=2 * sess.itemsize * n_rows * hd)
     return x
 
@@ -197,7 +207,7 @@ def emit_multiscale_attention(sess, attn, xn, residual, label="attn"):
     q_thw = q.thw
     for t in owned:
         sess.release(t)
-    y = emit_linear(sess, attn.proj, o, residual=residual, label=label + ".proj")
+    y = emit_linear(sess, attn.proj, o, residual=residual, y_f32=True, label=label + ".proj")
     sess.release(o)
     y.thw = q_thw
     return y
@@ -214,7 +224,7 @@ def emit_multiscale_block(sess, blk, x):
     xn = emit_layernorm(sess, blk.norm1, x, label="norm1")
     skip_src = x
     if blk.dim_mul_in_att and widen:
-        skip_src = emit_linear(sess, blk.proj, xn, label="proj_dim")
+        skip_src = emit_linear(sess, blk.proj, xn, y_f32=True, label="proj_dim")
     if blk._attention_pool.has_pool:
         k, s, p, mode = _pool_params(blk._attention_pool.pool)
         x_res = E.emit_pool_raw(sess, skip_src, k, s, p, mode, n_prefix=1 if blk.has_cls_embed else 0,
@@ -230,11 +240,11 @@ def emit_multiscale_block(sess, blk, x):
     xn2 = emit_layernorm(sess, blk.norm2, x1, label="norm2")
     hmid = emit_linear(sess, blk.mlp.fc1, xn2, act=act, label="mlp.fc1")
     if (not blk.dim_mul_in_att) and widen:
-        res2 = emit_linear(sess, blk.proj, xn2, label="proj_dim")
+        res2 = emit_linear(sess, blk.proj, xn2, y_f32=True, label="proj_dim")
     else:
         res2 = x1
     sess.release(xn2)
-    y = emit_linear(sess, blk.mlp.fc2, hmid, residual=res2, label="mlp.fc2")
+    y = emit_linear(sess, blk.mlp.fc2, hmid, residual=res2, y_f32=True, label="mlp.fc2")
     sess.release(hmid)
     if res2 is not x1:
         sess.release(res2)
@@ -256,11 +266,11 @@ def emit_patch_embed_and_pos(sess, patch_embed, cls_pos, x):
     T, H, W = cls_pos.patch_embed_shape()
     has_cls = bool(cls_pos.cls_embed_on)
     Cc = conv.out_channels
-    tok = sess.alloc_act(x.B, 1, 1, T * H * W + (1 if has_cls else 0), Cc)
+    tok = sess.alloc_act(x.B, 1, 1, T * H * W + (1 if has_cls else 0), Cc, f32=True)  # residual stream
     tok.thw, tok.has_cls = (T, H, W), has_cls
     grid = (tok.row_offset(1) if has_cls else tok).as_grid(T, H, W)
     grid.C = Cc
-    E.emit_conv(sess, conv, x, None, L.ACT_NONE, out=grid, label="patch_embed")
+    E.emit_conv(sess, conv, x, None, L.ACT_NONE, out=grid, y_f32=True, label="patch_embed")
     sep = bool(cls_pos.sep_pos_embed)
 
     def flat(p):
@@ -270,8 +280,8 @@ def emit_patch_embed_and_pos(sess, patch_embed, cls_pos, x):
              pos_spatial=flat(cls_pos.pos_embed_spatial if sep else cls_pos.pos_embed),
              pos_temporal=flat(cls_pos.pos_embed_temporal) if sep else None,
              pos_class=flat(cls_pos.pos_embed_class) if (sep and has_cls) else None,
-             B=x.B, T=T, HW=H * W, C=Cc, ld=tok.ld, dtype=sess.pv_dtype)
-    sess.add_op(L.OP_POSENC, f, label="pos_encoding", alg_bytes=2 * sess.itemsize * x.B * tok.voxels * pad8(Cc))
+             B=x.B, T=T, HW=H * W, C=Cc, ld=tok.ld, dtype=L.PV_F32)
+    sess.add_op(L.OP_POSENC, f, label="pos_encoding", alg_bytes=2 * 4 * x.B * tok.voxels * pad8(Cc))
     return tok
 
 
@@ -294,7 +304,7 @@ def emit_vit_head(sess, norm_embed, head, x):
         xn = x if isinstance(norm_embed, nn.Identity) else emit_layernorm(sess, norm_embed, x, label="norm_embed")
         pooled32 = sess.alloc_act(x.B, 1, 1, 1, x.C, f32=True)
         f = dict(x=xn.ptr, y=pooled32.ptr, gamma=None, beta=None, rows=x.B * x.voxels, C=x.C, ldx=xn.ld,
-                 ldy=pooled32.ld, rows_per_batch=x.voxels, eps=0.0, dtype=sess.pv_dtype)
+                 ldy=pooled32.ld, rows_per_batch=x.voxels, eps=0.0, dtype=sess.pv_dtype, x_f32=0)
         sess.add_op(L.OP_MEAN_ROWS, f, label="head.seq_mean")
         if xn is not x:
             sess.release(xn)

@@ -266,10 +266,16 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const pv_conv3d_de
         v[4 + j] = acc[2 * p + 1][t][j] * sc[4 + j] + sh[4 + j];
       }
       if (R != nullptr) {
-        Chunk8<T> rc;
-        rc.load(R + (long)b * d.r_bs + sp * d.ldr + c0);
         float rf[8];
-        rc.to_f32(rf);
+        if (d.r_f32) {
+          Chunk8<float> rc;
+          rc.load(static_cast<const float*>(d.residual) + (long)b * d.r_bs + sp * d.ldr + c0);
+          rc.to_f32(rf);
+        } else {
+          Chunk8<T> rc;
+          rc.load(R + (long)b * d.r_bs + sp * d.ldr + c0);
+          rc.to_f32(rf);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += rf[j];
       }

@@ -219,20 +219,20 @@ __global__ __launch_bounds__(kThreads) void egress_kernel(const pv_layout_desc d
 
 // --------------------------------------------------------------------- row ops
 // LayerNorm: one wave per row, two-pass statistics in registers (C <= 64*8*MAXC).
-template <typename T, int MAXC>
+template <typename TI, typename T, int MAXC>
 __global__ __launch_bounds__(kThreads) void layernorm_kernel(const pv_rows_desc d) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (row >= d.rows) return;
   const int CG = pv_round_up(d.C, 8) / 8;
-  const T* x = static_cast<const T*>(d.x) + row * d.ldx;
+  const TI* x = static_cast<const TI*>(d.x) + row * d.ldx;
   float f[MAXC][8];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int cg = lane + i * 64;
     if (cg < CG) {
-      Chunk8<T> c;
+      Chunk8<TI> c;
       c.load(x + cg * 8);
       c.to_f32(f[i]);
     } else {
@@ -488,13 +488,16 @@ extern "C" int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream) {
   const int CG = pv_round_up(d->C, 8) / 8;
   dim3 grid((unsigned)pv_ceil_div(d->rows, kThreads / 64)), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define PV_LN(T, MAXC) hipLaunchKernelGGL((layernorm_kernel<T, MAXC>), grid, block, 0, s, *d)
-  if (d->dtype == PV_BF16) {
-    if (CG <= 64) PV_LN(bf16_t, 1); else if (CG <= 128) PV_LN(bf16_t, 2); else if (CG <= 256) PV_LN(bf16_t, 4);
-    else return PV_ERR_UNSUPPORTED;
+#define PV_LN(TI, T, MAXC) hipLaunchKernelGGL((layernorm_kernel<TI, T, MAXC>), grid, block, 0, s, *d)
+  if (d->dtype == PV_BF16 && d->x_f32) {
+    if (CG <= 64) PV_LN(float, bf16_t, 1); else if (CG <= 128) PV_LN(float, bf16_t, 2);
+    else if (CG <= 256) PV_LN(float, bf16_t, 4); else return PV_ERR_UNSUPPORTED;
+  } else if (d->dtype == PV_BF16) {
+    if (CG <= 64) PV_LN(bf16_t, bf16_t, 1); else if (CG <= 128) PV_LN(bf16_t, bf16_t, 2);
+    else if (CG <= 256) PV_LN(bf16_t, bf16_t, 4); else return PV_ERR_UNSUPPORTED;
   } else if (d->dtype == PV_F32) {
-    if (CG <= 64) PV_LN(float, 1); else if (CG <= 128) PV_LN(float, 2); else if (CG <= 256) PV_LN(float, 4);
-    else return PV_ERR_UNSUPPORTED;
+    if (CG <= 64) PV_LN(float, float, 1); else if (CG <= 128) PV_LN(float, float, 2);
+    else if (CG <= 256) PV_LN(float, float, 4); else return PV_ERR_UNSUPPORTED;
   } else return PV_ERR_UNSUPPORTED;
 #undef PV_LN
   PV_LAUNCH_CHECK();
