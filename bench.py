@@ -163,6 +163,7 @@ def main():
     prof = sess.profile(iters=3)
     agg = {}
     for label, kind, ms, alg_bytes, flops in prof:
+        label = label.split("|")[0]
         a = agg.setdefault(label.split(".")[0] if label.startswith("conv_b") else label, [0, 0.0, 0, 0])
         a[0] += 1
         a[1] += ms
@@ -199,6 +200,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
+        if os.environ.get("PV_BENCH_VERBOSE") == "2":
+            for label, kind, ms, alg_bytes, flops in prof:
+                print("  op %-60s %8.4f ms %8.1f GB/s %8.2f TF/s" % (label, ms, alg_bytes / max(ms, 1e-9) / 1e6,
+                                                                   flops / max(ms, 1e-9) / 1e9), file=sys.stderr)
         if os.environ.get("PV_BENCH_VERBOSE"):
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print("  %-16s n=%3d %8.3f ms  %8.1f GB/s  %7.2f TF/s" % (

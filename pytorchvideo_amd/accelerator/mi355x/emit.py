@@ -156,7 +156,9 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
         + (residual.itemsize * vox_out * pad8(cout) if residual is not None else 0) \
         + (4 if y_f32 else sess.itemsize) * vox_out * pad8(cout)
     flops = 2 * vox_out * cout * taps * x.C
-    sess.add_op(L.OP_CONV3D, f, label=label, alg_bytes=alg, flops=flops)
+    detail = "|%dx%dx%dx%d c%d->%d k%dx%dx%d s%d%d%d%s" % (x.B, To, Ho, Wo, x.C, cout, kt, kh, kw, st, sh, sw,
+                                                          " gate" if a_gate is not None else "")
+    sess.add_op(L.OP_CONV3D, f, label=label + detail, alg_bytes=alg, flops=flops)
     return y
 
 
@@ -215,7 +217,8 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
         f["psum"] = psum
     vin, vout = x.B * Ti * Hi * Wi, x.B * To * Ho * Wo
     alg = sess.itemsize * (min(vin, vout * kt * kh * kw) + vout) * pad8(Cc)
-    sess.add_op(L.OP_DWCONV3D, f, label=label, alg_bytes=alg, flops=2 * vout * Cc * kt * kh * kw)
+    detail = "|%dx%dx%dx%d c%d k%dx%dx%d s%d%d%d%s" % (x.B, To, Ho, Wo, Cc, kt, kh, kw, st, sh, sw, " psum" if want_psum else "")
+    sess.add_op(L.OP_DWCONV3D, f, label=label + detail, alg_bytes=alg, flops=2 * vout * Cc * kt * kh * kw)
     if want_psum:
         return y, psum, nblk
     return y

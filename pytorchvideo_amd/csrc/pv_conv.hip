@@ -16,6 +16,8 @@
 // (squeeze-excitation * Swish of X3D folded into conv_c's load).
 #include "pv_common.h"
 
+int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s);  // pv_pwconv.hip
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -337,6 +339,10 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
   const bool pw = taps == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0;
   if ((d.a_gate || d.a_act != PV_ACT_NONE) && !pw) return PV_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (pw && d.dtype == PV_BF16) {
+    const int r = pv_pwconv_stream_try(d, s);  // HBM-bound widths: streaming kernel (pv_pwconv.hip)
+    if (r != PV_ERR_UNSUPPORTED) return r;
+  }
   if (d.dtype == PV_BF16) return launch_conv<bf16_t>(d, pw, s);
   if (d.dtype == PV_F32) return launch_conv<float>(d, pw, s);
   return PV_ERR_UNSUPPORTED;

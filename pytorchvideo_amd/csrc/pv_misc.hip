@@ -12,13 +12,35 @@ constexpr int kThreads = 256;
 // one block per batch item; psum[b][blk][c_p] -> gate[b][c_p]
 __global__ __launch_bounds__(kThreads) void se_gate_kernel(const pv_se_gate_desc d) {
   extern __shared__ float s[];
-  float* s_mean = s;            // [c_p]
-  float* s_hid = s + d.c_p;     // [cr]
+  float* s_mean = s;                 // [c_p]
+  float* s_hid = s + d.c_p;          // [cr]
+  float* s_part = s + d.c_p + d.cr;  // [groups][c_p]
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* ps = d.psum + (long)b * d.nblk * d.c_p;
+  // rows of the partial-sum table are split over `groups` thread groups; each group walks its
+  // rows with coalesced loads over the channels (4 independent loads in flight per thread)
+  const int cw = d.c_p < kThreads ? d.c_p : kThreads;   // channels covered per pass
+  const int groups = kThreads / cw;
+  const int g = tid / cw, cl = tid - g * cw;
+  for (int c0 = 0; c0 < d.c_p; c0 += cw) {
+    const int c = c0 + cl;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (g < groups && c < d.c_p) {
+      int k = g;
+      for (; k + 3 * groups < d.nblk; k += 4 * groups) {
+        a0 += ps[(long)k * d.c_p + c];
+        a1 += ps[(long)(k + groups) * d.c_p + c];
+        a2 += ps[(long)(k + 2 * groups) * d.c_p + c];
+        a3 += ps[(long)(k + 3 * groups) * d.c_p + c];
+      }
+      for (; k < d.nblk; k += groups) a0 += ps[(long)k * d.c_p + c];
+      s_part[g * d.c_p + c] = (a0 + a1) + (a2 + a3);
+    }
+  }
+  __syncthreads();
   for (int c = tid; c < d.c_p; c += kThreads) {
     float a = 0.f;
-    for (int k = 0; k < d.nblk; ++k) a += ps[(long)k * d.c_p + c];
+    for (int gg = 0; gg < groups; ++gg) a += s_part[gg * d.c_p + c];
     s_mean[c] = a * d.inv_count;
   }
   __syncthreads();
@@ -32,13 +54,13 @@ __global__ __launch_bounds__(kThreads) void se_gate_kernel(const pv_se_gate_desc
   }
   __syncthreads();
   for (int c = tid; c < d.c_p; c += kThreads) {
-    float g = 0.f;
+    float g2 = 0.f;
     if (c < d.C) {
       float a = d.b2 ? d.b2[c] : 0.f;
       for (int r = 0; r < d.cr; ++r) a += d.w2[(long)c * d.cr + r] * s_hid[r];
-      g = pv_sigmoid(a);
+      g2 = pv_sigmoid(a);
     }
-    d.gate[(long)b * d.c_p + c] = g;
+    d.gate[(long)b * d.c_p + c] = g2;
   }
 }
 
@@ -382,7 +404,8 @@ inline unsigned blocks_for(long total) { return (unsigned)pv_ceil_div(total, kTh
 extern "C" int pv_se_gate(const pv_se_gate_desc* d, pv_stream_t stream) {
   if (!d || !d->psum || !d->gate || !d->w1 || !d->w2) return PV_ERR_INVALID;
   if (d->B <= 0 || d->C <= 0 || d->cr <= 0 || d->nblk <= 0 || d->c_p < d->C || d->c_p % 8) return PV_ERR_INVALID;
-  const size_t lds = sizeof(float) * (d->c_p + d->cr);
+  const int cw = d->c_p < kThreads ? d->c_p : kThreads;
+  const size_t lds = sizeof(float) * ((size_t)d->c_p + d->cr + (size_t)(kThreads / cw) * d->c_p);
   hipLaunchKernelGGL(se_gate_kernel, dim3(d->B), dim3(kThreads), lds, static_cast<hipStream_t>(stream), *d);
   PV_LAUNCH_CHECK();
   return PV_OK;

@@ -1,0 +1,295 @@
+// Streaming pointwise (1x1x1, stride 1) convolution for the HBM-bound widths of X3D
+// (cin, cout <= a few hundred): out[voxel][n] = act( sum_k x'[voxel][k] w[n][k] * scale + shift + r ).
+//
+// These layers are "the same small GEMM at shrinking M": K and N are far too small to
+// amortise an LDS-staged, barrier-synchronised tile pipeline, and the arithmetic intensity
+// (17..133 FLOP/B) leaves the matrix cores idle -- the kernel has to behave like a streaming
+// copy with an MFMA in the middle:
+//   * the whole weight slab of the block (<= 128 output channels x K) is staged into LDS once,
+//     then the block walks voxel groups in a grid-stride loop with NO further barriers;
+//   * activations go global -> registers directly in MFMA B-operand shape: lane (n = lane&15,
+//     q = lane>>4) loads the 16 bytes x[voxel n][k0 + 8q .. 8q+7]; with channels-last rows that
+//     are back to back a wave's load covers one contiguous run of 16 voxels;
+//   * weights are the A operand with LDS rows permuted (pairs of 16-channel tiles interleaved
+//     in groups of 4) so a lane ends up with 8 contiguous output channels of its voxel: the
+//     epilogue (folded BN, residual, activation) stays in registers, one 16-byte store per lane;
+//   * latency is hidden by occupancy (4-8 waves per SIMD, every wave with several KB in flight)
+//     plus a one-chunk software prefetch along K;
+//   * squeeze-excitation: x' = swish(x * gate[b][k]) is applied to the operand registers; the
+//     gate rows of the (at most two) clips a wave's voxels belong to are cached in a wave-private
+//     LDS region, refreshed only when the wave crosses a clip boundary.
+#include "pv_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kKC = 1;  // k-steps (of 32 channels) per register chunk
+
+struct PwRows {  // per-lane geometry of one wave tile group: clip index and voxel within the clip (-1: none)
+  int b[4];
+  int sp[4];
+};
+
+template <int NT, int TM, bool XFORM, int KS>
+__global__ __launch_bounds__(kThreads, 4) void pw_stream_kernel(const pv_conv3d_desc d, int ksteps_rt, int ngroups) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int ksteps = KS > 0 ? KS : ksteps_rt;
+  const int Kp = ksteps * 32;
+  const int WLD = Kp + 8;  // weight row stride (elements): 16 B x odd -> conflict-free ds_read_b128
+  bf16_t* w_s = reinterpret_cast<bf16_t*>(smem_raw);
+  float* sc_s = reinterpret_cast<float*>(smem_raw + (size_t)NT * 16 * WLD * 2);
+  float* sh_s = sc_s + NT * 16;
+  float* gate_s = sh_s + NT * 16;  // [4 waves][2][cin]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int n16 = lane & 15;
+  const int q = lane >> 4;
+  const int cout_p8 = pv_round_up(d.cout, 8);
+  const int n0 = blockIdx.y * (NT * 16);
+  const long S_out = (long)d.To * d.Ho * d.Wo;
+  const long M = (long)d.B * S_out;
+
+  // ---- stage weights (row r of LDS = output channel n0 + perm(r)), scale, shift ----
+  {
+    const bf16_t* __restrict__ Wt = static_cast<const bf16_t*>(d.w);
+    const int cpr = Kp / 8;  // chunks per row
+    for (int id = tid; id < NT * 16 * cpr; id += kThreads) {
+      const int r = id / cpr, kc = id - r * cpr;
+      const int tn = r >> 4, ii = r & 15;
+      const int c = n0 + (tn >> 1) * 32 + (ii >> 2) * 8 + (tn & 1) * 4 + (ii & 3);
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (c < d.cout && kc * 8 < d.cin) v = *reinterpret_cast<const bf16x8*>(Wt + (long)c * d.cin + kc * 8);
+      *reinterpret_cast<bf16x8*>(w_s + r * WLD + kc * 8) = v;
+    }
+    for (int i = tid; i < NT * 16; i += kThreads) {
+      const int c = n0 + i;
+      const bool ok = c < d.cout;
+      sc_s[i] = ok ? (d.scale ? d.scale[c] : 1.f) : 0.f;
+      sh_s[i] = ok ? (d.shift ? d.shift[c] : 0.f) : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const bf16_t* __restrict__ X = static_cast<const bf16_t*>(d.x);
+  const bool has_gate = XFORM && d.a_gate != nullptr;
+  const bool has_res = d.residual != nullptr;
+  float* my_gate = gate_s + wave * 2 * d.cin;
+  long gate_b0 = -1;  // first clip whose gate rows are cached by this wave
+  const int live_pairs = min(NT / 2, (cout_p8 - n0 + 31) / 32);  // wave-uniform
+  constexpr int NP = NT / 2;
+  constexpr int KSR = KS > 0 ? KS : 1;
+
+  auto rows_of = [&](int g, PwRows& r) {
+    const long m_base = ((long)g * 4 + wave) * (TM * 16);
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      const long m = m_base + t * 16 + n16;
+      const bool ok = g < ngroups && m < M;
+      const long mm = ok ? m : 0;
+      const long b = mm / S_out;
+      r.b[t] = (int)b;
+      r.sp[t] = ok ? (int)(mm - b * S_out) : -1;
+    }
+  };
+  auto load_x = [&](bf16x8 (&dst)[KSR][TM], const PwRows& r, int ks0) {
+#pragma unroll
+    for (int kk = 0; kk < KSR; ++kk) {
+      const int k0 = (ks0 + kk) * 32 + q * 8;
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        if (r.sp[t] >= 0 && k0 < d.cin)
+          dst[kk][t] = *reinterpret_cast<const bf16x8*>(X + (long)r.b[t] * d.x_bs + (long)r.sp[t] * d.ldx + k0);
+        else dst[kk][t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+  };
+  // residual chunks in the epilogue's shape: [pair][tile] -> 8 bf16 channels (raw 16 bytes)
+  auto load_res = [&](f32x4 (&dst)[NP][TM], const PwRows& r) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c0 = n0 + p * 32 + q * 8;
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        if (has_res && r.sp[t] >= 0 && p < live_pairs && c0 < cout_p8)
+          dst[p][t] = *reinterpret_cast<const f32x4*>(static_cast<const bf16_t*>(d.residual) + (long)r.b[t] * d.r_bs +
+                                                      (long)r.sp[t] * d.ldr + c0);
+        else
+          dst[p][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto xform = [&](bf16x8 (&src)[KSR][TM], const PwRows& r, int ks0) {
+#pragma unroll
+    for (int kk = 0; kk < KSR; ++kk) {
+      const int k0 = (ks0 + kk) * 32 + q * 8;
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)src[kk][t][j];
+        if (has_gate && k0 < d.cin) {
+          const float* gp = my_gate + (r.b[t] - (int)gate_b0) * d.cin + k0;
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp);
+          const f32x4 g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { f[j] *= g0[j]; f[4 + j] *= g1[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) src[kk][t][j] = (bf16_t)pv_apply_act(f[j], d.a_act);
+      }
+    }
+  };
+  auto mma = [&](f32x4 (&acc)[NT][TM], const bf16x8 (&src)[KSR][TM], int ks0) {
+#pragma unroll
+    for (int kk = 0; kk < KSR; ++kk) {
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        if ((a >> 1) < live_pairs) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w_s + (a * 16 + n16) * WLD + (ks0 + kk) * 32 + q * 8);
+#pragma unroll
+          for (int t = 0; t < TM; ++t)
+            acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, src[kk][t], acc[a][t], 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto refresh_gate = [&](int g) {
+    if (!has_gate || g >= ngroups) return;
+    const long b_first = (((long)g * 4 + wave) * (TM * 16)) / S_out;  // wave-uniform
+    if (b_first < d.B && b_first != gate_b0) {
+      for (int i = lane; i < 2 * d.cin; i += 64) {
+        const long bb = b_first + (i >= d.cin ? 1 : 0);
+        my_gate[i] = bb < d.B ? d.a_gate[bb * d.cin + (i >= d.cin ? i - d.cin : i)] : 0.f;
+      }
+      gate_b0 = b_first;
+    }
+  };
+
+  PwRows cur, nxt;
+  bf16x8 xf[KSR][TM];
+  f32x4 rcur[NP][TM];
+  int g = blockIdx.x;
+  rows_of(g, cur);
+  load_x(xf, cur, 0);
+  for (; g < ngroups; g += gridDim.x) {
+    load_res(rcur, cur);  // consumed by the epilogue: in flight during the transform and the MFMAs
+    f32x4 acc[NT][TM];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int t = 0; t < TM; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    refresh_gate(g);
+    rows_of(g + gridDim.x, nxt);
+    if constexpr (KS > 0) {
+      if (XFORM) xform(xf, cur, 0);
+      mma(acc, xf, 0);
+      load_x(xf, nxt, 0);          // the operand registers are free again: prefetch the next group
+    } else {
+      for (int ks = 0; ks < ksteps; ++ks) {
+        if (XFORM) xform(xf, cur, ks);
+        bf16x8 xn[KSR][TM];
+        if (ks + 1 < ksteps) load_x(xn, cur, ks + 1);
+        mma(acc, xf, ks);
+        if (ks + 1 < ksteps) {
+#pragma unroll
+          for (int t = 0; t < TM; ++t) xf[0][t] = xn[0][t];
+        }
+      }
+      load_x(xf, nxt, 0);
+    }
+
+    // ---- epilogue ----
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (p >= live_pairs) break;
+      const int cl = p * 32 + q * 8;   // channel within the block's slab
+      const int c0 = n0 + cl;
+      if (c0 >= cout_p8) continue;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc_s + cl), s1 = *reinterpret_cast<const f32x4*>(sc_s + cl + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh_s + cl), h1 = *reinterpret_cast<const f32x4*>(sh_s + cl + 4);
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        if (cur.sp[t] < 0) continue;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[2 * p][t][j] * s0[j] + h0[j];
+          v[4 + j] = acc[2 * p + 1][t][j] * s1[j] + h1[j];
+        }
+        if (has_res) {
+          const bf16x8 rb = __builtin_bit_cast(bf16x8, rcur[p][t]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += (float)rb[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[j] = pv_apply_act(v[j], d.act);
+          if (c0 + j >= d.cout) v[j] = 0.f;
+        }
+        Chunk8<bf16_t> oc;
+        oc.from_f32(v);
+        oc.store(static_cast<bf16_t*>(d.y) + (long)cur.b[t] * d.y_bs + (long)cur.sp[t] * d.ldy + c0);
+      }
+    }
+    cur = nxt;
+  }
+}
+
+template <int NT, int TM, bool XFORM, int KS>
+int launch_pw_k(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) {
+  const long M = (long)d.B * d.To * d.Ho * d.Wo;
+  const long ngroups = pv_ceil_div(M, 4 * TM * 16);
+  const int nsplit = (int)pv_ceil_div(pv_round_up(d.cout, 8), NT * 16);
+  if (ngroups > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
+  auto kern = pw_stream_kernel<NT, TM, XFORM, KS>;
+  if (lds > 64 * 1024)
+    PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // enough resident blocks to fill the chip a few times over; the rest is the grid-stride loop
+  long gx = ngroups < 2048 ? ngroups : 2048;
+  if (nsplit > 1) gx = pv_ceil_div(gx, nsplit) > 256 ? pv_ceil_div(gx, nsplit) : (ngroups < 256 ? ngroups : 256);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nsplit), dim3(kThreads), lds, s, d, ksteps, (int)ngroups);
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
+template <int NT, int TM, bool XFORM>
+int launch_pw_x(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) {
+  // whole-K register residency (with cross-group prefetch) only where it does not spill
+  if (ksteps == 1) return launch_pw_k<NT, TM, XFORM, 1>(d, ksteps, lds, s);
+  if (ksteps == 2) return launch_pw_k<NT, TM, XFORM, 2>(d, ksteps, lds, s);
+  if constexpr (NT <= 4) {
+    if (ksteps == 3) return launch_pw_k<NT, TM, XFORM, 3>(d, ksteps, lds, s);
+  }
+  if constexpr (NT <= 2) {
+    if (ksteps == 4) return launch_pw_k<NT, TM, XFORM, 4>(d, ksteps, lds, s);
+  }
+  return launch_pw_k<NT, TM, XFORM, 0>(d, ksteps, lds, s);
+}
+
+template <int NT, int TM>
+int launch_pw(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) {
+  if (d.a_gate != nullptr || d.a_act != PV_ACT_NONE) return launch_pw_x<NT, TM, true>(d, ksteps, lds, s);
+  return launch_pw_x<NT, TM, false>(d, ksteps, lds, s);
+}
+
+}  // namespace
+
+// Returns PV_OK when the streaming kernel took the op, PV_ERR_UNSUPPORTED to let the caller
+// fall back to the generic implicit-GEMM kernel.
+int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s) {
+  if (d.dtype != PV_BF16 || d.y_f32 || d.r_f32) return PV_ERR_UNSUPPORTED;
+  const long S_out = (long)d.To * d.Ho * d.Wo;
+  if (d.a_gate && S_out < 64) return PV_ERR_UNSUPPORTED;  // a 64-voxel wave tile must span <= 2 clips
+  const int cout_p8 = pv_round_up(d.cout, 8);
+  const int ksteps = (d.cin + 31) / 32;
+  if (ksteps > 8) return PV_ERR_UNSUPPORTED;
+  int NT = cout_p8 <= 32 ? 2 : (cout_p8 <= 64 ? 4 : 8);
+  const size_t lds = (size_t)NT * 16 * (ksteps * 32 + 8) * 2 + (size_t)2 * NT * 16 * 4 +
+                     (d.a_gate ? (size_t)4 * 2 * d.cin * 4 : 0);
+  if (lds > 96 * 1024) return PV_ERR_UNSUPPORTED;
+  if (NT == 2) return launch_pw<2, 2>(d, ksteps, lds, s);
+  if (NT == 4) return launch_pw<4, 2>(d, ksteps, lds, s);
+  return launch_pw<8, 1>(d, ksteps, lds, s);
+}

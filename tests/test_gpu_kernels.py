@@ -183,3 +183,47 @@ def test_linear_as_pointwise_conv(dtype, M, K, N, act, res):
     d.act, d.a_act, d.dtype, d.y_f32 = act, L.ACT_NONE, pv_dtype(x), 0
     call("pv_conv3d", d)
     assert rel_err(y, want) <= TOL[dtype]
+
+
+# ------------------------------------------------------------------ X3D pointwise convs (streaming kernel)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,K,N,gate,res", [
+    (2, 3136, 24, 54, False, False),    # conv_a res2
+    (3, 784, 54, 24, True, True),       # conv_c res2 with SE gate + swish on load + residual
+    (2, 100, 108, 48, True, True),      # S not a multiple of 16: wave tiles straddle clips
+    (2, 196, 216, 96, True, True), (1, 200, 96, 216, False, False), (2, 49, 192, 432, False, False),
+    (2, 80, 432, 192, True, True),      # K too large for the streaming kernel -> generic path
+])
+def test_pointwise_conv_with_se_gate_swish_and_residual(dtype, B, S, K, N, gate, res):
+    Kp, Np = (K + 7) // 8 * 8, (N + 7) // 8 * 8
+    x = torch.zeros(B, S, Kp, dtype=dtype, device="cuda")
+    x[:, :, :K] = _rand((B, S, K), 51, dtype)
+    w = torch.zeros(N, Kp, dtype=dtype, device="cuda")
+    w[:, :K] = _rand((N, K), 52, dtype, K ** -0.5)
+    scale, shift = _rand((N,), 53, torch.float32) * 0.2 + 1.0, _rand((N,), 54, torch.float32)
+    g = torch.zeros(B, Kp, dtype=torch.float32, device="cuda")
+    g[:, :K] = torch.sigmoid(_rand((B, K), 55, torch.float32))
+    r = torch.zeros(B, S, Np, dtype=dtype, device="cuda")
+    r[:, :, :N] = _rand((B, S, N), 56, dtype)
+    xin = x.float()[:, :, :K]
+    if gate:
+        xin = xin * g[:, None, :K]
+        xin = xin * torch.sigmoid(xin)
+        if dtype == torch.bfloat16:
+            xin = xin.bfloat16().float()   # the kernel feeds the MFMA a bf16 operand
+    want = F.linear(xin, w.float()[:, :K]) * scale + shift
+    if res:
+        want = want + r.float()[:, :, :N]
+    want = F.relu(want)
+    y = torch.full((B, S, Np), 3.0, dtype=dtype, device="cuda")
+    d = L.Conv3dDesc()
+    d.x, d.w, d.y, d.scale, d.shift = x.data_ptr(), w.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr()
+    d.residual = r.data_ptr() if res else None
+    d.a_gate = g.data_ptr() if gate else None
+    d.x_bs, d.y_bs, d.r_bs, d.ldx, d.ldy, d.ldr = S * Kp, S * Np, S * Np, Kp, Np, Np
+    d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, 1, 1, S, Kp, 1, 1, S, N
+    d.kt = d.kh = d.kw = d.st = d.sh = d.sw = 1
+    d.act, d.a_act, d.dtype = L.ACT_RELU, (L.ACT_SWISH if gate else L.ACT_NONE), pv_dtype(x)
+    call("pv_conv3d", d)
+    assert rel_err(y[:, :, :N], want) <= TOL[dtype]
+    assert torch.all(y[:, :, N:] == 0)   # padding channels are written as exact zeros
