@@ -62,7 +62,8 @@ template <> struct alignas(16) Chunk8<float> {
   }
 };
 
-__device__ __forceinline__ float pv_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// 1/(1+e^-x) with the hardware reciprocal (1 ulp) instead of an IEEE division sequence
+__device__ __forceinline__ float pv_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float pv_apply_act(float v, int act) {
   switch (act) {

@@ -7,6 +7,7 @@
 // fp32.  The folded-BN affine, the activation and (optionally) the per-block partial sums
 // for the squeeze-excitation mean are fused into the epilogue; partial sums are written
 // per block (no atomics) so the result is run-to-run deterministic.
+#include <type_traits>
 #include "pv_common.h"
 
 namespace {
@@ -175,6 +176,247 @@ __global__ void dw_prefix_kernel(const pv_dwconv3d_desc d) {
   c.store(static_cast<T*>(d.y) + (long)b * d.y_bs + (long)r * d.ldy + cg * 8);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// 3x3x3 depthwise conv, temporal stride 1, spatial stride 1 or 2 (X3D conv_b): plane streaming.
+//
+// The generic kernel above re-reads every input voxel ~13x through the vector cache and is
+// bound by the texture-address path, not by HBM.  Here a workgroup (4 waves) owns a
+// (4 x 4*NW) output tile of one clip and 32 channels and walks the T axis:
+//   * every input plane (tile + halo, 32 channels = 64 B per voxel) is staged through LDS
+//     exactly once, double-buffered, one barrier per plane;
+//   * a lane owns ONE CHANNEL PAIR (lane&15) of NW consecutive output columns of one row
+//     (wave = row, lane>>4 = column group), so its 27 x 2 filter taps are loop-invariant and
+//     stay in 54 registers for the whole kernel -- no per-tap weight traffic at all;
+//   * each input dword (2 bf16 channels) is read from LDS once per plane, converted to fp32
+//     once and scattered with packed FMAs into THREE rolling accumulator sets (outputs t-1, t,
+//     t+1): LDS traffic and conversions are 3x lower than in a gather formulation;
+//   * output plane t-1 is finished after input plane t: folded BN, activation, store (16 lanes
+//     cover 64 contiguous bytes of a voxel), and -- for squeeze-excitation -- lane-private
+//     partial sums reduced once per workgroup (no atomics: bitwise reproducible).
+constexpr int kPlaneThreads = 256;  // 4 waves = 4 output rows
+constexpr int kPR = kPlaneThreads / 64;
+
+template <int S, int NW, int ACT>
+__global__ __launch_bounds__(kPlaneThreads) void dw3_plane_kernel(const pv_dwconv3d_desc d) {
+  constexpr int TW = 4 * NW;               // tile width (outputs)
+  constexpr int IH = (kPR - 1) * S + 3;
+  constexpr int IW = (TW - 1) * S + 3;
+  constexpr bool kDeep = S == 1;          // small planes: keep two of them in flight
+  constexpr int IWP = (IW + 1) & ~1;       // LDS row pitch (even: columns are pair-swapped)
+  constexpr int NVOX = IH * IW;
+  constexpr int NITEM = NVOX * 4;          // 16-byte items per plane
+  constexpr int NST = (NITEM + kPlaneThreads - 1) / kPlaneThreads;
+  constexpr int NC = (NW - 1) * S + 3;     // input columns feeding a lane's NW outputs
+  __shared__ __attribute__((aligned(16))) bf16_t s_in[2][IH * IWP][32];
+  __shared__ float s_ps[kPR][32];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int row = tid >> 6;                // wave = output row of the tile
+  const int cp = lane & 15;                // channel pair inside the 32-channel slab
+  const int sx = lane >> 4;                // column group
+  const int c_p = pv_round_up(d.C, 8);
+  const int cbase = blockIdx.y * 32;
+  const int ch = cbase + cp * 2;           // first of this lane's two channels
+  const bool ch_ok = ch < c_p;
+  const int tiles_w = (d.Wo + TW - 1) / TW;
+  const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
+  const int b = blockIdx.z;
+  const int ho0 = th * kPR, wo0 = tw * TW;
+  const int ho = ho0 + row, wo_first = wo0 + sx * NW;
+  const int hi0 = ho0 * S - 1, wi0 = wo0 * S - 1;
+
+  // Buffer descriptors over this clip's input / output: out-of-range offsets (halo outside the
+  // image, padded channels, masked outputs) read as 0 / are dropped by the hardware, so the plane
+  // loop has no exec-masked branches and the compiler keeps counted vmcnt waits.
+  constexpr unsigned kOOB = 0x80000000u;
+  const bf16_t* X = static_cast<const bf16_t*>(d.x) + (long)b * d.x_bs;
+  bf16_t* Y = static_cast<bf16_t*>(d.y) + (long)b * d.y_bs;
+  const unsigned x_plane_bytes = (unsigned)(d.Hi * d.Wi * d.ldx) * 2u;
+  const unsigned y_plane_bytes = (unsigned)(d.Ho * d.Wo * d.ldy) * 2u;
+  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(x_plane_bytes * (unsigned)d.Ti), 0x00020000);
+  __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)Y, 0, (int)(y_plane_bytes * (unsigned)d.To), 0x00020000);
+
+  // ---- this lane's 27 x 2 filter taps, folded-BN scale/shift: registers for the whole kernel ----
+  float2 wt[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+    wt[t] = ch_ok ? *reinterpret_cast<const float2*>(d.w + (long)t * c_p + ch) : float2{0.f, 0.f};
+  float2 sc = {0.f, 0.f}, sh = {0.f, 0.f};
+  if (ch_ok) {
+    sc.x = ch < d.C ? (d.scale ? d.scale[ch] : 1.f) : 0.f;
+    sc.y = ch + 1 < d.C ? (d.scale ? d.scale[ch + 1] : 1.f) : 0.f;
+    sh.x = ch < d.C ? (d.shift ? d.shift[ch] : 0.f) : 0.f;
+    sh.y = ch + 1 < d.C ? (d.shift ? d.shift[ch + 1] : 0.f) : 0.f;
+  }
+
+  // ---- staging geometry (fixed across planes) ----
+  // LDS column permutation: the two 16-lane halves of a 32-lane bank group read columns that are
+  // NW*S apart; with 64-byte voxels they would share banks, so odd groups of NW*S columns are
+  // stored pair-swapped (col ^ 1) -> conflict-free ds_read_b32
+  auto colperm = [](int c) { return c ^ ((c / (NW * S)) & 1); };
+  unsigned st_off[NST];   // byte offset inside a plane, or kOOB (reads as zero)
+  int st_lds[NST];        // LDS element index, or -1 (no such item)
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int id = tid + i * kPlaneThreads;
+    const int v = id >> 2, c = id & 3;
+    const int ih = v / IW, iw = v - ih * IW;
+    const int hi = hi0 + ih, wi = wi0 + iw;
+    const bool ok = id < NITEM && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi &&
+                    (cbase + c * 8) < c_p;
+    st_off[i] = ok ? (unsigned)((hi * d.Wi + wi) * d.ldx + cbase + c * 8) * 2u : kOOB;
+    st_lds[i] = id < NITEM ? (ih * IWP + colperm(iw)) * 32 + c * 8 : -1;
+  }
+  // two register sets: planes p+1 and p+2 are in flight while plane p is computed (with few workgroups
+  // per CU the bytes in flight, not the ALUs, set the streaming rate)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 st_a[NST], st_b[NST];
+  auto load_plane = [&](u32x4 (&reg)[NST], int p) {
+    if (p >= d.Ti) return;   // wave-uniform
+    const unsigned pb = (unsigned)p * x_plane_bytes;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(st_off[i] + pb), 0, 0);
+  };
+  auto store_plane = [&](const u32x4 (&reg)[NST], int p) {
+    if (p >= d.Ti) return;
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+      if ((i + 1) * kPlaneThreads <= NITEM || st_lds[i] >= 0)
+        *reinterpret_cast<u32x4*>(&s_in[p & 1][0][0] + st_lds[i]) = reg[i];
+  };
+
+  float2 acc[3][NW];   // acc[0] = output p-1 (finished by plane p), acc[1] = output p, acc[2] = output p+1
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int n = 0; n < NW; ++n) acc[a][n] = float2{0.f, 0.f};
+  float2 ps = {0.f, 0.f};
+
+  // per-output store offsets inside an output plane (kOOB: masked)
+  unsigned y_off[NW];
+#pragma unroll
+  for (int n = 0; n < NW; ++n) {
+    const int wo = wo_first + n;
+    const bool ok = ch_ok && ho < d.Ho && wo < d.Wo;
+    y_off[n] = ok ? (unsigned)((ho * d.Wo + wo) * d.ldy + ch) * 2u : kOOB;
+  }
+  auto finalize = [&](float2 (&a)[NW], int t) {
+    const unsigned tb = (unsigned)t * y_plane_bytes;
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+      float v0 = a[n].x * sc.x + sh.x, v1 = a[n].y * sc.y + sh.y;
+      const bool ok = y_off[n] != kOOB;
+      ps.x += ok ? v0 : 0.f;
+      ps.y += ok ? v1 : 0.f;
+      if (ACT == PV_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+      else if (ACT == PV_ACT_SWISH) { v0 *= pv_sigmoid(v0); v1 *= pv_sigmoid(v1); }
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      const bf16x2_t o = {(bf16_t)v0, (bf16_t)v1};
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ry, (int)(y_off[n] + tb), 0, 0);
+    }
+  };
+
+  auto plane = [&](int p) {
+    const bf16_t* base = &s_in[p & 1][0][0] + cp * 2;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      float2 x[NC];
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const uint32_t u = *reinterpret_cast<const uint32_t*>(base + ((row * S + dh) * IWP + colperm(sx * NW * S + i)) * 32);
+        x[i].x = __uint_as_float(u << 16);
+        x[i].y = __uint_as_float(u & 0xffff0000u);
+      }
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const float2 w0 = wt[(0 * 3 + dh) * 3 + dw];   // kt = 0 feeds output p+1
+        const float2 w1 = wt[(1 * 3 + dh) * 3 + dw];   // kt = 1: output p
+        const float2 w2 = wt[(2 * 3 + dh) * 3 + dw];   // kt = 2: output p-1
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+          const float2 xv = x[n * S + dw];
+          acc[2][n].x += xv.x * w0.x; acc[2][n].y += xv.y * w0.y;
+          acc[1][n].x += xv.x * w1.x; acc[1][n].y += xv.y * w1.y;
+          acc[0][n].x += xv.x * w2.x; acc[0][n].y += xv.y * w2.y;
+        }
+      }
+    }
+    if (p >= 1) finalize(acc[0], p - 1);
+    if (p == d.Ti - 1) finalize(acc[1], p);
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+      acc[0][n] = acc[1][n];
+      acc[1][n] = acc[2][n];
+      acc[2][n] = float2{0.f, 0.f};
+    }
+  };
+
+  load_plane(st_a, 0);
+  if (kDeep) load_plane(st_b, 1);
+  store_plane(st_a, 0);
+  __syncthreads();
+  if (kDeep) {
+    for (int p = 0; p < d.Ti; p += 2) {
+      load_plane(st_a, p + 2);     // st_b holds plane p+1
+      plane(p);
+      store_plane(st_b, p + 1);
+      __syncthreads();
+      if (p + 1 < d.Ti) {
+        load_plane(st_b, p + 3);   // st_a holds plane p+2
+        plane(p + 1);
+        store_plane(st_a, p + 2);
+        __syncthreads();
+      }
+    }
+  } else {
+    for (int p = 0; p < d.Ti; ++p) {
+      load_plane(st_a, p + 1);
+      plane(p);
+      store_plane(st_a, p + 1);
+      __syncthreads();
+    }
+  }
+
+  if (d.psum != nullptr) {
+    // lanes cp, cp+16, cp+32, cp+48 of a wave hold the same channel pair; then across the rows of the tile
+    ps.x += __shfl_xor(ps.x, 16, 64); ps.y += __shfl_xor(ps.y, 16, 64);
+    ps.x += __shfl_xor(ps.x, 32, 64); ps.y += __shfl_xor(ps.y, 32, 64);
+    if (lane < 16) { s_ps[row][cp * 2] = ps.x; s_ps[row][cp * 2 + 1] = ps.y; }
+    __syncthreads();
+    if (tid < 32 && cbase + tid < c_p) {
+      float a = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < kPR; ++rr) a += s_ps[rr][tid];
+      d.psum[((long)b * gridDim.x + blockIdx.x) * c_p + cbase + tid] = a;
+    }
+  }
+}
+
+// which layers the plane-streaming kernel takes, and with how many outputs per lane
+int plane_variant(const pv_dwconv3d_desc& d) {
+  if (d.dtype != PV_BF16 || d.w_mod != 0 || d.n_prefix != 0) return 0;
+  if (d.kt != 3 || d.kh != 3 || d.kw != 3 || d.st != 1 || d.pt != 1 || d.ph != 1 || d.pw != 1) return 0;
+  if (d.sh != d.sw || (d.sw != 1 && d.sw != 2)) return 0;
+  if (d.act != PV_ACT_NONE && d.act != PV_ACT_RELU && d.act != PV_ACT_SWISH) return 0;
+  if ((long)d.Ti * d.Hi * d.Wi * d.ldx > 0x3fffffffL || (long)d.To * d.Ho * d.Wo * d.ldy > 0x3fffffffL)
+    return 0;   // 31-bit byte offsets inside a clip (buffer addressing)
+  return d.Wo >= 12 ? 4 : 2;
+}
+
+int plane_tiles(const pv_dwconv3d_desc& d, int nw) { return ((d.Ho + kPR - 1) / kPR) * ((d.Wo + 4 * nw - 1) / (4 * nw)); }
+
+template <int S, int NW> int launch_plane(const pv_dwconv3d_desc& d, hipStream_t s) {
+  const int c_p = pv_round_up(d.C, 8);
+  dim3 grid(plane_tiles(d, NW), (c_p + 31) / 32, d.B), block(kPlaneThreads);
+  if (d.act == PV_ACT_NONE) hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_NONE>), grid, block, 0, s, d);
+  else if (d.act == PV_ACT_RELU) hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_RELU>), grid, block, 0, s, d);
+  else hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_SWISH>), grid, block, 0, s, d);
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
 struct DwGeom {
   int nw, gpb, wgroups, units_per_batch, nblk;
   size_t lds;
@@ -246,6 +488,8 @@ int validate(const pv_dwconv3d_desc& d) {
 
 extern "C" int pv_dwconv3d_psum_blocks(const pv_dwconv3d_desc* d) {
   if (!d) return PV_ERR_INVALID;
+  if (d->B <= 0 || d->C <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return PV_ERR_INVALID;
+  if (const int nw = plane_variant(*d)) return plane_tiles(*d, nw);  // pointers are not needed for the count
   DwGeom g;
   if (!geom(*d, &g)) return PV_ERR_UNSUPPORTED;
   return g.nblk;
@@ -256,9 +500,13 @@ extern "C" int pv_dwconv3d(const pv_dwconv3d_desc* dp, pv_stream_t stream) {
   const pv_dwconv3d_desc& d = *dp;
   const int v = validate(d);
   if (v != PV_OK) return v;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (const int nw = plane_variant(d)) {
+    if (d.sw == 1) return nw == 4 ? launch_plane<1, 4>(d, s) : launch_plane<1, 2>(d, s);
+    return nw == 4 ? launch_plane<2, 4>(d, s) : launch_plane<2, 2>(d, s);
+  }
   DwGeom g;
   if (!geom(d, &g)) return PV_ERR_UNSUPPORTED;
-  hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.dtype == PV_BF16) return launch_dw<bf16_t>(d, g, s);
   if (d.dtype == PV_F32) return launch_dw<float>(d, g, s);
   return PV_ERR_UNSUPPORTED;
