@@ -16,7 +16,9 @@
 // (squeeze-excitation * Swish of X3D folded into conv_c's load).
 #include "pv_common.h"
 
-int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s);  // pv_pwconv.hip
+#include <stdlib.h>
+int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s);      // pv_pwconv.hip
+int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);  // pv_gemm.hip
 
 namespace {
 
@@ -339,9 +341,28 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
   const bool pw = taps == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0;
   if ((d.a_gate || d.a_act != PV_ACT_NONE) && !pw) return PV_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (pw && d.dtype == PV_BF16) {
-    const int r = pv_pwconv_stream_try(d, s);  // HBM-bound widths: streaming kernel (pv_pwconv.hip)
-    if (r != PV_ERR_UNSUPPORTED) return r;
+  if (d.dtype == PV_BF16) {
+    // PV_CONV_ROUTE (experiments): 1 = prefer the streaming kernel, 2 = prefer the LDS-DMA GEMM, 3 = generic only
+    static const int route = getenv("PV_CONV_ROUTE") ? atoi(getenv("PV_CONV_ROUTE")) : 0;
+    const int cout_p8 = pv_round_up(d.cout, 8);
+    // HBM-bound widths (X3D): streaming kernel; everything else: LDS-DMA MFMA GEMM
+    const bool small = d.cin <= 64 || cout_p8 <= 64 || ((long)d.cin * cout_p8 <= 128 * 224);
+    if (route != 3) {
+      if (pw && (route == 1 || (route == 0 && small))) {
+        const int r = pv_pwconv_stream_try(d, s);
+        if (r != PV_ERR_UNSUPPORTED) return r;
+      }
+      // the 128-channel LDS-DMA tile wastes the matrix core on narrow outputs, and per-chunk tap
+      // decoding dominates when a tap is only 8 channels wide (RGB stems): those stay on the
+      // generic register-staged kernel
+      const bool gemm_ok = route == 2 || (cout_p8 > 64 && (pw || d.cin >= 32));
+      int r = gemm_ok ? pv_gemm_glds_try(d, pw, s) : PV_ERR_UNSUPPORTED;
+      if (r != PV_ERR_UNSUPPORTED) return r;
+      if (pw) {
+        r = pv_pwconv_stream_try(d, s);
+        if (r != PV_ERR_UNSUPPORTED) return r;
+      }
+    }
   }
   if (d.dtype == PV_BF16) return launch_conv<bf16_t>(d, pw, s);
   if (d.dtype == PV_F32) return launch_conv<float>(d, pw, s);

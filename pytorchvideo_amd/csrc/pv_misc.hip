@@ -294,6 +294,53 @@ __global__ __launch_bounds__(kThreads) void layernorm_kernel(const pv_rows_desc 
   }
 }
 
+// Narrow rows (C <= 256, e.g. MViT's 96/192-wide stream and per-head norms): G = 16 or 32 lanes per
+// row, 4 or 2 rows per wave, so a 96-channel row keeps 12 of 16 lanes busy instead of 12 of 64.
+template <typename TI, typename T, int G>
+__global__ __launch_bounds__(kThreads) void layernorm16_kernel(const pv_rows_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / G, l16 = lane % G;
+  const long row = ((long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * (64 / G) + sub;
+  const bool row_ok = row < d.rows;
+  const int CG = pv_round_up(d.C, 8) / 8;
+  const bool act = row_ok && l16 < CG;
+  float f[8];
+  if (act) {
+    Chunk8<TI> c;
+    c.load(static_cast<const TI*>(d.x) + row * d.ldx + l16 * 8);
+    c.to_f32(f);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += f[j];
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)d.C;
+  float v = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float dlt = (l16 * 8 + j < d.C) ? f[j] - mean : 0.f;
+    v += dlt * dlt;
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const float rstd = rsqrtf(v / (float)d.C + d.eps);
+  if (act) {
+    float o8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = l16 * 8 + j;
+      o8[j] = (c < d.C) ? (f[j] - mean) * rstd * (d.gamma ? d.gamma[c] : 1.f) + (d.beta ? d.beta[c] : 0.f) : 0.f;
+    }
+    Chunk8<T> oc;
+    oc.from_f32(o8);
+    oc.store(static_cast<T*>(d.y) + row * d.ldy + l16 * 8);
+  }
+}
+
 // softmax over channels of each row (head activation); one wave per row, generic C
 template <typename T>
 __global__ __launch_bounds__(kThreads) void softmax_rows_kernel(const pv_rows_desc d) {
@@ -509,8 +556,25 @@ extern "C" int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream) {
   if (v != PV_OK) return v;
   if (d->ldx % 8 || d->ldy % 8) return PV_ERR_INVALID;
   const int CG = pv_round_up(d->C, 8) / 8;
-  dim3 grid((unsigned)pv_ceil_div(d->rows, kThreads / 64)), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
+#define PV_LN16(G)                                                                                              \
+  do {                                                                                                          \
+    dim3 grid16((unsigned)pv_ceil_div(d->rows, (kThreads / 64) * (64 / G))), block16(kThreads);                 \
+    if (d->dtype == PV_BF16 && d->x_f32)                                                                        \
+      hipLaunchKernelGGL((layernorm16_kernel<float, bf16_t, G>), grid16, block16, 0, s, *d);                    \
+    else if (d->dtype == PV_BF16)                                                                               \
+      hipLaunchKernelGGL((layernorm16_kernel<bf16_t, bf16_t, G>), grid16, block16, 0, s, *d);                   \
+    else if (d->dtype == PV_F32)                                                                                \
+      hipLaunchKernelGGL((layernorm16_kernel<float, float, G>), grid16, block16, 0, s, *d);                     \
+    else                                                                                                        \
+      return PV_ERR_UNSUPPORTED;                                                                                \
+    PV_LAUNCH_CHECK();                                                                                          \
+    return PV_OK;                                                                                               \
+  } while (0)
+  if (CG <= 16) PV_LN16(16);
+  if (CG <= 32) PV_LN16(32);
+#undef PV_LN16
+  dim3 grid((unsigned)pv_ceil_div(d->rows, kThreads / 64)), block(kThreads);
 #define PV_LN(TI, T, MAXC) hipLaunchKernelGGL((layernorm_kernel<TI, T, MAXC>), grid, block, 0, s, *d)
   if (d->dtype == PV_BF16 && d->x_f32) {
     if (CG <= 64) PV_LN(float, bf16_t, 1); else if (CG <= 128) PV_LN(float, bf16_t, 2);

@@ -1,0 +1,75 @@
+"""Micro-benchmark of pv_conv3d as a plain GEMM / implicit-GEMM conv on the MI355X (dev tool).
+    python tools/bench_gemm.py            # MViT-B / SlowFast / X3D shapes
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pytorchvideo_amd import _lib as L
+
+SHAPES = [  # (label, B, T,H,W in, cin, cout, k(t,h,w), s(t,h,w), p)
+    ("mvit qkv b0   M401k K96  N288", 8, 1, 1, 50177, 96, 288, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("mvit fc1 b0   M401k K96  N384", 8, 1, 1, 50177, 96, 384, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("mvit fc2 b0   M401k K384 N192", 8, 1, 1, 50177, 384, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("mvit qkv b1   M401k K192 N576", 8, 1, 1, 50177, 192, 576, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("mvit fc1 b2   M100k K192 N768", 8, 1, 1, 12545, 192, 768, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("mvit qkv b4   M25k  K384 N1152", 8, 1, 1, 3137, 384, 1152, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("mvit fc1 b4   M25k  K384 N1536", 8, 1, 1, 3137, 384, 1536, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("mvit fc2 b4   M25k  K1536 N384", 8, 1, 1, 3137, 1536, 384, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("mvit fc1 b15  M6k   K768 N3072", 8, 1, 1, 785, 768, 3072, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("mvit fc2 b15  M6k   K3072 N768", 8, 1, 1, 785, 3072, 768, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("ksweep M25k K64   N1152", 8, 1, 1, 3137, 64, 1152, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("ksweep M25k K768  N1152", 8, 1, 1, 3137, 768, 1152, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("ksweep M25k K1536 N1152", 8, 1, 1, 3137, 1536, 1152, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("ksweep M25k K3072 N1152", 8, 1, 1, 3137, 3072, 1152, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("ksweep M100k K384 N1152", 8, 1, 1, 12545, 384, 1152, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("big gemm      M32k  K4096 N4096", 1, 1, 1, 32768, 4096, 4096, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("sf conv_a res4 slow 3x1x1 1024->256", 16, 8, 16, 16, 1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("sf conv_b res4 slow 1x3x3 256->256", 16, 8, 16, 16, 256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("sf conv_b res2 slow 1x3x3 64->64", 16, 8, 64, 64, 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("sf conv_c res2 slow 64->256", 16, 8, 64, 64, 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("sf stem slow 1x7x7 3->64", 16, 8, 256, 256, 8, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
+    ("sf stem fast 5x7x7 3->8", 16, 32, 256, 256, 8, 8, (5, 7, 7), (1, 2, 2), (2, 3, 3)),
+    ("x3d stem 1x3x3 3->24", 32, 16, 224, 224, 8, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("x3d conv_a s5 192->432", 32, 16, 7, 7, 192, 432, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("x3d conv_c s4 216->96", 32, 16, 14, 14, 216, 96, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+]
+
+
+def run(label, B, T, H, W, cin, cout, k, s, p, iters=20):
+    To, Ho, Wo = [(i + 2 * pp - kk) // ss + 1 for i, pp, kk, ss in zip((T, H, W), p, k, s)]
+    taps = k[0] * k[1] * k[2]
+    x = torch.randn(B, T, H, W, cin, device="cuda").bfloat16()
+    w = (torch.randn(cout, taps * cin, device="cuda") * 0.05).bfloat16()
+    cp = (cout + 7) // 8 * 8
+    y = torch.empty(B, To, Ho, Wo, cp, device="cuda", dtype=torch.bfloat16)
+    d = L.Conv3dDesc()
+    d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * cin, To * Ho * Wo * cp, cin, cp
+    d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, cin, To, Ho, Wo, cout
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *s, *p)
+    d.act, d.a_act, d.dtype = L.ACT_RELU, L.ACT_NONE, L.PV_BF16
+    lib = L.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        L.check(lib.pv_conv3d(C.byref(d), st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.pv_conv3d(C.byref(d), st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * B * To * Ho * Wo * cout * taps * cin
+    byts = 2.0 * (x.numel() + w.numel() + y.numel())
+    print("%-40s %8.3f ms %8.1f TF/s %8.1f GB/s" % (label, ms, flops / ms / 1e9, byts / ms / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    sel = sys.argv[1:] 
+    print("route", os.environ.get("PV_CONV_ROUTE", "0"))
+    for sh in SHAPES:
+        if not sel or any(t in sh[0] for t in sel):
+            run(*sh)
