@@ -68,6 +68,9 @@ int pv_device_count(void);        /* hipGetDeviceCount; 0 when no GPU is visible
  * x' = a_act(x * a_gate[b][k]) when a_gate/a_act are given (squeeze-excitation scale and
  * Swish of models/x3d.py:190-207 folded into the consumer conv_c).
  * Weights are packed [cout][kt*kh*kw][cin] (cin = padded channel count, tap-major K).
+ * First-layer special case (RGB input): cin == 4 && ldx == 4 && dtype == PV_BF16 -- the input carries
+ * 4 channels per voxel (8 bytes) and the weights are packed [cout][kt][kh][round_up(kw,2)][4] with
+ * zeros in the padding (models/stem.py:80-107,295-338, models/x3d.py:66-88).
  */
 typedef struct pv_conv3d_desc {
   const void* x;         /* input activations                                   */
@@ -158,7 +161,8 @@ int pv_pool3d(const pv_pool3d_desc* d, pv_stream_t stream);
 typedef struct pv_layout_desc {
   const void* src; void* dst;
   int32_t B, C, T, H, W;    /* logical NCDHW extent of the NCDHW side           */
-  int32_t c_p, ld;          /* NDHWC side: padded channels written, voxel stride */
+  int32_t c_p, ld;          /* NDHWC side: padded channels written (multiple of 8, or 4 with ld == 4:
+                               the 4-channel first-layer layout), voxel stride */
   int64_t bs;               /* NDHWC side batch stride                           */
   int32_t src_dtype, dst_dtype;
 } pv_layout_desc;

@@ -54,7 +54,7 @@ class Mi355xBlock(EfficientBlockBase):
             self.__dict__["_owns_session"] = True
         if input_ref is None:
             B, Cc, T, H, W = [int(v) for v in input_blob_size]
-            input_ref = sess.alloc_act(B, T, H, W, Cc)
+            input_ref = sess.alloc_input(B, T, H, W, Cc)
         first = len(sess.ops)
         out_ref = self._emit(sess, input_ref)
         self.__dict__.update(_sess=sess, _in_ref=input_ref, _out_ref=out_ref, _op_range=(first, len(sess.ops)))
@@ -92,7 +92,7 @@ class Mi355xMultiPathBlock(Mi355xBlock):
             self.__dict__["_owns_session"] = True
         if input_ref is None:
             # input_blob_size: list of (B,C,T,H,W), one per pathway
-            input_ref = [sess.alloc_act(int(s[0]), int(s[2]), int(s[3]), int(s[4]), int(s[1])) for s in input_blob_size]
+            input_ref = [sess.alloc_input(int(s[0]), int(s[2]), int(s[3]), int(s[4]), int(s[1])) for s in input_blob_size]
         first = len(sess.ops)
         pre = None
         if self._orig_cls.__name__ == "PoolConcatPathway":

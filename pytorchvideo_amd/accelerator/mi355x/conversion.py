@@ -178,7 +178,7 @@ def _try_fuse_mvit(model, sess, dtype, input_tensor):
     from ... import _lib as L
 
     B, Cc, T, H, W = [int(v) for v in input_tensor.shape]
-    first_in = sess.alloc_act(B, T, H, W, Cc)
+    first_in = sess.alloc_input(B, T, H, W, Cc)
     n_ops = len(sess.ops)
     try:
         if not isinstance(model.pos_drop, (nn.Identity, nn.Dropout)):

@@ -121,15 +121,25 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
     if min(To, Ho, Wo) <= 0:
         raise RuntimeError("conv output would be empty")
     cout, cin_p = conv.out_channels, pad8(x.C)
-    if x.ld < cin_p:
+    c4 = x.ld == 4   # 4-channel first-layer layout -> stem kernel (csrc/pv_stem.hip)
+    if c4:
+        if x.C > 4 or residual is not None or a_gate is not None or a_act != L.ACT_NONE or sess.itemsize != 2:
+            raise Unsupported("4-channel input layout is only consumed by a plain first-layer conv")
+        cin_p = 4
+    elif x.ld < cin_p:
         raise Unsupported("input row narrower than padded channels")
     y = out if out is not None else sess.alloc_act(x.B, To, Ho, Wo, cout, f32=y_f32)
     if (y.B, y.T, y.H, y.W) != (x.B, To, Ho, Wo) or y.C != cout:
         raise RuntimeError("conv output buffer geometry mismatch")
     # pack [cout][taps][cin_p]
     w = conv.weight.detach().float().cpu()  # [cout, cin, kt, kh, kw]
-    wp = torch.zeros(cout, kt * kh * kw, cin_p, dtype=torch.float32)
-    wp[:, :, : x.C] = w.permute(0, 2, 3, 4, 1).reshape(cout, kt * kh * kw, x.C)
+    if c4:   # [cout][kt][kh][round_up(kw,2)][4], zeros in the padding
+        wp = torch.zeros(cout, kt, kh, (kw + 1) // 2 * 2, 4, dtype=torch.float32)
+        wp[:, :, :, :kw, : x.C] = w.permute(0, 2, 3, 4, 1)
+        wp = wp.reshape(cout, -1)
+    else:
+        wp = torch.zeros(cout, kt * kh * kw, cin_p, dtype=torch.float32)
+        wp[:, :, : x.C] = w.permute(0, 2, 3, 4, 1).reshape(cout, kt * kh * kw, x.C)
     wp = wp.to(sess.dtype)
     scale, shift = fold_norm(norm, cout, conv.bias)
     has_affine = norm is not None and not isinstance(norm, nn.Identity)

@@ -144,10 +144,17 @@ class Session:
         self._desc_keep = []
 
     # ------------------------------------------------------------------ memory
-    def alloc_act(self, B, T, H, W, C, f32=False):
+    def alloc_input(self, B, T, H, W, C):
+        """Model-input activation.  In bf16 sessions an RGB-like input (C <= 4) uses the
+        4-channel first-layer layout (8 bytes per voxel) consumed by the stem kernel."""
+        if C <= 4 and self.itemsize == 2:
+            return self.alloc_act(B, T, H, W, C, ld=4)
+        return self.alloc_act(B, T, H, W, C)
+
+    def alloc_act(self, B, T, H, W, C, f32=False, ld=None):
         """New activation [B,T,H,W,pad8(C)]; token tensors are (B,1,1,N,C)."""
         isz = 4 if f32 else self.itemsize
-        ld = pad8(C)
+        ld = pad8(C) if ld is None else ld
         bs = T * H * W * ld
         nbytes = B * bs * isz
         off = self._arena.alloc(nbytes)
@@ -273,7 +280,7 @@ class Session:
         d = L.LayoutDesc()
         d.src, d.dst = x.data_ptr(), self.arena_t.data_ptr() + ref.off
         d.B, d.C, d.T, d.H, d.W = B, Cc, T, H, W
-        d.c_p, d.ld, d.bs = pad8(ref.C), ref.ld, ref.bs
+        d.c_p, d.ld, d.bs = (4 if ref.ld == 4 else pad8(ref.C)), ref.ld, ref.bs
         d.src_dtype = L.PV_BF16 if x.dtype == torch.bfloat16 else L.PV_F32
         d.dst_dtype = self.pv_dtype
         L.check(lib.pv_ingest_ncdhw(C.byref(d), self._stream()), "ingest")

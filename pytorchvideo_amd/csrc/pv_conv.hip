@@ -19,6 +19,7 @@
 #include <stdlib.h>
 int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s);      // pv_pwconv.hip
 int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);  // pv_gemm.hip
+int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s);                 // pv_stem.hip
 
 namespace {
 
@@ -329,7 +330,9 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
   const pv_conv3d_desc& d = *dp;
   if (!d.x || !d.w || !d.y) return PV_ERR_INVALID;
   if (d.B <= 0 || d.cin <= 0 || d.cout <= 0 || d.To <= 0 || d.Ho <= 0 || d.Wo <= 0) return PV_ERR_INVALID;
-  if (d.cin % 8 || d.ldx % 8 || d.ldy % 8 || d.x_bs % 8 || d.y_bs % 8) return PV_ERR_INVALID;
+  const bool c4 = d.cin == 4 && d.ldx == 4 && d.dtype == PV_BF16;   // 4-channel-padded first layer (pv_stem.hip)
+  if (!c4 && (d.cin % 8 || d.ldx % 8 || d.x_bs % 8)) return PV_ERR_INVALID;
+  if (d.ldy % 8 || d.y_bs % 8 || (c4 && d.x_bs % 4)) return PV_ERR_INVALID;
   if (d.residual && (d.ldr % 8 || d.r_bs % 8)) return PV_ERR_INVALID;
   if (d.kt < 1 || d.kh < 1 || d.kw < 1 || d.st < 1 || d.sh < 1 || d.sw < 1) return PV_ERR_INVALID;
   const int taps = d.kt * d.kh * d.kw;
@@ -341,6 +344,7 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
   const bool pw = taps == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0;
   if ((d.a_gate || d.a_act != PV_ACT_NONE) && !pw) return PV_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (c4) return pv_stem_c4(d, s);
   if (d.dtype == PV_BF16) {
     // PV_CONV_ROUTE (experiments): 1 = prefer the streaming kernel, 2 = prefer the LDS-DMA GEMM, 3 = generic only
     static const int route = getenv("PV_CONV_ROUTE") ? atoi(getenv("PV_CONV_ROUTE")) : 0;

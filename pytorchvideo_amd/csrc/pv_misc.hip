@@ -217,6 +217,21 @@ __global__ __launch_bounds__(kThreads) void ingest_kernel(const pv_layout_desc d
   o.store(static_cast<T*>(d.dst) + (long)b * d.bs + sp * d.ld + cg * 8);
 }
 
+// NCDHW -> NDHWC with 4 channels per voxel (first-layer layout of pv_stem.hip): thread = voxel
+template <typename S>
+__global__ __launch_bounds__(kThreads) void ingest_c4_kernel(const pv_layout_desc d, long nvox) {
+  const long vox = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (vox >= nvox) return;
+  const long S3 = (long)d.T * d.H * d.W;
+  const long b = vox / S3;
+  const long sp = vox - b * S3;
+  const S* src = static_cast<const S*>(d.src) + b * d.C * S3 + sp;
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(j < d.C ? ld_as_f32(src + (long)j * S3) : 0.f);
+  *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(d.dst) + b * d.bs + sp * 4) = o;
+}
+
 template <typename T, typename S>
 __global__ __launch_bounds__(kThreads) void egress_kernel(const pv_layout_desc d, long nvox) {
   const int CG = d.c_p / 8;
@@ -300,44 +315,62 @@ template <typename TI, typename T, int G>
 __global__ __launch_bounds__(kThreads) void layernorm16_kernel(const pv_rows_desc d) {
   const int lane = threadIdx.x & 63;
   const int sub = lane / G, l16 = lane % G;
-  const long row = ((long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * (64 / G) + sub;
-  const bool row_ok = row < d.rows;
   const int CG = pv_round_up(d.C, 8) / 8;
-  const bool act = row_ok && l16 < CG;
-  float f[8];
-  if (act) {
-    Chunk8<TI> c;
-    c.load(static_cast<const TI*>(d.x) + row * d.ldx + l16 * 8);
-    c.to_f32(f);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = 0.f;
-  }
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) s += f[j];
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  const float mean = s / (float)d.C;
-  float v = 0.f;
+  constexpr int RPW = 64 / G;                       // rows per wave per iteration
+  const long wave_id = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  const long wave_stride = (long)gridDim.x * (kThreads / 64);
+  // this lane's slice of gamma / beta is the same for every row: load it once
+  float gm[8], bt[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float dlt = (l16 * 8 + j < d.C) ? f[j] - mean : 0.f;
-    v += dlt * dlt;
+    const int c = l16 * 8 + j;
+    gm[j] = (c < d.C && d.gamma) ? d.gamma[c] : 1.f;
+    bt[j] = (c < d.C && d.beta) ? d.beta[c] : 0.f;
   }
+  // grid-stride over row groups, two groups in flight per wave
+  for (long g0 = wave_id; g0 * RPW < d.rows; g0 += 2 * wave_stride) {
+    float f[2][8];
+    long row[2];
+    bool act[2];
 #pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  const float rstd = rsqrtf(v / (float)d.C + d.eps);
-  if (act) {
-    float o8[8];
+    for (int u = 0; u < 2; ++u) {
+      row[u] = (g0 + u * wave_stride) * RPW + sub;
+      act[u] = row[u] < d.rows && l16 < CG;
+      if (act[u]) {
+        Chunk8<TI> c;
+        c.load(static_cast<const TI*>(d.x) + row[u] * d.ldx + l16 * 8);
+        c.to_f32(f[u]);
+      } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = l16 * 8 + j;
-      o8[j] = (c < d.C) ? (f[j] - mean) * rstd * (d.gamma ? d.gamma[c] : 1.f) + (d.beta ? d.beta[c] : 0.f) : 0.f;
+        for (int j = 0; j < 8; ++j) f[u][j] = 0.f;
+      }
     }
-    Chunk8<T> oc;
-    oc.from_f32(o8);
-    oc.store(static_cast<T*>(d.y) + row * d.ldy + l16 * 8);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += f[u][j];
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mean = s / (float)d.C;
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dlt = (l16 * 8 + j < d.C) ? f[u][j] - mean : 0.f;
+        v += dlt * dlt;
+      }
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      const float rstd = rsqrtf(v / (float)d.C + d.eps);
+      if (act[u]) {
+        float o8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = (l16 * 8 + j < d.C) ? (f[u][j] - mean) * rstd * gm[j] + bt[j] : 0.f;
+        Chunk8<T> oc;
+        oc.from_f32(o8);
+        oc.store(static_cast<T*>(d.y) + row[u] * d.ldy + l16 * 8);
+      }
+    }
   }
 }
 
@@ -504,6 +537,17 @@ static int layout_check(const pv_layout_desc* d) {
 }
 
 extern "C" int pv_ingest_ncdhw(const pv_layout_desc* d, pv_stream_t stream) {
+  if (d && d->src && d->dst && d->c_p == 4 && d->ld == 4 && d->C >= 1 && d->C <= 4 && d->dst_dtype == PV_BF16 &&
+      d->B > 0 && d->T > 0 && d->H > 0 && d->W > 0 && d->bs % 4 == 0) {
+    const long nvox = (long)d->B * d->T * d->H * d->W;
+    dim3 grid(blocks_for(nvox)), block(kThreads);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d->src_dtype == PV_F32) hipLaunchKernelGGL(ingest_c4_kernel<float>, grid, block, 0, s, *d, nvox);
+    else if (d->src_dtype == PV_BF16) hipLaunchKernelGGL(ingest_c4_kernel<bf16_t>, grid, block, 0, s, *d, nvox);
+    else return PV_ERR_UNSUPPORTED;
+    PV_LAUNCH_CHECK();
+    return PV_OK;
+  }
   const int v = layout_check(d);
   if (v != PV_OK) return v;
   const long nvox = (long)d->B * d->T * d->H * d->W;
@@ -559,7 +603,8 @@ extern "C" int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define PV_LN16(G)                                                                                              \
   do {                                                                                                          \
-    dim3 grid16((unsigned)pv_ceil_div(d->rows, (kThreads / 64) * (64 / G))), block16(kThreads);                 \
+    const long nb16 = pv_ceil_div(d->rows, (kThreads / 64) * (64 / G) * 2);                                    \
+    dim3 grid16((unsigned)(nb16 < 4096 ? nb16 : 4096)), block16(kThreads);                                    \
     if (d->dtype == PV_BF16 && d->x_f32)                                                                        \
       hipLaunchKernelGGL((layernorm16_kernel<float, bf16_t, G>), grid16, block16, 0, s, *d);                    \
     else if (d->dtype == PV_BF16)                                                                               \

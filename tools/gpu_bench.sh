@@ -3,6 +3,6 @@
 TAG=$1; shift
 mkdir -p gpurun_out
 for WL in "$@"; do
-  PV_BENCH_VERBOSE=1 python bench.py --workload $WL --steps 10 --warmup 3 > gpurun_out/${TAG}_bench_${WL}.json 2> gpurun_out/${TAG}_bench_${WL}.err
-  cat gpurun_out/${TAG}_bench_${WL}.json; grep -v amdgpu.ids gpurun_out/${TAG}_bench_${WL}.err | tail -32
+  PV_BENCH_VERBOSE=2 python bench.py --workload $WL --steps 10 --warmup 3 > gpurun_out/${TAG}_bench_${WL}.json 2> gpurun_out/${TAG}_bench_${WL}.err
+  cat gpurun_out/${TAG}_bench_${WL}.json; grep -v amdgpu.ids gpurun_out/${TAG}_bench_${WL}.err | grep -v "^  op" | tail -32
 done
