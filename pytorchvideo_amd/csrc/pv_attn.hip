@@ -52,7 +52,7 @@ template <int D> struct AttnCfg<float, D> {
 };
 
 template <typename T, int D>
-__global__ __launch_bounds__(kThreads) void attn_kernel(const pv_attention_desc d, int nqb, int total) {
+__global__ __launch_bounds__(kThreads, 2) void attn_kernel(const pv_attention_desc d, int nqb, int total) {
   using Cfg = AttnCfg<T, D>;
   constexpr bool kBf16 = sizeof(T) == 2;
   constexpr int KT = Cfg::KT, NBUF = Cfg::NBUF, KLD = Cfg::KLD, VLD = Cfg::VLD;
@@ -199,19 +199,32 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(const pv_attention_desc 
     const T* ks_ = smem + buf * (Cfg::K_ELEMS + Cfg::V_ELEMS);
     const T* vs_ = ks_ + Cfg::K_ELEMS;
 
-    // ---- S^T = K Q^T ----
+    // ---- S^T = K Q^T ----  (K fragments are read two k-steps ahead of the MFMAs that use them)
     f32x16 s[NSUB];
 #pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub) {
+    for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
-      if constexpr (kBf16) {
+    if constexpr (kBf16) {
+      constexpr int NKS = D / 16;
+      bf16x8 kf[3][NSUB];
+      auto read_k = [&](int slot, int ks) {
 #pragma unroll
-        for (int ks = 0; ks < D / 16; ++ks) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(ks_ + (sub * 32 + l31) * KLD + ks * 16 + hi * 8);
-          s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[sub], 0, 0, 0);
-        }
-      } else {
+        for (int sub = 0; sub < NSUB; ++sub)
+          kf[slot][sub] = *reinterpret_cast<const bf16x8*>(ks_ + (sub * 32 + l31) * KLD + ks * 16 + hi * 8);
+      };
+      read_k(0, 0);
+      if (NKS > 1) read_k(1, 1);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + 2 < NKS) read_k((ks + 2) % 3, ks + 2);
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+          s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks % 3][sub], qf[ks], s[sub], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
         for (int ss = 0; ss < D / 2; ++ss) {
           const float a = (float)ks_[(sub * 32 + l31) * KLD + 2 * ss + hi];
@@ -221,54 +234,72 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(const pv_attention_desc 
     }
 
     // ---- online softmax (lane-private: this lane's query, 16*NSUB of the tile's keys) ----
-    const bool tail = (t + 1) * KT > d.Nk;
+    // exp2 domain; raw v_exp_f32 (arguments are <= kDefer, results never need denormal scaling).
+    // Deferred rescale: the running max is only advanced (and O, l rescaled) when some lane's tile
+    // max exceeds it by more than kDefer -- otherwise P = exp2(x - m_stale) <= 2^kDefer is still
+    // exact to bf16 precision and the O accumulators never leave the matrix-core register file.
+    constexpr float kDefer = 8.0f;
+    if ((t + 1) * KT > d.Nk) {   // last tile: mask the keys past Nk (wave-uniform branch)
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if ((t * KT + sub * 32 + crow(r, hi)) >= d.Nk) s[sub][r] = -INFINITY;
+    }
     float mx = -1e30f;
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float x = s[sub][r] * sc;
-        if (tail && (t * KT + sub * 32 + crow(r, hi)) >= d.Nk) x = -INFINITY;
-        s[sub][r] = x;
-        mx = fmaxf(mx, x);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
+    mx *= sc;   // sc > 0: max commutes with the scaling
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
+    if (__any(mx > m_run + kDefer)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
     float psum = 0.f;
+    const float neg_m = -m_run;
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(s[sub][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[sub][r], sc, neg_m));
         s[sub][r] = p;
         psum += p;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < NDB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    l_run += psum;
 
-    // ---- O^T += V^T P^T ----
+    // ---- O^T += V^T P^T ----  (P -> bf16 first, which frees the score registers; V^T fragments are
+    //      read two MFMAs ahead)
     if constexpr (kBf16) {
+      bf16x8 pb[NSUB * 2];
 #pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub)
+      for (int i = 0; i < NSUB * 2; ++i)
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          bf16x8 pb;
+        for (int j = 0; j < 8; ++j) pb[i][j] = (bf16_t)s[i >> 1][(i & 1) * 8 + j];
+      constexpr int NF = NSUB * 2 * NDB;   // fragment sequence: i = (sub*2 + k2) * NDB + db
+      bf16x8 vf[3];
+      auto read_v = [&](int slot, int i) {
+        const int sk = i / NDB, db = i - sk * NDB;
+        const T* vp = vs_ + (db * 32 + l31) * VLD + sk * 16 + hi * 4;
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vp);
+        const bf16x4 up = *reinterpret_cast<const bf16x4*>(vp + 8);
+        vf[slot] = bf16x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+      };
+      read_v(0, 0);
+      read_v(1, 1);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pb[j] = (bf16_t)s[sub][k2 * 8 + j];
-#pragma unroll
-          for (int db = 0; db < NDB; ++db) {
-            const T* vp = vs_ + (db * 32 + l31) * VLD + sub * 32 + k2 * 16 + hi * 4;
-            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vp);
-            const bf16x4 up = *reinterpret_cast<const bf16x4*>(vp + 8);
-            const bf16x8 a = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
-          }
-        }
+      for (int i = 0; i < NF; ++i) {
+        if (i + 2 < NF) read_v((i + 2) % 3, i + 2);
+        const int sk = i / NDB, db = i - sk * NDB;
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pb[sk], o[db], 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int sub = 0; sub < NSUB; ++sub)
