@@ -177,6 +177,15 @@ def main():
     dom_tfs = dom[3] / (dom[1] * 1e-3) / 1e12 if dom[1] > 0 else 0.0
     mfma_bound = dom[2] > 0 and dom[3] / dom[2] > MFMA_PEAK_TFS * 1e12 / (HBM_PEAK_GBS * 1e9)
 
+    # HBM traffic of the dominant kernel family from the committed rocprofv3 PMC passes
+    # (tools/gpu_profile.sh + tools/summarize_pmc.py -> profiles/traffic.json), bytes per launch
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        traffic = tj.get(args.workload, {}).get(dom_label, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         clips_s = batch * world * args.steps / elapsed
@@ -192,7 +201,8 @@ def main():
                 "bound": "mfma" if mfma_bound else "hbm", "kernel": dom_label, "launches_per_step": dom[0],
                 "achieved": round(dom_tfs if mfma_bound else dom_gbs, 1),
                 "peak": MFMA_PEAK_TFS if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                "frac": round(dom_tfs / MFMA_PEAK_TFS if mfma_bound else dom_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(dom_tfs / MFMA_PEAK_TFS if mfma_bound else dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "alg_bytes_per_launch": int(dom[2] / max(dom[0], 1)), "avg_launch_ms": round(dom[1] / max(dom[0], 1), 5),
                 "kernel_ms_per_step": round(dom[1], 4), "all_kernels_ms_per_step": round(total_kernel_ms, 4),
                 "model_hbm_frac": round(clips_s / world * wl["mb"] * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
                 "model_mfma_frac": round(clips_s / world * wl["gflop"] * 1e9 / (MFMA_PEAK_TFS * 1e12), 4),

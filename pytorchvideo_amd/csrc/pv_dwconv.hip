@@ -198,7 +198,7 @@ constexpr int kPlaneThreads = 256;  // 4 waves = 4 output rows
 constexpr int kPR = kPlaneThreads / 64;
 
 template <int S, int NW, int ACT>
-__global__ __launch_bounds__(kPlaneThreads) void dw3_plane_kernel(const pv_dwconv3d_desc d) {
+__global__ __launch_bounds__(kPlaneThreads) void dw3_plane_kernel(const pv_dwconv3d_desc d, int ntiles, int ngroups) {
   constexpr int TW = 4 * NW;               // tile width (outputs)
   constexpr int IH = (kPR - 1) * S + 3;
   constexpr int IW = (TW - 1) * S + 3;
@@ -217,12 +217,20 @@ __global__ __launch_bounds__(kPlaneThreads) void dw3_plane_kernel(const pv_dwcon
   const int cp = lane & 15;                // channel pair inside the 32-channel slab
   const int sx = lane >> 4;                // column group
   const int c_p = pv_round_up(d.C, 8);
-  const int cbase = blockIdx.y * 32;
+  // 1-D grid decoded so that the channel groups of one tile (which share every 128-byte line of
+  // the input when C is not a multiple of 64 channels) are consecutive workgroups of the SAME XCD:
+  // the second group's reads hit in that XCD's L2 instead of going back to the fabric.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int grp = slot % ngroups;
+  const long tb = (long)(slot / ngroups) * 8 + xcd;     // (clip, tile) index
+  if (tb >= (long)ntiles * d.B) return;                 // grid is padded to a multiple of 8 tiles
+  const int tile_id = (int)(tb % ntiles);
+  const int cbase = grp * 32;
   const int ch = cbase + cp * 2;           // first of this lane's two channels
   const bool ch_ok = ch < c_p;
   const int tiles_w = (d.Wo + TW - 1) / TW;
-  const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
-  const int b = blockIdx.z;
+  const int th = tile_id / tiles_w, tw = tile_id - th * tiles_w;
+  const int b = (int)(tb / ntiles);
   const int ho0 = th * kPR, wo0 = tw * TW;
   const int ho = ho0 + row, wo_first = wo0 + sx * NW;
   const int hi0 = ho0 * S - 1, wi0 = wo0 * S - 1;
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(kPlaneThreads) void dw3_plane_kernel(const pv_dwcon
       float a = 0.f;
 #pragma unroll
       for (int rr = 0; rr < kPR; ++rr) a += s_ps[rr][tid];
-      d.psum[((long)b * gridDim.x + blockIdx.x) * c_p + cbase + tid] = a;
+      d.psum[((long)b * ntiles + tile_id) * c_p + cbase + tid] = a;
     }
   }
 }
@@ -409,10 +417,13 @@ int plane_tiles(const pv_dwconv3d_desc& d, int nw) { return ((d.Ho + kPR - 1) / 
 
 template <int S, int NW> int launch_plane(const pv_dwconv3d_desc& d, hipStream_t s) {
   const int c_p = pv_round_up(d.C, 8);
-  dim3 grid(plane_tiles(d, NW), (c_p + 31) / 32, d.B), block(kPlaneThreads);
-  if (d.act == PV_ACT_NONE) hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_NONE>), grid, block, 0, s, d);
-  else if (d.act == PV_ACT_RELU) hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_RELU>), grid, block, 0, s, d);
-  else hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_SWISH>), grid, block, 0, s, d);
+  const int ntiles = plane_tiles(d, NW), ngroups = (c_p + 31) / 32;
+  const long blocks = pv_ceil_div((long)ntiles * d.B, 8) * 8 * ngroups;
+  if (blocks > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)blocks), block(kPlaneThreads);
+  if (d.act == PV_ACT_NONE) hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_NONE>), grid, block, 0, s, d, ntiles, ngroups);
+  else if (d.act == PV_ACT_RELU) hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_RELU>), grid, block, 0, s, d, ntiles, ngroups);
+  else hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_SWISH>), grid, block, 0, s, d, ntiles, ngroups);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }
