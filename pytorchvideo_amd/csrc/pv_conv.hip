@@ -350,7 +350,9 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
     static const int route = getenv("PV_CONV_ROUTE") ? atoi(getenv("PV_CONV_ROUTE")) : 0;
     const int cout_p8 = pv_round_up(d.cout, 8);
     // HBM-bound widths (X3D): streaming kernel; everything else: LDS-DMA MFMA GEMM
-    const bool small = d.cin <= 64 || cout_p8 <= 64 || ((long)d.cin * cout_p8 <= 128 * 224);
+    // arithmetic intensity of the layer as its own op, K*N/(K+N) FLOP/B (bf16): well below the ridge
+    // (312) the layer is a streaming problem -> streaming kernel; near or above it -> MFMA GEMM
+    const bool small = d.cin <= 64 || cout_p8 <= 64 || ((long)d.cin * cout_p8 < 170L * (d.cin + cout_p8));
     if (route != 3) {
       if (pw && (route == 1 || (route == 0 && small))) {
         const int r = pv_pwconv_stream_try(d, s);

@@ -374,6 +374,77 @@ __global__ __launch_bounds__(kThreads) void layernorm16_kernel(const pv_rows_des
   }
 }
 
+// fp32 rows -> `T` rows (the fp32 residual stream of the bf16 MViT plan): a lane owns FOUR channels
+// (one 16-byte fp32 load, one 8-byte bf16 store), so every load instruction of a wave covers a dense
+// run of memory; NL loads per lane cover rows up to 64*4*NL channels; G lanes per row.
+template <typename T, int G, int NL>
+__global__ __launch_bounds__(kThreads) void layernorm_f32in_kernel(const pv_rows_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / G, lg = lane % G;
+  constexpr int RPW = 64 / G;
+  const long wave_id = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  const long wave_stride = (long)gridDim.x * (kThreads / 64);
+  const int C4 = pv_round_up(d.C, 8) / 4;   // 4-channel chunks per (padded) row
+  f32x4 gm[NL], bt[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int c0 = (lg + i * G) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gm[i][j] = (c0 + j < d.C && d.gamma) ? d.gamma[c0 + j] : 1.f;
+      bt[i][j] = (c0 + j < d.C && d.beta) ? d.beta[c0 + j] : 0.f;
+    }
+  }
+  for (long g0 = wave_id; g0 * RPW < d.rows; g0 += 2 * wave_stride) {
+    f32x4 f[2][NL];
+    long row[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      row[u] = (g0 + u * wave_stride) * RPW + sub;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int ch = lg + i * G;
+        if (row[u] < d.rows && ch < C4)
+          f[u][i] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(d.x) + row[u] * d.ldx + ch * 4);
+        else
+          f[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) s += (f[u][i][0] + f[u][i][1]) + (f[u][i][2] + f[u][i][3]);   // padding is zero
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mean = s / (float)d.C;
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float dlt = ((lg + i * G) * 4 + j < d.C) ? f[u][i][j] - mean : 0.f;
+          v += dlt * dlt;
+        }
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      const float rstd = rsqrtf(v / (float)d.C + d.eps);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int ch = lg + i * G;
+        if (row[u] < d.rows && ch < C4) {
+          float o4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o4[j] = (ch * 4 + j < d.C) ? (f[u][i][j] - mean) * rstd * gm[i][j] + bt[i][j] : 0.f;
+          T* yp = static_cast<T*>(d.y) + row[u] * d.ldy + ch * 4;
+          if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x4*>(yp) = bf16x4{(bf16_t)o4[0], (bf16_t)o4[1], (bf16_t)o4[2], (bf16_t)o4[3]};
+          else *reinterpret_cast<f32x4*>(yp) = f32x4{o4[0], o4[1], o4[2], o4[3]};
+        }
+      }
+    }
+  }
+}
+
 // softmax over channels of each row (head activation); one wave per row, generic C
 template <typename T>
 __global__ __launch_bounds__(kThreads) void softmax_rows_kernel(const pv_rows_desc d) {
@@ -616,6 +687,23 @@ extern "C" int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream) {
     PV_LAUNCH_CHECK();                                                                                          \
     return PV_OK;                                                                                               \
   } while (0)
+  if (d->dtype == PV_BF16 && d->x_f32 && CG <= 128) {   // fp32 stream -> bf16 operand: 4 channels per lane
+    const int C4 = CG * 2;
+#define PV_LNF(G, NL)                                                                                  \
+  do {                                                                                                 \
+    const long nb = pv_ceil_div(d->rows, (kThreads / 64) * (64 / G) * 2);                              \
+    hipLaunchKernelGGL((layernorm_f32in_kernel<bf16_t, G, NL>), dim3((unsigned)(nb < 4096 ? nb : 4096)), \
+                       dim3(kThreads), 0, s, *d);                                                      \
+    PV_LAUNCH_CHECK();                                                                                 \
+    return PV_OK;                                                                                      \
+  } while (0)
+    if (C4 <= 16) PV_LNF(16, 1);
+    if (C4 <= 32) PV_LNF(32, 1);
+    if (C4 <= 64) PV_LNF(64, 1);
+    if (C4 <= 128) PV_LNF(64, 2);
+    PV_LNF(64, 4);
+#undef PV_LNF
+  }
   if (CG <= 16) PV_LN16(16);
   if (CG <= 32) PV_LN16(32);
 #undef PV_LN16

@@ -30,8 +30,9 @@ struct PwRows {  // per-lane geometry of one wave tile group: clip index and vox
   int sp[4];
 };
 
-template <int NT, int TM, bool XFORM, int KS>
-__global__ __launch_bounds__(kThreads, 4) void pw_stream_kernel(const pv_conv3d_desc d, int ksteps_rt, int ngroups) {
+template <int NT, int TM, bool XFORM, int KS, bool F32>
+__global__ __launch_bounds__(kThreads, 4) void pw_stream_kernel(const pv_conv3d_desc d, int ksteps_rt, int ngroups,
+                                                                int nchunks, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ksteps = KS > 0 ? KS : ksteps_rt;
   const int Kp = ksteps * 32;
@@ -47,7 +48,11 @@ __global__ __launch_bounds__(kThreads, 4) void pw_stream_kernel(const pv_conv3d_
   const int n16 = lane & 15;
   const int q = lane >> 4;
   const int cout_p8 = pv_round_up(d.cout, 8);
-  const int n0 = blockIdx.y * (NT * 16);
+  // 1-D grid: the N-splits of one voxel chunk are consecutive workgroups of the same XCD, so the
+  // activation rows are fetched from HBM once and re-read from that XCD's L2 by the other splits
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int chunk = (slot / nsplit) * 8 + xcd;
+  const int n0 = (slot % nsplit) * (NT * 16);
   const long S_out = (long)d.To * d.Ho * d.Wo;
   const long M = (long)d.B * S_out;
 
@@ -106,17 +111,22 @@ __global__ __launch_bounds__(kThreads, 4) void pw_stream_kernel(const pv_conv3d_
     }
   };
   // residual chunks in the epilogue's shape: [pair][tile] -> 8 bf16 channels (raw 16 bytes)
-  auto load_res = [&](f32x4 (&dst)[NP][TM], const PwRows& r) {
+  auto load_res = [&](f32x4 (&dst)[NP][TM][F32 ? 2 : 1], const PwRows& r) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int c0 = n0 + p * 32 + q * 8;
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
-        if (has_res && r.sp[t] >= 0 && p < live_pairs && c0 < cout_p8)
-          dst[p][t] = *reinterpret_cast<const f32x4*>(static_cast<const bf16_t*>(d.residual) + (long)r.b[t] * d.r_bs +
-                                                      (long)r.sp[t] * d.ldr + c0);
-        else
-          dst[p][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool ok = has_res && r.sp[t] >= 0 && p < live_pairs && c0 < cout_p8;
+        const long ro = (long)r.b[t] * d.r_bs + (long)r.sp[t] * d.ldr + c0;
+        if constexpr (F32) {
+          const float* rp = static_cast<const float*>(d.residual) + ro;
+          dst[p][t][0] = ok ? *reinterpret_cast<const f32x4*>(rp) : f32x4{0.f, 0.f, 0.f, 0.f};
+          dst[p][t][1] = ok ? *reinterpret_cast<const f32x4*>(rp + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+          dst[p][t][0] = ok ? *reinterpret_cast<const f32x4*>(static_cast<const bf16_t*>(d.residual) + ro)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
   };
@@ -169,11 +179,11 @@ __global__ __launch_bounds__(kThreads, 4) void pw_stream_kernel(const pv_conv3d_
 
   PwRows cur, nxt;
   bf16x8 xf[KSR][TM];
-  f32x4 rcur[NP][TM];
-  int g = blockIdx.x;
+  f32x4 rcur[NP][TM][F32 ? 2 : 1];
+  int g = chunk < nchunks ? chunk : ngroups;   // padded blocks (grid is a multiple of 8 chunks) do nothing
   rows_of(g, cur);
   load_x(xf, cur, 0);
-  for (; g < ngroups; g += gridDim.x) {
+  for (; g < ngroups; g += nchunks) {
     load_res(rcur, cur);  // consumed by the epilogue: in flight during the transform and the MFMAs
     f32x4 acc[NT][TM];
 #pragma unroll
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(kThreads, 4) void pw_stream_kernel(const pv_conv3d_
 #pragma unroll
       for (int t = 0; t < TM; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     refresh_gate(g);
-    rows_of(g + gridDim.x, nxt);
+    rows_of(g + nchunks, nxt);
     if constexpr (KS > 0) {
       if (XFORM) xform(xf, cur, 0);
       mma(acc, xf, 0);
@@ -219,39 +229,60 @@ __global__ __launch_bounds__(kThreads, 4) void pw_stream_kernel(const pv_conv3d_
           v[4 + j] = acc[2 * p + 1][t][j] * s1[j] + h1[j];
         }
         if (has_res) {
-          const bf16x8 rb = __builtin_bit_cast(bf16x8, rcur[p][t]);
+          if constexpr (F32) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += (float)rb[j];
+            for (int j = 0; j < 4; ++j) { v[j] += rcur[p][t][0][j]; v[4 + j] += rcur[p][t][1][j]; }
+          } else {
+            const bf16x8 rb = __builtin_bit_cast(bf16x8, rcur[p][t][0]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)rb[j];
+          }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           v[j] = pv_apply_act(v[j], d.act);
           if (c0 + j >= d.cout) v[j] = 0.f;
         }
-        Chunk8<bf16_t> oc;
-        oc.from_f32(v);
-        oc.store(static_cast<bf16_t*>(d.y) + (long)cur.b[t] * d.y_bs + (long)cur.sp[t] * d.ldy + c0);
+        const long yo = (long)cur.b[t] * d.y_bs + (long)cur.sp[t] * d.ldy + c0;
+        if constexpr (F32) {
+          Chunk8<float> oc;
+          oc.from_f32(v);
+          oc.store(static_cast<float*>(d.y) + yo);
+        } else {
+          Chunk8<bf16_t> oc;
+          oc.from_f32(v);
+          oc.store(static_cast<bf16_t*>(d.y) + yo);
+        }
       }
     }
     cur = nxt;
   }
 }
 
-template <int NT, int TM, bool XFORM, int KS>
-int launch_pw_k(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) {
+template <int NT, int TM, bool XFORM, int KS, bool F32>
+int launch_pw_f(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) {
   const long M = (long)d.B * d.To * d.Ho * d.Wo;
   const long ngroups = pv_ceil_div(M, 4 * TM * 16);
   const int nsplit = (int)pv_ceil_div(pv_round_up(d.cout, 8), NT * 16);
   if (ngroups > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
-  auto kern = pw_stream_kernel<NT, TM, XFORM, KS>;
+  auto kern = pw_stream_kernel<NT, TM, XFORM, KS, F32>;
   if (lds > 64 * 1024)
     PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // enough resident blocks to fill the chip a few times over; the rest is the grid-stride loop
-  long gx = ngroups < 2048 ? ngroups : 2048;
-  if (nsplit > 1) gx = pv_ceil_div(gx, nsplit) > 256 ? pv_ceil_div(gx, nsplit) : (ngroups < 256 ? ngroups : 256);
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nsplit), dim3(kThreads), lds, s, d, ksteps, (int)ngroups);
+  long nchunks = ngroups < 2048 ? ngroups : 2048;
+  if (nsplit > 1) nchunks = pv_ceil_div(nchunks, nsplit) > 256 ? pv_ceil_div(nchunks, nsplit) : (ngroups < 256 ? ngroups : 256);
+  const long blocks = pv_ceil_div(nchunks, 8) * 8 * nsplit;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), lds, s, d, ksteps, (int)ngroups, (int)nchunks, nsplit);
   PV_LAUNCH_CHECK();
   return PV_OK;
+}
+
+template <int NT, int TM, bool XFORM, int KS>
+int launch_pw_k(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) {
+  if constexpr (!XFORM) {   // fp32 output / residual: the residual stream of the bf16 MViT plan
+    if (d.y_f32) return launch_pw_f<NT, TM, XFORM, KS, true>(d, ksteps, lds, s);
+  }
+  return launch_pw_f<NT, TM, XFORM, KS, false>(d, ksteps, lds, s);
 }
 
 template <int NT, int TM, bool XFORM>
@@ -279,7 +310,10 @@ int launch_pw(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) {
 // Returns PV_OK when the streaming kernel took the op, PV_ERR_UNSUPPORTED to let the caller
 // fall back to the generic implicit-GEMM kernel.
 int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s) {
-  if (d.dtype != PV_BF16 || d.y_f32 || d.r_f32) return PV_ERR_UNSUPPORTED;
+  if (d.dtype != PV_BF16) return PV_ERR_UNSUPPORTED;
+  // fp32 I/O only in the combination the MViT plan uses: fp32 output with an (optional) fp32 residual
+  if ((d.r_f32 != 0) != (d.residual != nullptr && d.y_f32) || (d.y_f32 && (d.a_gate || d.a_act != PV_ACT_NONE)))
+    return PV_ERR_UNSUPPORTED;
   const long S_out = (long)d.To * d.Ho * d.Wo;
   if (d.a_gate && S_out < 64) return PV_ERR_UNSUPPORTED;  // a 64-voxel wave tile must span <= 2 clips
   const int cout_p8 = pv_round_up(d.cout, 8);
