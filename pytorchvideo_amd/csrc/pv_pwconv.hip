@@ -268,9 +268,13 @@ int launch_pw_f(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) 
   auto kern = pw_stream_kernel<NT, TM, XFORM, KS, F32>;
   if (lds > 64 * 1024)
     PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  // enough resident blocks to fill the chip a few times over; the rest is the grid-stride loop
-  long nchunks = ngroups < 2048 ? ngroups : 2048;
-  if (nsplit > 1) nchunks = pv_ceil_div(nchunks, nsplit) > 256 ? pv_ceil_div(nchunks, nsplit) : (ngroups < 256 ? ngroups : 256);
+  // one resident generation of workgroups (what LDS and the 4-waves-per-SIMD register budget admit
+  // per CU); the rest is the grid-stride loop, so the weight slab is staged once per resident
+  // workgroup, not once per 64 voxels
+  const long per_cu = lds > 0 ? (160 * 1024) / (long)(lds + 1024) : 4;
+  const long resident = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+  long nchunks = pv_ceil_div(resident, nsplit);
+  if (nchunks > ngroups) nchunks = ngroups;
   const long blocks = pv_ceil_div(nchunks, 8) * 8 * nsplit;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), lds, s, d, ksteps, (int)ngroups, (int)nchunks, nsplit);
   PV_LAUNCH_CHECK();
