@@ -227,3 +227,90 @@ def test_pointwise_conv_with_se_gate_swish_and_residual(dtype, B, S, K, N, gate,
     call("pv_conv3d", d)
     assert rel_err(y[:, :, :N], want) <= TOL[dtype]
     assert torch.all(y[:, :, N:] == 0)   # padding channels are written as exact zeros
+
+
+# ------------------------------------------------------------------ first-layer conv on the 4-channel layout
+@pytest.mark.parametrize("B,T,H,W,cout,k,s,p,f32out", [
+    (2, 4, 32, 32, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3), False),    # SlowFast slow stem
+    (1, 8, 24, 40, 8, (5, 7, 7), (1, 2, 2), (2, 3, 3), False),     # SlowFast fast stem
+    (2, 4, 18, 22, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1), False),    # X3D stem conv (odd kw: padded pair)
+    (1, 6, 28, 28, 96, (3, 7, 7), (2, 4, 4), (1, 3, 3), True),     # MViT patch embedding (+bias, fp32 out)
+    (1, 3, 9, 11, 20, (3, 2, 4), (1, 1, 3), (1, 0, 2), False),     # odd everything
+])
+def test_first_layer_conv_on_c4_layout(B, T, H, W, cout, k, s, p, f32out):
+    x = _rand((B, 3, T, H, W), 61, torch.bfloat16)
+    w = _rand((cout, 3) + k, 62, torch.bfloat16, (3 * k[0] * k[1] * k[2]) ** -0.5)
+    bias = _rand((cout,), 63, torch.float32)
+    want = F.relu(F.conv3d(x.float(), w.float(), bias, stride=s, padding=p))
+    To, Ho, Wo = want.shape[2:]
+    # NCDHW -> NDHWC with 4 channels per voxel, through the library's own ingest
+    x4 = torch.full((B, T, H, W, 4), 9.0, dtype=torch.bfloat16, device="cuda")
+    ld = L.LayoutDesc()
+    ld.src, ld.dst = x.data_ptr(), x4.data_ptr()
+    ld.B, ld.C, ld.T, ld.H, ld.W, ld.c_p, ld.ld, ld.bs = B, 3, T, H, W, 4, 4, T * H * W * 4
+    ld.src_dtype, ld.dst_dtype = L.PV_BF16, L.PV_BF16
+    call("pv_ingest_ncdhw", ld)
+    assert torch.equal(x4[..., :3].permute(0, 4, 1, 2, 3), x) and torch.all(x4[..., 3] == 0)
+    kwp = (k[2] + 1) // 2 * 2
+    wp = torch.zeros(cout, k[0], k[1], kwp, 4, dtype=torch.bfloat16, device="cuda")
+    wp[:, :, :, : k[2], :3] = w.permute(0, 2, 3, 4, 1)
+    cp = (cout + 7) // 8 * 8
+    y = torch.full((B, To, Ho, Wo, cp), 5.0, dtype=torch.float32 if f32out else torch.bfloat16, device="cuda")
+    d = L.Conv3dDesc()
+    d.x, d.w, d.y, d.shift = x4.data_ptr(), wp.data_ptr(), y.data_ptr(), bias.data_ptr()
+    d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * 4, To * Ho * Wo * cp, 4, cp
+    d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, 4, To, Ho, Wo, cout
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *s, *p)
+    d.act, d.a_act, d.dtype, d.y_f32 = L.ACT_RELU, L.ACT_NONE, L.PV_BF16, int(f32out)
+    call("pv_conv3d", d)
+    assert rel_err(y[..., :cout].permute(0, 4, 1, 2, 3), want) <= (2e-3 if f32out else 1e-2)
+    assert torch.all(y[..., cout:] == 0)
+
+
+@pytest.mark.parametrize("rows,Cc", [(1000, 96), (333, 192), (77, 384), (50, 768), (9, 1000)])
+def test_layernorm_fp32_stream_to_bf16_operand(rows, Cc):
+    """The bf16 MViT plan normalises its fp32 residual stream into the bf16 GEMM operand."""
+    x = _rand((rows, Cc), 71, torch.float32, 2.0) + 0.5
+    g, b = _rand((Cc,), 72, torch.float32), _rand((Cc,), 73, torch.float32)
+    want = F.layer_norm(x, (Cc,), g, b, 1e-6)
+    y = torch.zeros(rows, Cc, dtype=torch.bfloat16, device="cuda")
+    d = L.RowsDesc()
+    d.x, d.y, d.gamma, d.beta = x.data_ptr(), y.data_ptr(), g.data_ptr(), b.data_ptr()
+    d.rows, d.C, d.ldx, d.ldy, d.eps, d.dtype, d.x_f32 = rows, Cc, Cc, Cc, 1e-6, L.PV_BF16, 1
+    call("pv_layernorm", d)
+    assert rel_err(y, want) <= 1e-2
+
+
+@pytest.mark.parametrize("stride,act", [((1, 1, 1), L.ACT_SWISH), ((1, 2, 2), L.ACT_NONE), ((1, 1, 1), L.ACT_RELU)])
+@pytest.mark.parametrize("B,T,H,W,Cc", [(2, 5, 20, 23, 54), (1, 16, 7, 7, 432), (2, 3, 30, 9, 40)])
+def test_depthwise_3x3x3_plane_kernel_with_se_partial_sums(B, T, H, W, Cc, stride, act):
+    """X3D conv_b (bf16): output and the squeeze-excitation partial sums against torch."""
+    cp = (Cc + 7) // 8 * 8
+    x = torch.zeros(B, T, H, W, cp, dtype=torch.bfloat16, device="cuda")
+    x[..., :Cc] = _rand((B, T, H, W, Cc), 81, torch.bfloat16)
+    w = _rand((Cc, 1, 3, 3, 3), 82, torch.float32, 0.3)
+    scale, shift = _rand((Cc,), 83, torch.float32) * 0.2 + 1.0, _rand((Cc,), 84, torch.float32)
+    pre = F.conv3d(x[..., :Cc].float().permute(0, 4, 1, 2, 3), w, None, stride=stride, padding=1, groups=Cc)
+    pre = pre * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+    want = pre * torch.sigmoid(pre) if act == L.ACT_SWISH else (F.relu(pre) if act == L.ACT_RELU else pre)
+    To, Ho, Wo = pre.shape[2:]
+    y = torch.full((B, To, Ho, Wo, cp), 3.0, dtype=torch.bfloat16, device="cuda")
+    wp = torch.zeros(27, cp, device="cuda")
+    wp[:, :Cc] = w.reshape(Cc, 27).t()
+    d = L.DwConv3dDesc()
+    d.x, d.w, d.y, d.scale, d.shift = x.data_ptr(), wp.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr()
+    d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * cp, To * Ho * Wo * cp, cp, cp
+    d.B, d.Ti, d.Hi, d.Wi, d.C, d.To, d.Ho, d.Wo = B, T, H, W, Cc, To, Ho, Wo
+    d.kt = d.kh = d.kw = 3
+    d.st, d.sh, d.sw = stride
+    d.pt = d.ph = d.pw = 1
+    d.w_mod, d.act, d.dtype, d.n_prefix = 0, act, L.PV_BF16, 0
+    nblk = L.lib().pv_dwconv3d_psum_blocks(C.byref(d))
+    assert nblk > 0
+    psum = torch.full((B, nblk, cp), float("nan"), device="cuda")
+    d.psum = psum.data_ptr()
+    call("pv_dwconv3d", d)
+    assert rel_err(y[..., :Cc].permute(0, 4, 1, 2, 3), want) <= 1e-2
+    assert torch.all(y[..., Cc:] == 0)
+    got_mean = psum.sum(1)[:, :Cc] / (To * Ho * Wo)
+    assert rel_err(got_mean, pre.mean(dim=[2, 3, 4])) <= 1e-3   # sums are fp32, before the bf16 rounding
