@@ -22,7 +22,6 @@
 //     bias, fp32-or-bf16 residual, activation) stays in registers and leaves as 16-byte stores;
 //   * tiles are numbered so that consecutive workgroups (same XCD -> same L2) share the
 //     activation rows and walk the weight panels.
-#include <stdlib.h>
 #include "pv_common.h"
 
 __device__ __attribute__((aligned(16))) unsigned int pv_zero_page[4] = {0u, 0u, 0u, 0u};
@@ -43,19 +42,29 @@ __device__ __forceinline__ int chi(int rho) {
   return (rho & ~31) + 16 * ((rho >> 2) & 1) + 4 * ((rho >> 3) & 3) + (rho & 3);
 }
 
-// BK = 64: two workgroups per CU, fewest barriers per FLOP (long K).  BK = 32: half the LDS, three
-// workgroups per CU cover each other's prologue / epilogue when K is only a few steps deep.
-template <bool PW, int BK>
+struct GemmGeom {   // per-thread staging geometry of one output tile
+  long w_off[4];    // element offset of the weight row carried by item j, or -1
+  long x_off[4];    // PW: element offset of the voxel row, or -1 ; general: clip offset or -1
+  int x_t[4], x_h[4], x_w[4];
+  long m0;
+  int n0;
+};
+
+// Persistent workgroups (two per CU): each walks a strided list of output tiles.  While the last K step
+// of a tile is multiplied and its epilogue runs, the LDS-DMA for the first K step of the NEXT tile is
+// already in flight, and the next tile's address arithmetic is done under the current tile's MFMAs --
+// for the short-K layers of MViT (K = 384: six steps) the per-tile prologue / epilogue is otherwise
+// as long as the K loop itself.
+template <bool PW>
 __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles,
                                                                 float inv_cin) {
+  constexpr int BK = 64;
   constexpr int TILE_ELEMS = 128 * BK;                          // one operand tile (elements)
-  constexpr int NJ = TILE_ELEMS * 2 / (kThreads * 16);          // 16-byte items per thread per operand tile
+  constexpr int NJ = TILE_ELEMS * 2 / (kThreads * 16);          // 16-byte items per thread per operand tile (4)
   constexpr int CPR = BK / 8;                                   // 16-byte chunks per tile row
-  // XOR swizzle of the chunk index that makes ds_read_b128 conflict-free (rows are CPR*16 bytes)
-  auto swz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
-  constexpr int NBUF = BK == 32 ? 4 : 2;                        // LDS ring depth
-  constexpr int PD = NBUF - 1;                                  // K steps in flight ahead of the multiply
-  __shared__ __attribute__((aligned(16))) bf16_t smem[NBUF * 2 * TILE_ELEMS];   // [buf][W | X][128][BK]
+  // XOR swizzle of the chunk index that makes ds_read_b128 conflict-free (rows are 128 bytes)
+  auto swz = [](int row) { return (row >> 1) & 7; };
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * TILE_ELEMS];   // [buf][W | X][128][64]
   __shared__ int s_tap[PW ? 1 : kMaxTaps];
 
   const int tid = threadIdx.x;
@@ -63,19 +72,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   const int wn = wave & 1, wm = wave >> 1;
-
-  // XCD-aware tile order (bijective for any tile count)
-  int tile;
-  {
-    const int id = blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3;
-    const int qn = total_tiles >> 3, rn = total_tiles & 7;
-    tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
-  }
-  const int tile_n = tile % tiles_n;
-  const long tile_m = tile / tiles_n;
-  const long m0 = tile_m * BM;
-  const int n0 = tile_n * BN;
 
   const long S_out = (long)d.To * d.Ho * d.Wo;
   const long M = (long)d.B * S_out;
@@ -96,49 +92,58 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
     __syncthreads();
   }
 
-  // ---- per-thread staging geometry: item g = j*256 + tid -> (row g>>3, LDS position g&7) ----
-  long w_off[NJ];          // element offset of the weight row, or -1
-  long x_off[NJ];          // PW: element offset of the voxel row, or -1 ; general: clip offset or -1
-  int x_t[NJ], x_h[NJ], x_w[NJ];
-  int kch[NJ];             // logical 8-channel chunk inside a K step carried by this item
+  // item g = j*256 + tid -> (row g/8, LDS position g%8); the logical chunk it carries is tile-independent
+  int kch[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int g = j * kThreads + tid;
-    const int row = g / CPR, pos = g % CPR;
-    kch[j] = pos ^ swz(row);
-    const int n = n0 + chi(row);
-    w_off[j] = n < d.cout ? (long)n * K : -1;
-    const long m = m0 + row;
-    if (m < M) {
-      const long b = m / S_out;
-      const long sp = m - b * S_out;
-      if constexpr (PW) {
-        x_off[j] = b * d.x_bs + sp * d.ldx;
-        x_t[j] = x_h[j] = x_w[j] = 0;
-      } else {
-        const int to = (int)(sp / (d.Ho * d.Wo));
-        const int r2 = (int)(sp - (long)to * d.Ho * d.Wo);
-        const int ho = r2 / d.Wo;
-        x_off[j] = b * d.x_bs;
-        x_t[j] = to * d.st - d.pt;
-        x_h[j] = ho * d.sh - d.ph;
-        x_w[j] = (r2 - ho * d.Wo) * d.sw - d.pw;
-      }
-    } else {
-      x_off[j] = -1;
-      x_t[j] = x_h[j] = x_w[j] = 0;
-    }
+    kch[j] = (g % CPR) ^ swz(g / CPR);
   }
 
+  // XCD-aware tile order (bijective for any tile count): work item `it` -> tile
+  auto geom_of = [&](int it, GemmGeom& gg) {
+    const int xcd = it & 7, slot = it >> 3;
+    const int qn = total_tiles >> 3, rn = total_tiles & 7;
+    const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+    const int tile_n = tile % tiles_n;
+    gg.m0 = (long)(tile / tiles_n) * BM;
+    gg.n0 = tile_n * BN;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int row = (j * kThreads + tid) / CPR;
+      const int n = gg.n0 + chi(row);
+      gg.w_off[j] = n < d.cout ? (long)n * K : -1;
+      const long m = gg.m0 + row;
+      if (m < M) {
+        const long b = m / S_out;
+        const long sp = m - b * S_out;
+        if constexpr (PW) {
+          gg.x_off[j] = b * d.x_bs + sp * d.ldx;
+          gg.x_t[j] = gg.x_h[j] = gg.x_w[j] = 0;
+        } else {
+          const int to = (int)(sp / (d.Ho * d.Wo));
+          const int r2 = (int)(sp - (long)to * d.Ho * d.Wo);
+          const int ho = r2 / d.Wo;
+          gg.x_off[j] = b * d.x_bs;
+          gg.x_t[j] = to * d.st - d.pt;
+          gg.x_h[j] = ho * d.sh - d.ph;
+          gg.x_w[j] = (r2 - ho * d.Wo) * d.sw - d.pw;
+        }
+      } else {
+        gg.x_off[j] = -1;
+        gg.x_t[j] = gg.x_h[j] = gg.x_w[j] = 0;
+      }
+    }
+  };
+
   // Source selection is done with bit masks, not `?:` -- the compiler would turn a select between two
-  // pointers into two exec-masked LDS-DMA instructions, and the K loop below COUNTS the DMA
-  // instructions a wave has in flight (exactly GL per step).
+  // pointers into two exec-masked LDS-DMA instructions.
   const unsigned long zaddr = (unsigned long)zero;
   auto pick = [&](bool ok, const bf16_t* p) -> const bf16_t* {
     const unsigned long m = 0ul - (unsigned long)ok;
     return reinterpret_cast<const bf16_t*>(((unsigned long)p & m) | (zaddr & ~m));
   };
-  auto stage = [&](int buf, int ks) {
+  auto stage = [&](int buf, const GemmGeom& gg, int ks) {
     bf16_t* wb = smem + buf * 2 * TILE_ELEMS;
     bf16_t* xb = wb + TILE_ELEMS;
     const int k0 = ks * BK;
@@ -146,32 +151,22 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
     for (int j = 0; j < NJ; ++j) {
       const int k = k0 + kch[j] * 8;
       const bool kok = k < K;
-      // weights
-      __builtin_amdgcn_global_load_lds((gptr_t)pick(kok && w_off[j] >= 0, Wt + (w_off[j] >= 0 ? w_off[j] : 0) + k),
+      __builtin_amdgcn_global_load_lds((gptr_t)pick(kok && gg.w_off[j] >= 0, Wt + (gg.w_off[j] >= 0 ? gg.w_off[j] : 0) + k),
                                        (lptr_t)(wb + (j * kThreads + wave * 64) * 8), 16, 0, 0);
-      // activations
-      bool xok = kok && x_off[j] >= 0;
-      long xo = x_off[j] >= 0 ? x_off[j] : 0;
+      bool xok = kok && gg.x_off[j] >= 0;
+      long xo = gg.x_off[j] >= 0 ? gg.x_off[j] : 0;
       if constexpr (PW) {
         xo += k;
       } else {
         const int tap = (int)(((float)k + 0.5f) * inv_cin);
         const int tp = s_tap[tap < taps ? tap : 0];
-        const int ti = x_t[j] + (tp & 255), hh = x_h[j] + ((tp >> 8) & 255), ww = x_w[j] + (tp >> 16);
+        const int ti = gg.x_t[j] + (tp & 255), hh = gg.x_h[j] + ((tp >> 8) & 255), ww = gg.x_w[j] + (tp >> 16);
         xok = xok && (unsigned)ti < (unsigned)d.Ti && (unsigned)hh < (unsigned)d.Hi && (unsigned)ww < (unsigned)d.Wi;
         xo += ((long)(ti * d.Hi + hh) * d.Wi + ww) * d.ldx + (k - tap * d.cin);
       }
       __builtin_amdgcn_global_load_lds((gptr_t)pick(xok, X + xo), (lptr_t)(xb + (j * kThreads + wave * 64) * 8), 16, 0, 0);
     }
   };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int v = 0; v < 2; ++v)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][v][r] = 0.f;
 
   // read-side swizzle of this lane's fragment rows (fixed for the whole kernel)
   int a_row[2], b_row[2];
@@ -180,116 +175,163 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
     a_row[t] = wn * 64 + t * 32 + l31;
     b_row[t] = wm * 64 + t * 32 + l31;
   }
+  // s_waitcnt simm16 on gfx9: vmcnt = bits [3:0] | [15:14]; expcnt [6:4] and lgkmcnt [11:8] left at "no wait"
+  constexpr auto vm = [](int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); };
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr unsigned kOOB = 0x80000000u;
+  __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      d.y, 0, (int)((unsigned)d.B * (unsigned)d.y_bs * (d.y_f32 ? 4u : 2u)), 0x00020000);
+  bool first_wait_stores = false;   // wave-uniform
 
   const int nk = (K + BK - 1) / BK;
-  // K loop: an LDS ring of NBUF step-buffers with PD = NBUF-1 steps of LDS-DMA in flight.  Each wave
-  // waits only for ITS OWN loads of the step about to be multiplied (counted vmcnt: the younger
-  // steps stay in flight across the barrier), then one raw barrier publishes the buffer to the
-  // workgroup and, at the same time, proves that everybody is done reading the buffer that is
-  // refilled next.  (A plain __syncthreads() would drain the whole DMA queue every step.)
-  constexpr int GL = 2 * NJ;   // LDS-DMA instructions per thread per K step
-#pragma unroll
-  for (int s0 = 0; s0 < PD; ++s0)
-    if (s0 < nk) stage(s0, s0);
-  for (int ks = 0; ks < nk; ++ks) {
-    const int rem = nk - 1 - ks;   // steps after this one (wave-uniform)
-    // s_waitcnt simm16 on gfx9: vmcnt = bits [3:0] | [15:14], expcnt [6:4] and lgkmcnt [11:8] left at "no wait"
-    constexpr int kWaitNone = (7 << 4) | (15 << 8);
-    constexpr auto vm = [](int n) { return (n & 15) | ((n >> 4) << 14) | kWaitNone; };
-    if (PD >= 3 && rem >= 2) __builtin_amdgcn_s_waitcnt(vm(2 * GL));
-    else if (PD >= 2 && rem >= 1) __builtin_amdgcn_s_waitcnt(vm(GL));
-    else __builtin_amdgcn_s_waitcnt(vm(0));
-    __builtin_amdgcn_s_barrier();
-    if (ks + PD < nk) stage((ks + PD) % NBUF, ks + PD);
-    const bf16_t* wb = smem + (ks % NBUF) * 2 * TILE_ELEMS;
-    const bf16_t* xb = wb + TILE_ELEMS;
-    // fragment reads are software-pipelined one 16-deep sub-step ahead of the MFMAs that use them
-    bf16x8 af[2][2], bfr[2][2];
-    auto read_frags = [&](int slot, int s) {
-      const int c = 2 * s + hi;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        af[slot][t] = *reinterpret_cast<const bf16x8*>(wb + a_row[t] * BK + ((c ^ swz(a_row[t])) << 3));
-        bfr[slot][t] = *reinterpret_cast<const bf16x8*>(xb + b_row[t] * BK + ((c ^ swz(b_row[t])) << 3));
-      }
-    };
-    read_frags(0, 0);
-#pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      if (s + 1 < BK / 16) read_frags((s + 1) & 1, s + 1);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int v = 0; v < 2; ++v)
-          acc[a][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][a], bfr[s & 1][v], acc[a][v], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  }
+  GemmGeom cur, nxt;
+  int it = blockIdx.x;
+  geom_of(it, cur);
+  stage(0, cur, 0);
+  int gs = 0;   // global K-step counter: LDS buffer parity runs on across tiles
+  for (; it < total_tiles; it += gridDim.x) {
+    const bool has_next = it + (int)gridDim.x < total_tiles;
+    if (has_next) geom_of(it + gridDim.x, nxt);
 
-  // ---- epilogue: lane owns channels cb..cb+15 of voxel m for every (channel tile a, voxel tile v) ----
+    f32x16 acc[2][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int cb = n0 + wn * 64 + a * 32 + 16 * hi;
-    if (cb >= cout_p8) continue;
-    float sc[16], sh[16];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const bool ok = cb + r < d.cout;
-      sc[r] = ok ? (d.scale ? d.scale[cb + r] : 1.f) : 0.f;
-      sh[r] = ok ? (d.shift ? d.shift[cb + r] : 0.f) : 0.f;
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][v][r] = 0.f;
+
+    for (int ks = 0; ks < nk; ++ks, ++gs) {
+      // this wave's share of the step's tiles has landed; the barrier publishes the buffer and proves
+      // that every wave is done reading the other one, which is refilled next
+      if (first_wait_stores) {
+        // the LDS-DMA of this step was issued BEFORE the previous tile's stores (in-order return):
+        // leave exactly those stores in flight
+        if (d.y_f32) __builtin_amdgcn_s_waitcnt(vm(16));
+        else __builtin_amdgcn_s_waitcnt(vm(8));
+        first_wait_stores = false;
+      } else {
+        __builtin_amdgcn_s_waitcnt(vm(0));
+      }
+      __builtin_amdgcn_s_barrier();
+      if (ks + 1 < nk) stage((gs + 1) & 1, cur, ks + 1);
+      else if (has_next) stage((gs + 1) & 1, nxt, 0);   // first step of the next tile: in flight during the epilogue
+      const bf16_t* wb = smem + (gs & 1) * 2 * TILE_ELEMS;
+      const bf16_t* xb = wb + TILE_ELEMS;
+      // fragment reads are software-pipelined one 16-deep sub-step ahead of the MFMAs that use them
+      bf16x8 af[2][2], bfr[2][2];
+      auto read_frags = [&](int slot, int s) {
+        const int c = 2 * s + hi;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          af[slot][t] = *reinterpret_cast<const bf16x8*>(wb + a_row[t] * BK + ((c ^ swz(a_row[t])) << 3));
+          bfr[slot][t] = *reinterpret_cast<const bf16x8*>(xb + b_row[t] * BK + ((c ^ swz(b_row[t])) << 3));
+        }
+      };
+      read_frags(0, 0);
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        if (s + 1 < BK / 16) read_frags((s + 1) & 1, s + 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int v = 0; v < 2; ++v)
+            acc[a][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][a], bfr[s & 1][v], acc[a][v], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
     }
+
+    // ---- epilogue: lane owns channels cb..cb+15 of voxel m for every (channel tile a, voxel tile v) ----
+    // Output goes through a buffer descriptor: masked stores get an out-of-range offset and are dropped
+    // by the hardware, so every wave issues EXACTLY kStores store instructions per tile -- the next
+    // tile's first wait can then be a counted vmcnt that leaves them in flight.
+    // every load of the epilogue (residual rows, scale / shift) is consumed before the first store is
+    // issued -- a load consumed after a store would make the compiler drain the store queue
+    long e_b[2], e_sp[2];
+    bool e_ok[2];
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
-      const long m = m0 + wm * 64 + v * 32 + l31;
-      if (m >= M) continue;
-      const long b = m / S_out;
-      const long sp = m - b * S_out;
-      float o[16];
+      const long m = cur.m0 + wm * 64 + v * 32 + l31;
+      e_ok[v] = m < M;
+      const long mm = e_ok[v] ? m : 0;
+      e_b[v] = mm / S_out;
+      e_sp[v] = mm - e_b[v] * S_out;
+    }
+    // finish the accumulators in place, one channel tile at a time (scale/shift and residual loads of
+    // tile a are consumed before tile a+1's are issued; no store has been issued yet) ...
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] = acc[a][v][r] * sc[r] + sh[r];
+    for (int a = 0; a < 2; ++a) {
+      const int cb = cur.n0 + wn * 64 + a * 32 + 16 * hi;
+      f32x4 res[2][2][2];   // [v][h8][half]: 8 channels as 2 x f32x4 (fp32) or 1 x 16 bytes (bf16)
       if (d.residual != nullptr) {
-        const long ro = b * d.r_bs + sp * d.ldr + cb;
 #pragma unroll
-        for (int h8 = 0; h8 < 2; ++h8) {
-          if (cb + h8 * 8 >= cout_p8) continue;
-          float rf[8];
-          if (d.r_f32) {
-            Chunk8<float> rc;
-            rc.load(static_cast<const float*>(d.residual) + ro + h8 * 8);
-            rc.to_f32(rf);
-          } else {
-            Chunk8<bf16_t> rc;
-            rc.load(static_cast<const bf16_t*>(d.residual) + ro + h8 * 8);
-            rc.to_f32(rf);
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int h8 = 0; h8 < 2; ++h8) {
+            const bool ok = e_ok[v] && cb + h8 * 8 < cout_p8;
+            const long ro = ok ? e_b[v] * d.r_bs + e_sp[v] * d.ldr + cb + h8 * 8 : 0;
+            if (d.r_f32) {
+              const float* rp = static_cast<const float*>(d.residual) + ro;
+              res[v][h8][0] = *reinterpret_cast<const f32x4*>(rp);
+              res[v][h8][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+            } else {
+              res[v][h8][0] = *reinterpret_cast<const f32x4*>(static_cast<const bf16_t*>(d.residual) + ro);
+            }
           }
-#pragma unroll
-          for (int r = 0; r < 8; ++r) o[h8 * 8 + r] += rf[r];
-        }
       }
+      float sc[16], sh[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        o[r] = pv_apply_act(o[r], d.act);
-        if (cb + r >= d.cout) o[r] = 0.f;
+        const bool ok = cb + r < d.cout;
+        sc[r] = ok ? (d.scale ? d.scale[cb + r] : 1.f) : 0.f;
+        sh[r] = ok ? (d.shift ? d.shift[cb + r] : 0.f) : 0.f;
       }
-      const long yo = b * d.y_bs + sp * d.ldy + cb;
 #pragma unroll
-      for (int h8 = 0; h8 < 2; ++h8) {
-        if (cb + h8 * 8 >= cout_p8) continue;
-        float o8[8];
+      for (int v = 0; v < 2; ++v) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) o8[r] = o[h8 * 8 + r];
-        if (d.y_f32) {
-          Chunk8<float> oc;
-          oc.from_f32(o8);
-          oc.store(static_cast<float*>(d.y) + yo + h8 * 8);
-        } else {
-          Chunk8<bf16_t> oc;
-          oc.from_f32(o8);
-          oc.store(static_cast<bf16_t*>(d.y) + yo + h8 * 8);
+        for (int r = 0; r < 16; ++r) {
+          float o = acc[a][v][r] * sc[r] + sh[r];
+          if (d.residual != nullptr) {
+            if (d.r_f32) o += res[v][r >> 3][(r >> 2) & 1][r & 3];
+            else o += (float)__builtin_bit_cast(bf16x8, res[v][r >> 3][0])[r & 7];
+          }
+          o = pv_apply_act(o, d.act);
+          acc[a][v][r] = cb + r < d.cout ? o : 0.f;
         }
       }
     }
+    // ... then nothing but stores
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int cb = cur.n0 + wn * 64 + a * 32 + 16 * hi;
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const unsigned yo = (unsigned)(e_b[v] * d.y_bs + e_sp[v] * d.ldy + cb);   // elements (< 2^31 bytes: host check)
+#pragma unroll
+        for (int h8 = 0; h8 < 2; ++h8) {
+          const bool ok = e_ok[v] && cb + h8 * 8 < cout_p8;
+          const int r0 = h8 * 8;
+          if (d.y_f32) {
+            const unsigned off = ok ? (yo + r0) * 4u : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b128(
+                u32x4{__float_as_uint(acc[a][v][r0 + 0]), __float_as_uint(acc[a][v][r0 + 1]),
+                      __float_as_uint(acc[a][v][r0 + 2]), __float_as_uint(acc[a][v][r0 + 3])}, ry, (int)off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(
+                u32x4{__float_as_uint(acc[a][v][r0 + 4]), __float_as_uint(acc[a][v][r0 + 5]),
+                      __float_as_uint(acc[a][v][r0 + 6]), __float_as_uint(acc[a][v][r0 + 7])}, ry,
+                (int)(ok ? off + 16u : kOOB), 0, 0);
+          } else {
+            bf16x8 ob;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ob[r] = (bf16_t)acc[a][v][r0 + r];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), ry, (int)(ok ? (yo + r0) * 2u : kOOB), 0, 0);
+          }
+        }
+      }
+    }
+    first_wait_stores = true;
+    cur = nxt;
   }
 }
 
@@ -306,16 +348,13 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   const int tiles_n = (int)pv_ceil_div(cout_p8, BN);
   const long total = tiles_m * tiles_n;
   if (total <= 0 || total > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
+  if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return PV_ERR_UNSUPPORTED;   // 31-bit buffer offsets
   const float inv_cin = 1.0f / (float)d.cin;
-  static const int bk_env = getenv("PV_GEMM_BK") ? atoi(getenv("PV_GEMM_BK")) : 0;
-  const int K = taps * d.cin;
-  (void)K;
-  const bool bk32 = bk_env == 32;   // measured: the 64-deep step wins at every K once fragment reads are pipelined
-  dim3 grid((unsigned)total), block(kThreads);
-  if (pw && bk32) hipLaunchKernelGGL((gemm_glds_kernel<true, 32>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-  else if (pw) hipLaunchKernelGGL((gemm_glds_kernel<true, 64>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-  else if (bk32) hipLaunchKernelGGL((gemm_glds_kernel<false, 32>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-  else hipLaunchKernelGGL((gemm_glds_kernel<false, 64>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+  // two persistent workgroups per CU (64 KB of LDS each), in multiples of the 8 XCDs
+  const long resident = 2 * 256;
+  dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads);
+  if (pw) hipLaunchKernelGGL(gemm_glds_kernel<true>, grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+  else hipLaunchKernelGGL(gemm_glds_kernel<false>, grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }
