@@ -120,6 +120,34 @@ typedef struct pv_dwconv3d_desc {
 int pv_dwconv3d(const pv_dwconv3d_desc* d, pv_stream_t stream);
 int pv_dwconv3d_psum_blocks(const pv_dwconv3d_desc* d);
 
+/* ---- MViT attention pooling (fused) ----------------------------------------------------
+ * _AttentionPool.forward with pool_mode="conv" (layers/attention.py:162-212, pools built at
+ * :363-404): for up to three token tensors at once (q, k, v of one MultiScaleAttention) the
+ * depthwise Conv3d over the (T,H,W) token grid (weights [taps][head_dim] fp32, shared by all
+ * heads, padding = kernel/2, no bias), the cls-token pass-through (n_prefix rows) and the
+ * LayerNorm(head_dim) applied to every (token, head) afterwards -- one launch instead of six.
+ * Tensor i reads x[i] (B, n_prefix + Ti*Hi*Wi, heads*head_dim) with row stride ldx[i] and writes
+ * y[i] (B, n_prefix + To[i]*Ho[i]*Wo[i], heads*head_dim) with row stride ldy[i].
+ */
+typedef struct pv_token_pool_desc {
+  const void* x[3];
+  void* y[3];
+  const float* w[3];      /* [kt*kh*kw][head_dim]                    */
+  const float* gamma[3];  /* LayerNorm weight [head_dim] or NULL     */
+  const float* beta[3];   /* LayerNorm bias   [head_dim] or NULL     */
+  int64_t x_bs[3], y_bs[3];
+  int32_t ldx[3], ldy[3];
+  int32_t st[3], sh[3], sw[3];
+  int32_t To[3], Ho[3], Wo[3];
+  int32_t n;              /* tensors in this launch (1..3)           */
+  int32_t B, Ti, Hi, Wi, heads, head_dim;
+  int32_t kt, kh, kw;
+  int32_t n_prefix;
+  float eps;
+  int32_t dtype;
+} pv_token_pool_desc;
+int pv_token_pool(const pv_token_pool_desc* d, pv_stream_t stream);
+
 /* ---- squeeze-excitation gate -------------------------------------------------------
  * fvcore.nn.squeeze_excitation.SqueezeExcitation as used at models/x3d.py:190-198:
  * gate[b][c] = sigmoid(W2 . relu(W1 . mean_{T,H,W}(x) + b1) + b2); the multiply is done
@@ -238,7 +266,7 @@ int pv_add_act(const pv_add_desc* d, pv_stream_t stream);
 enum pv_op_kind {
   PV_OP_CONV3D = 1, PV_OP_DWCONV3D = 2, PV_OP_SE_GATE = 3, PV_OP_POOL3D = 4,
   PV_OP_LAYERNORM = 5, PV_OP_SOFTMAX_ROWS = 6, PV_OP_MEAN_ROWS = 7, PV_OP_POSENC = 8,
-  PV_OP_ATTENTION = 9, PV_OP_ADD_ACT = 10, PV_OP_INGEST = 11, PV_OP_EGRESS = 12
+  PV_OP_ATTENTION = 9, PV_OP_ADD_ACT = 10, PV_OP_INGEST = 11, PV_OP_EGRESS = 12, PV_OP_TOKEN_POOL = 13
 };
 typedef struct pv_plan pv_plan;
 pv_plan* pv_plan_create(void);

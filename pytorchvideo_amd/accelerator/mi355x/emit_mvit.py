@@ -145,6 +145,83 @@ def emit_attention_pool(sess, ap, x, heads, label):
     return y
 
 
+def _streams_well(ap, x):
+    """Pooling convs the plane-streaming depthwise kernel takes (3x3x3, temporal stride 1, spatial
+    stride 1 or 2) on a grid big enough to fill the chip: it reads every input voxel about once,
+    where the fused per-token kernel re-reads the 27-voxel window from L2 for every output."""
+    pool = ap.pool if ap.has_pool else None
+    if not isinstance(pool, nn.Conv3d) or x.thw is None:
+        return False
+    if tuple(pool.kernel_size) != (3, 3, 3) or tuple(E._triple(pool.padding)) != (1, 1, 1):
+        return False
+    st = tuple(pool.stride)
+    if st[0] != 1 or st[1] != st[2] or st[1] not in (1, 2):
+        return False
+    T, H, W = x.thw
+    return x.B * T * H * W * x.C >= (1 << 23)
+
+
+def emit_attention_pools_fused(sess, pools, xs, heads, label, skip=()):
+    """q / k / v pooling of one MultiScaleAttention as ONE launch (pv_token_pool): depthwise conv on
+    the token grid + cls pass-through + LayerNorm(head_dim).  `pools` are the _AttentionPool modules,
+    `xs` their inputs; tensors whose module has no pool are returned unchanged.  Returns None when
+    the combination is not covered (the caller then emits the pools one by one)."""
+    todo = [(i, ap, x) for i, (ap, x) in enumerate(zip(pools, xs)) if ap.has_pool and i not in skip]
+    if not todo:
+        return list(xs)
+    x0 = todo[0][2]
+    hd = x0.C // heads
+    if x0.thw is None or hd % 8 or hd > 128:
+        return None
+    kernel = None
+    for _, ap, x in todo:
+        pool = ap.pool
+        if not isinstance(pool, nn.Conv3d) or pool.groups != pool.in_channels or pool.in_channels != pool.out_channels:
+            return None
+        if pool.in_channels != hd or pool.bias is not None or tuple(pool.dilation) != (1, 1, 1) or pool.padding_mode != "zeros":
+            return None
+        if tuple(E._triple(pool.padding)) != tuple(k // 2 for k in pool.kernel_size):
+            return None
+        if ap.has_norm and (ap.norm_before_pool or not isinstance(ap.norm, nn.LayerNorm)
+                            or tuple(ap.norm.normalized_shape) != (hd,)):
+            return None
+        if kernel is None:
+            kernel, eps, prefix = tuple(pool.kernel_size), (float(ap.norm.eps) if ap.has_norm else 1e-6), ap.has_cls_embed
+        elif tuple(pool.kernel_size) != kernel or bool(ap.has_cls_embed) != bool(prefix) or x.thw != x0.thw \
+                or x.C != x0.C or (ap.has_norm and float(ap.norm.eps) != eps):
+            return None
+    if kernel[0] * kernel[1] * kernel[2] > 64:
+        return None
+    T, H, W = x0.thw
+    n_prefix = 1 if prefix else 0
+    out = list(xs)
+    f = dict(x=[], y=[], w=[], gamma=[], beta=[], x_bs=[], y_bs=[], ldx=[], ldy=[], st=[], sh=[], sw=[],
+             To=[], Ho=[], Wo=[], n=len(todo), B=x0.B, Ti=T, Hi=H, Wi=W, heads=heads, head_dim=hd,
+             kt=kernel[0], kh=kernel[1], kw=kernel[2], n_prefix=n_prefix, eps=eps, dtype=sess.pv_dtype)
+    alg = flops = 0
+    for i, ap, x in todo:
+        pool = ap.pool
+        st = tuple(pool.stride)
+        To, Ho, Wo = [E._conv_out(v, k, s_, k // 2) for v, k, s_ in zip((T, H, W), kernel, st)]
+        if min(To, Ho, Wo) <= 0:
+            raise RuntimeError("pool output would be empty")
+        y = sess.alloc_act(x.B, 1, 1, n_prefix + To * Ho * Wo, x.C)
+        y.thw, y.has_cls = (To, Ho, Wo), bool(n_prefix)
+        f["x"].append(x.ptr), f["y"].append(y.ptr)
+        f["w"].append(sess.add_weight(pool.weight.detach().float().reshape(hd, -1).t().contiguous()))
+        f["gamma"].append(sess.add_weight(ap.norm.weight.detach().float()) if ap.has_norm and ap.norm.weight is not None else None)
+        f["beta"].append(sess.add_weight(ap.norm.bias.detach().float()) if ap.has_norm and ap.norm.bias is not None else None)
+        f["x_bs"].append(x.bs), f["y_bs"].append(y.bs), f["ldx"].append(x.ld), f["ldy"].append(y.ld)
+        f["st"].append(st[0]), f["sh"].append(st[1]), f["sw"].append(st[2])
+        f["To"].append(To), f["Ho"].append(Ho), f["Wo"].append(Wo)
+        vin, vout = x.B * T * H * W, x.B * To * Ho * Wo
+        alg += sess.itemsize * (min(vin, vout * kernel[0] * kernel[1] * kernel[2]) + vout) * x.C
+        flops += 2 * vout * x.C * kernel[0] * kernel[1] * kernel[2]
+        out[i] = y
+    sess.add_op(L.OP_TOKEN_POOL, f, label=label, alg_bytes=alg, flops=flops)
+    return out
+
+
 def emit_attention_core(sess, q, k, v, heads, scale, residual_q, label="attention"):
     hd = q.C // heads
     if hd not in (32, 64, 96, 128):
@@ -198,9 +275,22 @@ def emit_multiscale_attention(sess, attn, xn, residual, label="attn"):
             t = qkv.channel_slice(i * attn.dim_out, attn.dim_out)
             t.thw, t.has_cls = xn.thw, xn.has_cls
             parts.append(t)
-        q = emit_attention_pool(sess, attn._attention_pool_q, parts[0], heads, label + ".pool_q")
-        k = emit_attention_pool(sess, attn._attention_pool_k, parts[1], heads, label + ".pool_k")
-        v = emit_attention_pool(sess, attn._attention_pool_v, parts[2], heads, label + ".pool_v")
+        pools = (attn._attention_pool_q, attn._attention_pool_k, attn._attention_pool_v)
+        names = (".pool_q", ".pool_k", ".pool_v")
+        outs = list(parts)
+        big = [i for i in range(3) if _streams_well(pools[i], parts[i])]
+        for i in big:
+            outs[i] = emit_attention_pool(sess, pools[i], parts[i], heads, label + names[i])
+        fused = emit_attention_pools_fused(sess, pools, parts, heads, label + ".pool_qkv", skip=big)
+        if fused is not None:
+            for i in range(3):
+                if i not in big:
+                    outs[i] = fused[i]
+        else:
+            for i in range(3):
+                if i not in big:
+                    outs[i] = emit_attention_pool(sess, pools[i], parts[i], heads, label + names[i])
+        q, k, v = outs
         owned += [t for t, p in zip((q, k, v), parts) if t is not p]
         owned.append(qkv)
     o = emit_attention_core(sess, q, k, v, heads, attn.scale, attn.residual_pool, label=label + ".core")

@@ -205,12 +205,17 @@ class Session:
         self.plan = C.c_void_p(lib.pv_plan_create())
         for kind, cls, fields, label, _, _ in self.ops:
             d = cls()
+            def resolve(v):
+                return base[v.space] + v.off if isinstance(v, Ptr) else v
+
             for k, v in fields.items():
-                if isinstance(v, Ptr):
-                    v = base[v.space] + v.off
-                elif v is None:
-                    v = None
-                setattr(d, k, v)
+                if isinstance(v, (list, tuple)):   # fixed-size array field, short lists are zero-padded
+                    arr_t = dict(cls._fields_)[k]
+                    vals = [resolve(e) for e in v]
+                    vals += [None if arr_t._type_ is C.c_void_p else 0] * (arr_t._length_ - len(vals))
+                    setattr(d, k, arr_t(*vals))
+                else:
+                    setattr(d, k, resolve(v))
             self._desc_keep.append(d)
             L.check(lib.pv_plan_add(self.plan, kind, C.byref(d), C.sizeof(d)), "pv_plan_add(%s)" % label)
         self.finalized = True

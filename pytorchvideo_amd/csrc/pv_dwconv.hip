@@ -239,18 +239,23 @@ __global__ __launch_bounds__(kPlaneThreads) void dw3_plane_kernel(const pv_dwcon
   // image, padded channels, masked outputs) read as 0 / are dropped by the hardware, so the plane
   // loop has no exec-masked branches and the compiler keeps counted vmcnt waits.
   constexpr unsigned kOOB = 0x80000000u;
-  const bf16_t* X = static_cast<const bf16_t*>(d.x) + (long)b * d.x_bs;
-  bf16_t* Y = static_cast<bf16_t*>(d.y) + (long)b * d.y_bs;
+  // token tensors (MViT pooling): the n_prefix leading rows (cls token) are skipped here and
+  // copied by dw_prefix_kernel
+  const bf16_t* X = static_cast<const bf16_t*>(d.x) + (long)b * d.x_bs + (long)d.n_prefix * d.ldx;
+  bf16_t* Y = static_cast<bf16_t*>(d.y) + (long)b * d.y_bs + (long)d.n_prefix * d.ldy;
   const unsigned x_plane_bytes = (unsigned)(d.Hi * d.Wi * d.ldx) * 2u;
   const unsigned y_plane_bytes = (unsigned)(d.Ho * d.Wo * d.ldy) * 2u;
   __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(x_plane_bytes * (unsigned)d.Ti), 0x00020000);
   __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)Y, 0, (int)(y_plane_bytes * (unsigned)d.To), 0x00020000);
 
   // ---- this lane's 27 x 2 filter taps, folded-BN scale/shift: registers for the whole kernel ----
+  // (w_mod > 0: one filter shared by every head, channel c uses filter column c % w_mod)
   float2 wt[27];
+  const int w_p = d.w_mod > 0 ? pv_round_up(d.w_mod, 8) : c_p;
+  const int wch = d.w_mod > 0 ? ch % d.w_mod : ch;
 #pragma unroll
   for (int t = 0; t < 27; ++t)
-    wt[t] = ch_ok ? *reinterpret_cast<const float2*>(d.w + (long)t * c_p + ch) : float2{0.f, 0.f};
+    wt[t] = ch_ok ? *reinterpret_cast<const float2*>(d.w + (long)t * w_p + wch) : float2{0.f, 0.f};
   float2 sc = {0.f, 0.f}, sh = {0.f, 0.f};
   if (ch_ok) {
     sc.x = ch < d.C ? (d.scale ? d.scale[ch] : 1.f) : 0.f;
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(kPlaneThreads) void dw3_plane_kernel(const pv_dwcon
 
 // which layers the plane-streaming kernel takes, and with how many outputs per lane
 int plane_variant(const pv_dwconv3d_desc& d) {
-  if (d.dtype != PV_BF16 || d.w_mod != 0 || d.n_prefix != 0) return 0;
+  if (d.dtype != PV_BF16 || (d.n_prefix != 0 && d.psum)) return 0;
   if (d.kt != 3 || d.kh != 3 || d.kw != 3 || d.st != 1 || d.pt != 1 || d.ph != 1 || d.pw != 1) return 0;
   if (d.sh != d.sw || (d.sw != 1 && d.sw != 2)) return 0;
   if (d.act != PV_ACT_NONE && d.act != PV_ACT_RELU && d.act != PV_ACT_SWISH) return 0;
@@ -421,6 +426,11 @@ template <int S, int NW> int launch_plane(const pv_dwconv3d_desc& d, hipStream_t
   const long blocks = pv_ceil_div((long)ntiles * d.B, 8) * 8 * ngroups;
   if (blocks > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
   dim3 grid((unsigned)blocks), block(kPlaneThreads);
+  if (d.n_prefix > 0) {
+    const int total = d.B * d.n_prefix * (c_p / 8);
+    hipLaunchKernelGGL(dw_prefix_kernel<bf16_t>, dim3((unsigned)pv_ceil_div(total, kThreads)), dim3(kThreads), 0, s, d);
+    PV_LAUNCH_CHECK();
+  }
   if (d.act == PV_ACT_NONE) hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_NONE>), grid, block, 0, s, d, ntiles, ngroups);
   else if (d.act == PV_ACT_RELU) hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_RELU>), grid, block, 0, s, d, ntiles, ngroups);
   else hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_SWISH>), grid, block, 0, s, d, ntiles, ngroups);

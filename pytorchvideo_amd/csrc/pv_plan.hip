@@ -9,7 +9,7 @@
 
 namespace {
 thread_local std::string g_last_error;
-constexpr int kAbiVersion = 3;
+constexpr int kAbiVersion = 4;
 }  // namespace
 
 int pv_set_hip_error(hipError_t e, const char* what) {
@@ -53,6 +53,7 @@ size_t desc_size(int kind) {
     case PV_OP_ADD_ACT: return sizeof(pv_add_desc);
     case PV_OP_INGEST:
     case PV_OP_EGRESS: return sizeof(pv_layout_desc);
+    case PV_OP_TOKEN_POOL: return sizeof(pv_token_pool_desc);
     default: return 0;
   }
 }
@@ -72,6 +73,7 @@ int run_op(const pv_plan::Op& op, pv_stream_t s) {
     case PV_OP_ADD_ACT: return pv_add_act(static_cast<const pv_add_desc*>(p), s);
     case PV_OP_INGEST: return pv_ingest_ncdhw(static_cast<const pv_layout_desc*>(p), s);
     case PV_OP_EGRESS: return pv_egress_ncdhw(static_cast<const pv_layout_desc*>(p), s);
+    case PV_OP_TOKEN_POOL: return pv_token_pool(static_cast<const pv_token_pool_desc*>(p), s);
     default: return PV_ERR_INVALID;
   }
 }

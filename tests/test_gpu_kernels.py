@@ -314,3 +314,45 @@ def test_depthwise_3x3x3_plane_kernel_with_se_partial_sums(B, T, H, W, Cc, strid
     assert torch.all(y[..., Cc:] == 0)
     got_mean = psum.sum(1)[:, :Cc] / (To * Ho * Wo)
     assert rel_err(got_mean, pre.mean(dim=[2, 3, 4])) <= 1e-3   # sums are fp32, before the bf16 rounding
+
+
+# ------------------------------------------------------------------ fused q/k/v pooling + LayerNorm (one launch)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("heads,hd,thw,strides,cls", [
+    (4, 96, (4, 14, 14), [(1, 1, 1), (1, 2, 2), (1, 2, 2)], 1),   # MViT-B block 4..13 (q unpooled there; all three here)
+    (2, 96, (2, 16, 16), [(1, 2, 2), (1, 4, 4), (1, 4, 4)], 1),
+    (1, 96, (4, 8, 8), [(1, 8, 8)], 1),
+    (2, 64, (4, 6, 6), [(2, 2, 2), (1, 1, 1)], 0),
+])
+def test_fused_token_pooling_conv_layernorm(dtype, heads, hd, thw, strides, cls):
+    B = 2
+    T, H, W = thw
+    Cw = heads * hd
+    n = len(strides)
+    d = L.TokenPoolDesc()
+    keep, wants, outs = [], [], []
+    for i, st in enumerate(strides):
+        x = _rand((B, cls + T * H * W, Cw), 90 + i, dtype)
+        w = _rand((hd, 1, 3, 3, 3), 95 + i, torch.float32, 0.3)
+        g, bta = _rand((hd,), 100 + i, torch.float32) * 0.2 + 1.0, _rand((hd,), 105 + i, torch.float32) * 0.2
+        grid = x[:, cls:].float().reshape(B, T, H, W, heads, hd).permute(0, 4, 5, 1, 2, 3).reshape(B * heads, hd, T, H, W)
+        ref = F.conv3d(grid, w, None, stride=st, padding=1, groups=hd)
+        To, Ho, Wo = ref.shape[2:]
+        ref = ref.reshape(B, heads, hd, To * Ho * Wo).permute(0, 3, 1, 2)          # (B, L, heads, hd)
+        if cls:
+            ref = torch.cat([x[:, :1].float().reshape(B, 1, heads, hd), ref], 1)
+        wants.append(F.layer_norm(ref, (hd,), g, bta, 1e-6).reshape(B, -1, Cw))
+        y = torch.full((B, cls + To * Ho * Wo, Cw), 7.0, dtype=dtype, device="cuda")
+        wp = w.reshape(hd, 27).t().contiguous()
+        keep += [x, wp, g, bta]
+        outs.append(y)
+        d.x[i], d.y[i], d.w[i], d.gamma[i], d.beta[i] = x.data_ptr(), y.data_ptr(), wp.data_ptr(), g.data_ptr(), bta.data_ptr()
+        d.x_bs[i], d.y_bs[i], d.ldx[i], d.ldy[i] = x.stride(0), y.stride(0), Cw, Cw
+        d.st[i], d.sh[i], d.sw[i] = st
+        d.To[i], d.Ho[i], d.Wo[i] = To, Ho, Wo
+    d.n, d.B, d.Ti, d.Hi, d.Wi, d.heads, d.head_dim = n, B, T, H, W, heads, hd
+    d.kt = d.kh = d.kw = 3
+    d.n_prefix, d.eps, d.dtype = cls, 1e-6, pv_dtype(keep[0])
+    call("pv_token_pool", d)
+    for y, want in zip(outs, wants):
+        assert rel_err(y, want) <= TOL[dtype]
