@@ -164,7 +164,7 @@ def main():
     agg = {}
     for label, kind, ms, alg_bytes, flops in prof:
         label = label.split("|")[0]
-        a = agg.setdefault(label.split(".")[0] if label.startswith("conv_b") else label, [0, 0.0, 0, 0])
+        a = agg.setdefault(label.split(".")[0] if label.startswith(("conv_b", "conv_ab")) else label, [0, 0.0, 0, 0])
         a[0] += 1
         a[1] += ms
         a[2] += alg_bytes

@@ -116,9 +116,20 @@ typedef struct pv_dwconv3d_desc {
   int32_t dtype;
   int32_t n_prefix;          /* rows before the grid in each batch item (the cls    */
                              /* token of layers/attention.py:185-186) copied verbatim */
+  /* Optional fused pointwise producer -- conv_a + norm_a + act_a of an X3D / ir-CSN bottleneck
+   * (models/x3d.py:169-189, models/resnet.py:1345-1352): when pw_w is set, x is the 1x1x1 conv's
+   * INPUT (pw_cin channels, row stride ldx) and the depthwise conv consumes
+   * pw_act(pw_scale * (pw_w . x) + pw_shift) rounded to bf16, evaluated on the fly per halo tile --
+   * the expanded tensor never exists in memory.  Only where pv_dwconv3d_pw_supported(d) is 1. */
+  const void* pw_w;          /* [round_up(C,32)][round_up(pw_cin,32)] bf16, zero padded, or NULL */
+  const float* pw_scale;     /* [C] or NULL */
+  const float* pw_shift;     /* [C] or NULL */
+  int32_t pw_cin, pw_act;
 } pv_dwconv3d_desc;
 int pv_dwconv3d(const pv_dwconv3d_desc* d, pv_stream_t stream);
 int pv_dwconv3d_psum_blocks(const pv_dwconv3d_desc* d);
+/* 1 if this geometry (pointers are ignored) can run with the fused pointwise producer, else 0 */
+int pv_dwconv3d_pw_supported(const pv_dwconv3d_desc* d);
 
 /* ---- MViT attention pooling (fused) ----------------------------------------------------
  * _AttentionPool.forward with pool_mode="conv" (layers/attention.py:162-212, pools built at

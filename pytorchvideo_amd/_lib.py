@@ -39,7 +39,8 @@ DwConv3dDesc = _struct("DwConv3dDesc", [
     ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("psum", _p),
     ("x_bs", _i64), ("y_bs", _i64)]
     + _ints("ldx", "ldy", "B", "Ti", "Hi", "Wi", "C", "To", "Ho", "Wo",
-            "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "w_mod", "act", "dtype", "n_prefix"))
+            "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "w_mod", "act", "dtype", "n_prefix")
+    + [("pw_w", _p), ("pw_scale", _p), ("pw_shift", _p)] + _ints("pw_cin", "pw_act"))
 
 SeGateDesc = _struct("SeGateDesc", [
     ("psum", _p), ("gate", _p), ("w1", _p), ("b1", _p), ("w2", _p), ("b2", _p)]
@@ -94,6 +95,7 @@ _SYMBOLS = [
     ("pv_conv3d", C.c_int, [C.POINTER(Conv3dDesc), _p]),
     ("pv_dwconv3d", C.c_int, [C.POINTER(DwConv3dDesc), _p]),
     ("pv_dwconv3d_psum_blocks", C.c_int, [C.POINTER(DwConv3dDesc)]),
+    ("pv_dwconv3d_pw_supported", C.c_int, [C.POINTER(DwConv3dDesc)]),
     ("pv_se_gate", C.c_int, [C.POINTER(SeGateDesc), _p]),
     ("pv_pool3d", C.c_int, [C.POINTER(Pool3dDesc), _p]),
     ("pv_ingest_ncdhw", C.c_int, [C.POINTER(LayoutDesc), _p]),
@@ -116,7 +118,7 @@ _SYMBOLS = [
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

@@ -11,6 +11,7 @@ scaling and Swish are fused into conv epilogues / prologues as described in DESI
 in place (reference convention: transmuter_mobile_cpu.py:21-22).
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -172,12 +173,66 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
     return y
 
 
+def _pointwise_producer_fields(sess, producer, x, Cc):
+    """Descriptor fields of pv_dwconv3d's fused pointwise producer: `producer` = (conv, norm, act)
+    of the 1x1x1 conv whose output (Cc channels) the depthwise conv consumes."""
+    conv, norm, act = producer
+    if conv.in_channels != x.C:
+        raise RuntimeError("conv expects %d input channels, got %d" % (conv.in_channels, x.C))
+    cin = x.C
+    wp = torch.zeros((Cc + 31) // 32 * 32, (cin + 31) // 32 * 32, dtype=torch.float32)
+    wp[:Cc, :cin] = conv.weight.detach().float().cpu().reshape(Cc, cin)
+    scale, shift = fold_norm(norm, Cc, conv.bias)
+    has_affine = norm is not None and not isinstance(norm, nn.Identity)
+    return dict(pw_w=sess.add_weight(wp.to(sess.dtype)),
+                pw_scale=sess.add_weight(scale) if has_affine else None,
+                pw_shift=sess.add_weight(shift) if (has_affine or conv.bias is not None) else None,
+                pw_cin=cin, pw_act=act)
+
+
+def can_fuse_pointwise_into_dw(sess, conv_a, conv_b, x):
+    """True when conv_a (1x1x1) -> conv_b (depthwise 3x3x3) can run as one pv_dwconv3d launch with
+    the fused pointwise producer (csrc/pv_pwdw.hip); decided by the library from the geometry."""
+    if os.environ.get("PV_FUSE_AB", "1") == "0" or sess.itemsize != 2 or x.f32:
+        return False
+    # Every 32-channel slab of the expanded tensor is a workgroup that reads the whole block input, so
+    # the fusion pays while the input is narrow (X3D res2/res3: measured 1.3-1.8x over the pair of
+    # launches); with >= 96 input channels the slabs' re-reads cost more than the round trip saved.
+    if x.C > int(os.environ.get("PV_FUSE_AB_MAX_CIN", "64")):
+        return False
+    if not isinstance(conv_a, nn.Conv3d) or not isinstance(conv_b, nn.Conv3d):
+        return False
+    if conv_a.kernel_size != (1, 1, 1) or conv_a.stride != (1, 1, 1) or _triple(conv_a.padding) != (0, 0, 0) \
+            or conv_a.groups != 1 or conv_a.in_channels != x.C or conv_a.out_channels != conv_b.in_channels:
+        return False
+    try:
+        if check_conv3d(conv_a) or not check_conv3d(conv_b):
+            return False
+    except Unsupported:
+        return False
+    kt, kh, kw = conv_b.kernel_size
+    st, sh, sw = conv_b.stride
+    pt, ph, pw = _triple(conv_b.padding)
+    d = L.DwConv3dDesc()
+    d.ldx, d.ldy = x.ld, pad8(conv_b.out_channels)
+    d.B, d.Ti, d.Hi, d.Wi, d.C = x.B, x.T, x.H, x.W, conv_b.out_channels
+    d.To, d.Ho, d.Wo = _conv_out(x.T, kt, st, pt), _conv_out(x.H, kh, sh, ph), _conv_out(x.W, kw, sw, pw)
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = kt, kh, kw, st, sh, sw, pt, ph, pw
+    d.dtype, d.pw_cin = sess.pv_dtype, x.C
+    return min(d.To, d.Ho, d.Wo) > 0 and L.lib().pv_dwconv3d_pw_supported(C.byref(d)) == 1
+
+
 def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=None, w_mod=0, label="dwconv",
-                grid=None, n_prefix=0):
+                grid=None, n_prefix=0, producer=None):
     """Depthwise Conv3d (+BN +act [+SE partial sums]) -> pv_dwconv3d.  Returns y or (y, psum, nblk).
     With `grid=(T,H,W)` the input is a token tensor (B, n_prefix + T*H*W, C) convolved on its
-    grid, the n_prefix leading rows (cls token) being copied through (attention.py:185-200)."""
-    if not w_mod:
+    grid, the n_prefix leading rows (cls token) being copied through (attention.py:185-200).
+    With `producer=(conv_a, norm_a, act_a)` x is the INPUT of that 1x1x1 conv, which is evaluated
+    inside the depthwise kernel (only where can_fuse_pointwise_into_dw said so)."""
+    if producer is not None:
+        if not check_conv3d(conv) or w_mod or grid is not None:
+            raise Unsupported("fused producer on a token pooling conv")
+    elif not w_mod:
         if not check_conv3d(conv):
             raise Unsupported("not depthwise")
         if conv.in_channels != x.C:
@@ -191,7 +246,7 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
     To, Ho, Wo = _conv_out(Ti, kt, st, pt), _conv_out(Hi, kh, sh, ph), _conv_out(Wi, kw, sw, pw)
     if min(To, Ho, Wo) <= 0:
         raise RuntimeError("conv output would be empty")
-    Cc = x.C
+    Cc = x.C if producer is None else conv.in_channels
     wc = w_mod if w_mod else Cc
     w = conv.weight.detach().float().cpu().reshape(wc, kt * kh * kw)
     wp = torch.zeros(kt * kh * kw, pad8(wc), dtype=torch.float32)
@@ -214,6 +269,8 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
         kt=kt, kh=kh, kw=kw, st=st, sh=sh, sw=sw, pt=pt, ph=ph, pw=pw,
         w_mod=w_mod, act=act, dtype=sess.pv_dtype, n_prefix=n_prefix,
     )
+    if producer is not None:
+        f.update(_pointwise_producer_fields(sess, producer, x, Cc))
     psum = nblk = None
     if want_psum:
         d = L.DwConv3dDesc()
@@ -226,9 +283,16 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
         psum = sess.alloc_raw(4 * x.B * nblk * pad8(Cc))
         f["psum"] = psum
     vin, vout = x.B * Ti * Hi * Wi, x.B * To * Ho * Wo
-    alg = sess.itemsize * (min(vin, vout * kt * kh * kw) + vout) * pad8(Cc)
-    detail = "|%dx%dx%dx%d c%d k%dx%dx%d s%d%d%d%s" % (x.B, To, Ho, Wo, Cc, kt, kh, kw, st, sh, sw, " psum" if want_psum else "")
-    sess.add_op(L.OP_DWCONV3D, f, label=label + detail, alg_bytes=alg, flops=2 * vout * Cc * kt * kh * kw)
+    flops = 2 * vout * Cc * kt * kh * kw
+    if producer is None:
+        alg = sess.itemsize * (min(vin, vout * kt * kh * kw) + vout) * pad8(Cc)
+        detail = "|%dx%dx%dx%d c%d k%dx%dx%d s%d%d%d%s" % (x.B, To, Ho, Wo, Cc, kt, kh, kw, st, sh, sw, " psum" if want_psum else "")
+    else:   # the block input once, the depthwise output once; conv_a's flops at the input resolution
+        alg = sess.itemsize * (vin * pad8(x.C) + vout * pad8(Cc) + Cc * x.C)
+        flops += 2 * vin * x.C * Cc
+        detail = "|%dx%dx%dx%d c%d->%d k1x1x1+k%dx%dx%d s%d%d%d%s" % (x.B, To, Ho, Wo, x.C, Cc, kt, kh, kw, st, sh, sw,
+                                                                     " psum" if want_psum else "")
+    sess.add_op(L.OP_DWCONV3D, f, label=label + detail, alg_bytes=alg, flops=flops)
     if want_psum:
         return y, psum, nblk
     return y
@@ -334,11 +398,22 @@ def _split_norm_b(norm_b):
     return norm_b, None
 
 
-def emit_conv_b(sess, conv_b, x, norm_b, act_b):
+def emit_conv_b(sess, conv_b, x, norm_b, act_b, producer=None):
     """conv_b + norm_b + act_b of a bottleneck.  Returns (y, gate_ptr_or_None, deferred_act):
-    with squeeze-excitation the activation is deferred to the consumer's load."""
+    with squeeze-excitation the activation is deferred to the consumer's load.  `producer`:
+    conv_a fused into a depthwise conv_b (see emit_dwconv); x is then the block input."""
     bn, se = _split_norm_b(norm_b)
     act = act_code(act_b)
+    if producer is not None:
+        if se is not None:
+            if getattr(se, "is_3d", True) is not True:
+                raise Unsupported("2-D squeeze-excitation")
+            y, psum, nblk = emit_dwconv(sess, conv_b, x, bn, L.ACT_NONE, want_psum=True, label="conv_ab.dw+se",
+                                        producer=producer)
+            gate = emit_se_gate(sess, se, psum, nblk, y.B, y.C, y.voxels)
+            sess.release(psum)
+            return y, gate, act
+        return emit_dwconv(sess, conv_b, x, bn, act, label="conv_ab", producer=producer), None, L.ACT_NONE
     if _cls_name(conv_b) == "Conv2plus1d":
         first, second = (conv_b.conv_xy, conv_b.conv_t) if conv_b.conv_xy_first else (conv_b.conv_t, conv_b.conv_xy)
         if se is not None:
@@ -367,9 +442,14 @@ def emit_bottleneck(sess, bb, x, residual=None, final_act=L.ACT_NONE, out=None):
     for name in ("conv_a", "conv_b", "conv_c"):
         if getattr(bb, name, None) is None:
             raise Unsupported("bottleneck without %s" % name)
-    a = emit_conv(sess, bb.conv_a, x, bb.norm_a, act_code(bb.act_a), label="conv_a")
-    b, gate, deferred = emit_conv_b(sess, bb.conv_b, a, bb.norm_b, bb.act_b)
-    sess.release(a)
+    if can_fuse_pointwise_into_dw(sess, bb.conv_a, bb.conv_b, x):
+        # conv_a -> conv_b in one pass: the expanded tensor is never written (csrc/pv_pwdw.hip)
+        b, gate, deferred = emit_conv_b(sess, bb.conv_b, x, bb.norm_b, bb.act_b,
+                                        producer=(bb.conv_a, bb.norm_a, act_code(bb.act_a)))
+    else:
+        a = emit_conv(sess, bb.conv_a, x, bb.norm_a, act_code(bb.act_a), label="conv_a")
+        b, gate, deferred = emit_conv_b(sess, bb.conv_b, a, bb.norm_b, bb.act_b)
+        sess.release(a)
     check_conv3d(bb.conv_c)
     if (gate is not None or deferred != L.ACT_NONE) and \
             (bb.conv_c.kernel_size != (1, 1, 1) or bb.conv_c.stride != (1, 1, 1) or _triple(bb.conv_c.padding) != (0, 0, 0)):

@@ -507,6 +507,16 @@ int validate(const pv_dwconv3d_desc& d) {
 
 }  // namespace
 
+int pv_plane_variant(const pv_dwconv3d_desc& d) { return plane_variant(d); }
+int pv_plane_tiles(const pv_dwconv3d_desc& d, int nw) { return plane_tiles(d, nw); }
+int pv_pwdw_supported(const pv_dwconv3d_desc& d);           // pv_pwdw.hip
+int pv_pwdw_launch(const pv_dwconv3d_desc& d, hipStream_t s);  // pv_pwdw.hip
+
+extern "C" int pv_dwconv3d_pw_supported(const pv_dwconv3d_desc* d) {
+  if (!d || d->B <= 0 || d->C <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
+  return pv_pwdw_supported(*d);
+}
+
 extern "C" int pv_dwconv3d_psum_blocks(const pv_dwconv3d_desc* d) {
   if (!d) return PV_ERR_INVALID;
   if (d->B <= 0 || d->C <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return PV_ERR_INVALID;
@@ -522,6 +532,7 @@ extern "C" int pv_dwconv3d(const pv_dwconv3d_desc* dp, pv_stream_t stream) {
   const int v = validate(d);
   if (v != PV_OK) return v;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d.pw_w) return pv_pwdw_launch(d, s);   // fused conv_a -> conv_b; no unfused fallback inside the library
   if (const int nw = plane_variant(d)) {
     if (d.sw == 1) return nw == 4 ? launch_plane<1, 4>(d, s) : launch_plane<1, 2>(d, s);
     return nw == 4 ? launch_plane<2, 4>(d, s) : launch_plane<2, 2>(d, s);

@@ -316,6 +316,79 @@ def test_depthwise_3x3x3_plane_kernel_with_se_partial_sums(B, T, H, W, Cc, strid
     assert rel_err(got_mean, pre.mean(dim=[2, 3, 4])) <= 1e-3   # sums are fp32, before the bf16 rounding
 
 
+# ------------------------------------------------------------------ conv_a fused into conv_b (pointwise producer)
+@pytest.mark.parametrize("stride,act", [((1, 1, 1), L.ACT_SWISH), ((1, 2, 2), L.ACT_NONE)])
+@pytest.mark.parametrize("B,T,H,W,Cin,Cc", [
+    (2, 5, 20, 23, 24, 54),     # X3D res2 widths, ragged tiles, one k-step
+    (1, 4, 14, 14, 96, 216),    # res4: three k-steps, seven channel slabs
+    (1, 16, 7, 7, 192, 432),    # res5: narrow tiles (2 outputs per lane), six k-steps
+    (2, 3, 30, 9, 48, 108),     # two k-steps
+    (1, 3, 9, 40, 128, 40),     # four k-steps, output narrower than the input
+])
+def test_pointwise_conv_fused_into_depthwise_3x3x3(B, T, H, W, Cin, Cc, stride, act):
+    """X3D conv_a+norm_a+ReLU -> conv_b+norm_b(+act) in one launch (csrc/pv_pwdw.hip): against torch,
+    and bit-identical to the unfused pv_conv3d -> pv_dwconv3d pair (same bf16 rounding point)."""
+    cp, cinp = (Cc + 7) // 8 * 8, (Cin + 7) // 8 * 8
+    x = torch.zeros(B, T, H, W, cinp, dtype=torch.bfloat16, device="cuda")
+    x[..., :Cin] = _rand((B, T, H, W, Cin), 91, torch.bfloat16)
+    wa = _rand((Cc, Cin), 92, torch.bfloat16, Cin ** -0.5)
+    sa, ha = _rand((Cc,), 93, torch.float32) * 0.2 + 1.0, _rand((Cc,), 94, torch.float32) * 0.5
+    w = _rand((Cc, 1, 3, 3, 3), 95, torch.float32, 0.3)
+    scale, shift = _rand((Cc,), 96, torch.float32) * 0.2 + 1.0, _rand((Cc,), 97, torch.float32)
+    # reference: fp32 math on the bf16 inputs, conv_a output rounded to bf16 like the stored tensor
+    h = torch.einsum("bthwc,oc->bthwo", x[..., :Cin].float(), wa.float()) * sa + ha
+    h = F.relu(h).to(torch.bfloat16).float()
+    pre = F.conv3d(h.permute(0, 4, 1, 2, 3), w, None, stride=stride, padding=1, groups=Cc)
+    pre = pre * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+    want = pre * torch.sigmoid(pre) if act == L.ACT_SWISH else pre
+    To, Ho, Wo = pre.shape[2:]
+    wp = torch.zeros(27, cp, device="cuda")
+    wp[:, :Cc] = w.reshape(Cc, 27).t()
+
+    def dw_desc(src, ld, y, psum):
+        d = L.DwConv3dDesc()
+        d.x, d.w, d.y, d.scale, d.shift = src.data_ptr(), wp.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr()
+        d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * ld, To * Ho * Wo * cp, ld, cp
+        d.B, d.Ti, d.Hi, d.Wi, d.C, d.To, d.Ho, d.Wo = B, T, H, W, Cc, To, Ho, Wo
+        d.kt = d.kh = d.kw = 3
+        d.st, d.sh, d.sw = stride
+        d.pt = d.ph = d.pw = 1
+        d.w_mod, d.act, d.dtype, d.n_prefix = 0, act, L.PV_BF16, 0
+        d.psum = psum.data_ptr()
+        return d
+
+    # fused
+    y = torch.full((B, To, Ho, Wo, cp), 3.0, dtype=torch.bfloat16, device="cuda")
+    wap = torch.zeros((Cc + 31) // 32 * 32, (Cin + 31) // 32 * 32, dtype=torch.bfloat16, device="cuda")
+    wap[:Cc, :Cin] = wa
+    d = dw_desc(x, cinp, y, torch.zeros(1, device="cuda"))
+    d.pw_w, d.pw_scale, d.pw_shift, d.pw_cin, d.pw_act = wap.data_ptr(), sa.data_ptr(), ha.data_ptr(), Cin, L.ACT_RELU
+    assert L.lib().pv_dwconv3d_pw_supported(C.byref(d)) == 1
+    nblk = L.lib().pv_dwconv3d_psum_blocks(C.byref(d))
+    psum = torch.full((B, nblk, cp), float("nan"), device="cuda")
+    d.psum = psum.data_ptr()
+    call("pv_dwconv3d", d)
+    assert rel_err(y[..., :Cc].permute(0, 4, 1, 2, 3), want) <= 1e-2
+    assert torch.all(y[..., Cc:] == 0)
+    assert rel_err(psum.sum(1)[:, :Cc] / (To * Ho * Wo), pre.mean(dim=[2, 3, 4])) <= 2e-3
+
+    # unfused pair through the same library
+    hbuf = torch.zeros(B, T, H, W, cp, dtype=torch.bfloat16, device="cuda")
+    wa8 = torch.zeros(Cc, cinp, dtype=torch.bfloat16, device="cuda")
+    wa8[:, :Cin] = wa
+    c = L.Conv3dDesc()
+    c.x, c.w, c.y, c.scale, c.shift = x.data_ptr(), wa8.data_ptr(), hbuf.data_ptr(), sa.data_ptr(), ha.data_ptr()
+    c.x_bs, c.y_bs, c.ldx, c.ldy = T * H * W * cinp, T * H * W * cp, cinp, cp
+    c.B, c.Ti, c.Hi, c.Wi, c.cin, c.To, c.Ho, c.Wo, c.cout = B, T, H, W, cinp, T, H, W, Cc
+    c.kt = c.kh = c.kw = c.st = c.sh = c.sw = 1
+    c.act, c.a_act, c.dtype = L.ACT_RELU, L.ACT_NONE, L.PV_BF16
+    call("pv_conv3d", c)
+    y2 = torch.full((B, To, Ho, Wo, cp), 5.0, dtype=torch.bfloat16, device="cuda")
+    psum2 = torch.full((B, nblk, cp), float("nan"), device="cuda")
+    call("pv_dwconv3d", dw_desc(hbuf, cp, y2, psum2))
+    assert rel_err(y, y2) <= 2e-3   # same rounding points; MFMA accumulation order may differ in the last bit
+
+
 # ------------------------------------------------------------------ fused q/k/v pooling + LayerNorm (one launch)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("heads,hd,thw,strides,cls", [
