@@ -90,8 +90,17 @@ typedef struct pv_conv3d_desc {
   int32_t dtype;         /* pv_dtype of x, w, residual                           */
   int32_t y_f32;         /* 1: y is fp32 regardless of dtype (logits, residual stream) */
   int32_t r_f32;         /* 1: residual is fp32 regardless of dtype              */
+  /* Optional fused depthwise temporal conv -- the X3D stem (models/x3d.py:66-88: Conv2plus1d with
+   * norm=None, activation=None between conv_xy and the depthwise 5x1x1 conv_t): when dwt_w is set
+   *   y = act(scale * dwt(conv(x)) + shift),  dwt = depthwise conv over T, dwt_k taps, stride 1,
+   *   padding dwt_k/2, taps [dwt_k][round_up(cout,8)] fp32.
+   * Only for the first-layer layout, where pv_conv3d_dwt_supported(d) is 1. */
+  const float* dwt_w;
+  int32_t dwt_k;
 } pv_conv3d_desc;
 int pv_conv3d(const pv_conv3d_desc* d, pv_stream_t stream);
+/* 1 if this geometry (pointers are ignored) can run with the fused temporal conv, else 0 */
+int pv_conv3d_dwt_supported(const pv_conv3d_desc* d);
 
 /* ---- depthwise convolution ---------------------------------------------------------
  * Replaces nn.Conv3d(groups=C) [+ BatchNorm3d eval][+ activation]:

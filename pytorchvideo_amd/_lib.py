@@ -33,7 +33,8 @@ Conv3dDesc = _struct("Conv3dDesc", [
     ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("residual", _p), ("a_gate", _p),
     ("x_bs", _i64), ("y_bs", _i64), ("r_bs", _i64)]
     + _ints("ldx", "ldy", "ldr", "B", "Ti", "Hi", "Wi", "cin", "To", "Ho", "Wo", "cout",
-            "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "act", "a_act", "dtype", "y_f32", "r_f32"))
+            "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "act", "a_act", "dtype", "y_f32", "r_f32")
+    + [("dwt_w", _p)] + _ints("dwt_k"))
 
 DwConv3dDesc = _struct("DwConv3dDesc", [
     ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("psum", _p),
@@ -93,6 +94,7 @@ _SYMBOLS = [
     ("pv_last_error", C.c_char_p, []),
     ("pv_device_count", C.c_int, []),
     ("pv_conv3d", C.c_int, [C.POINTER(Conv3dDesc), _p]),
+    ("pv_conv3d_dwt_supported", C.c_int, [C.POINTER(Conv3dDesc)]),
     ("pv_dwconv3d", C.c_int, [C.POINTER(DwConv3dDesc), _p]),
     ("pv_dwconv3d_psum_blocks", C.c_int, [C.POINTER(DwConv3dDesc)]),
     ("pv_dwconv3d_pw_supported", C.c_int, [C.POINTER(DwConv3dDesc)]),
@@ -118,7 +120,7 @@ _SYMBOLS = [
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 

@@ -106,8 +106,10 @@ def is_add_fusion(fn):
 
 # --------------------------------------------------------------------------- conv family
 def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=None, a_act=L.ACT_NONE,
-              out=None, y_f32=False, label="conv"):
-    """Dense Conv3d (+BN +bias +residual +act) -> pv_conv3d, or depthwise -> pv_dwconv3d."""
+              out=None, y_f32=False, label="conv", dwt=None):
+    """Dense Conv3d (+BN +bias +residual +act) -> pv_conv3d, or depthwise -> pv_dwconv3d.
+    `dwt`: a depthwise temporal Conv3d (k,1,1) applied to the conv's output before norm/act inside the
+    same launch (X3D stem; only where can_fuse_temporal_dw said so)."""
     depthwise = check_conv3d(conv)
     if depthwise:
         if residual is not None or a_gate is not None or a_act != L.ACT_NONE or y_f32:
@@ -142,12 +144,13 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
         wp = torch.zeros(cout, kt * kh * kw, cin_p, dtype=torch.float32)
         wp[:, :, : x.C] = w.permute(0, 2, 3, 4, 1).reshape(cout, kt * kh * kw, x.C)
     wp = wp.to(sess.dtype)
-    scale, shift = fold_norm(norm, cout, conv.bias)
+    bias = conv.bias if dwt is None else dwt.bias
+    scale, shift = fold_norm(norm, cout, bias)
     has_affine = norm is not None and not isinstance(norm, nn.Identity)
     f = dict(
         x=x.ptr, w=sess.add_weight(wp), y=y.ptr,
         scale=sess.add_weight(scale) if has_affine else None,
-        shift=sess.add_weight(shift) if (has_affine or conv.bias is not None) else None,
+        shift=sess.add_weight(shift) if (has_affine or bias is not None) else None,
         residual=residual.ptr if residual is not None else None,
         a_gate=a_gate,
         x_bs=x.bs, y_bs=y.bs, r_bs=residual.bs if residual is not None else 0,
@@ -160,6 +163,11 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
     if residual is not None and ((residual.B, residual.T, residual.H, residual.W) != (y.B, y.T, y.H, y.W)
                                  or residual.C != cout):
         raise RuntimeError("residual geometry mismatch")
+    if dwt is not None:
+        dk = dwt.kernel_size[0]
+        taps_t = torch.zeros(dk, pad8(cout), dtype=torch.float32)
+        taps_t[:, :cout] = dwt.weight.detach().float().cpu().reshape(cout, dk).t()
+        f.update(dwt_w=sess.add_weight(taps_t), dwt_k=dk)
     vox_in, vox_out = x.B * x.voxels, y.B * y.voxels
     taps = kt * kh * kw
     reads = vox_out * cin_p if taps == 1 else vox_in * cin_p  # each input voxel once
@@ -169,6 +177,9 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
     flops = 2 * vox_out * cout * taps * x.C
     detail = "|%dx%dx%dx%d c%d->%d k%dx%dx%d s%d%d%d%s" % (x.B, To, Ho, Wo, x.C, cout, kt, kh, kw, st, sh, sw,
                                                           " gate" if a_gate is not None else "")
+    if dwt is not None:
+        flops += 2 * vox_out * cout * dwt.kernel_size[0]
+        detail += "+k%dx1x1" % dwt.kernel_size[0]
     sess.add_op(L.OP_CONV3D, f, label=label + detail, alg_bytes=alg, flops=flops)
     return y
 
@@ -493,16 +504,51 @@ def emit_res_stage(sess, stage, x, out=None):
     return cur
 
 
+def can_fuse_temporal_dw(sess, first, second, mid_norm, mid_act, x, act):
+    """True when `first` (dense 1 x kh x kw conv on the 4-channel first-layer layout) and `second`
+    (depthwise k x 1 x 1 temporal conv) with nothing in between can run as one pv_conv3d launch
+    (csrc/pv_stem.hip, X3D stem); decided by the library from the geometry."""
+    if os.environ.get("PV_FUSE_STEM", "1") == "0" or x.ld != 4 or sess.itemsize != 2:
+        return False
+    if mid_norm is not None and not isinstance(mid_norm, nn.Identity):
+        return False
+    if mid_act != L.ACT_NONE or not isinstance(first, nn.Conv3d) or not isinstance(second, nn.Conv3d):
+        return False
+    try:
+        if check_conv3d(first) or not check_conv3d(second):
+            return False
+    except Unsupported:
+        return False
+    k = second.kernel_size
+    if first.bias is not None or first.out_channels != second.in_channels or second.in_channels != second.out_channels:
+        return False
+    if k[1:] != (1, 1) or second.stride != (1, 1, 1) or _triple(second.padding) != (k[0] // 2, 0, 0) or k[0] % 2 == 0:
+        return False
+    kt, kh, kw = first.kernel_size
+    st, sh, sw = first.stride
+    pt, ph, pw = _triple(first.padding)
+    d = L.Conv3dDesc()
+    d.ldx, d.cin, d.cout, d.dtype, d.act, d.dwt_k = 4, 4, first.out_channels, sess.pv_dtype, act, k[0]
+    d.B, d.Ti, d.Hi, d.Wi = x.B, x.T, x.H, x.W
+    d.To, d.Ho, d.Wo = _conv_out(x.T, kt, st, pt), _conv_out(x.H, kh, sh, ph), _conv_out(x.W, kw, sw, pw)
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = kt, kh, kw, st, sh, sw, pt, ph, pw
+    return min(d.To, d.Ho, d.Wo) > 0 and L.lib().pv_conv3d_dwt_supported(C.byref(d)) == 1
+
+
 def emit_stem(sess, stem, x, out=None):
     """ResNetBasicStem.forward (stem.py:252-260); conv may be Conv3d or X3D's Conv2plus1d."""
     act = act_code(stem.activation)
     conv = stem.conv
     if _cls_name(conv) == "Conv2plus1d":
         first, second = (conv.conv_xy, conv.conv_t) if conv.conv_xy_first else (conv.conv_t, conv.conv_xy)
-        mid = emit_conv(sess, first, x, conv.norm, act_code(conv.activation), label="stem.conv0")
-        y = emit_conv(sess, second, mid, stem.norm, act, out=out if stem.pool is None else None,
-                      label="stem.conv1")
-        sess.release(mid)
+        if can_fuse_temporal_dw(sess, first, second, conv.norm, act_code(conv.activation), x, act):
+            y = emit_conv(sess, first, x, stem.norm, act, out=out if stem.pool is None else None,
+                          label="stem.conv01", dwt=second)
+        else:
+            mid = emit_conv(sess, first, x, conv.norm, act_code(conv.activation), label="stem.conv0")
+            y = emit_conv(sess, second, mid, stem.norm, act, out=out if stem.pool is None else None,
+                          label="stem.conv1")
+            sess.release(mid)
     else:
         y = emit_conv(sess, conv, x, stem.norm, act, out=out if stem.pool is None else None, label="stem.conv")
     if stem.pool is not None:

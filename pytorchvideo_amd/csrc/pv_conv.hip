@@ -20,6 +20,7 @@
 int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s);      // pv_pwconv.hip
 int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);  // pv_gemm.hip
 int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s);                 // pv_stem.hip
+int pv_stem_dwt_supported(const pv_conv3d_desc& d);                     // pv_stem.hip
 
 namespace {
 
@@ -325,6 +326,11 @@ template <typename T> int launch_conv(const pv_conv3d_desc& d, bool pw, hipStrea
 
 }  // namespace
 
+extern "C" int pv_conv3d_dwt_supported(const pv_conv3d_desc* d) {
+  if (!d || d->B <= 0 || d->cout <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
+  return pv_stem_dwt_supported(*d);
+}
+
 extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
   if (!dp) return PV_ERR_INVALID;
   const pv_conv3d_desc& d = *dp;
@@ -345,6 +351,7 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
   if ((d.a_gate || d.a_act != PV_ACT_NONE) && !pw) return PV_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (c4) return pv_stem_c4(d, s);
+  if (d.dwt_w) return PV_ERR_UNSUPPORTED;   // the fused temporal conv exists for the first-layer layout only
   if (d.dtype == PV_BF16) {
     // PV_CONV_ROUTE (experiments): 1 = prefer the streaming kernel, 2 = prefer the LDS-DMA GEMM, 3 = generic only
     static const int route = getenv("PV_CONV_ROUTE") ? atoi(getenv("PV_CONV_ROUTE")) : 0;

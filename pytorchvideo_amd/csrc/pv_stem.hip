@@ -177,7 +177,216 @@ template <int NT, int TM> int launch_stem(const pv_conv3d_desc& d, int ksteps, h
   return PV_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// X3D stem in one pass: conv_xy (1 x kh x kw from the 4-channel input, MFMA) followed, with nothing in
+// between (models/x3d.py:66-88: Conv2plus1d(norm=None, activation=None)), by the depthwise temporal
+// conv_t (DK x 1 x 1, stride 1, padding DK/2) + folded BN + activation.  A lane owns its voxels for
+// the whole clip: it walks the T axis, evaluates one frame of conv_xy per step and scatters it into a
+// register ring of DK partial output frames (frame t feeds outputs t-DK/2 .. t+DK/2), so the
+// 24-channel intermediate -- 2x the bytes of the RGB input -- never exists in memory and the temporal
+// conv needs no halo, no LDS and no second launch.  The ring index is a compile-time constant (the T
+// loop is unrolled DK-fold), so "rotating" the ring costs no moves.
+template <int V> struct IntC { static constexpr int value = V; };
+
+template <int NT, int TM, int KS, int DK, int ACT>
+__global__ __launch_bounds__(kThreads) void stem_c4_dwt_kernel(const pv_conv3d_desc d, int groups_per_clip) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int Kp = KS * 32;
+  constexpr int WLD = Kp + 8;
+  constexpr int HALF = DK / 2;
+  bf16_t* w_s = reinterpret_cast<bf16_t*>(smem_raw);
+  int* tab_s = reinterpret_cast<int*>(smem_raw + (size_t)NT * 16 * WLD * 2);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int n16 = lane & 15, q = lane >> 4;
+  const int KWP = (d.kw + 1) & ~1;
+  const int PPR = KWP / 2;
+  const int K = d.kh * KWP * 4;
+  const int S_sp = d.Ho * d.Wo;
+  const int cout_p8 = pv_round_up(d.cout, 8);
+  const int b = blockIdx.x / groups_per_clip, g = blockIdx.x - b * groups_per_clip;
+
+  {
+    const bf16_t* __restrict__ Wt = static_cast<const bf16_t*>(d.w);
+    constexpr int cpr = Kp / 8;
+    for (int id = tid; id < NT * 16 * cpr; id += kThreads) {
+      const int r = id / cpr, kc = id - r * cpr;
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (r < d.cout && kc * 8 < K) v = *reinterpret_cast<const bf16x8*>(Wt + (long)r * K + kc * 8);
+      *reinterpret_cast<bf16x8*>(w_s + r * WLD + kc * 8) = v;
+    }
+    for (int pi = tid; pi < KS * 4; pi += kThreads) {
+      const int dh = pi / PPR, pv = pi - dh * PPR;
+      tab_s[pi] = dh < d.kh ? ((dh << 8) | ((2 * pv) << 16)) : -1;
+    }
+  }
+  __syncthreads();
+
+  constexpr unsigned kOOB = 0x80000000u;
+  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(d.x), 0, (int)((unsigned)d.B * (unsigned)d.x_bs * 2u), 0x00020000);
+  __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      d.y, 0, (int)((unsigned)d.B * (unsigned)d.y_bs * 2u), 0x00020000);
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+  // ---- this lane's voxels (fixed for the whole clip) and their load / store offsets inside a frame ----
+  unsigned xo[TM][KS][2];   // byte offset of the two 8-byte halves of each k-step's fragment, or kOOB
+  unsigned yo[TM];          // byte offset of (voxel, channel 4q) inside an output frame, or kOOB
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int sp = ((g * 4 + wave) * TM + t) * 16 + n16;
+    const bool vok = sp < S_sp;
+    const int ho = sp / d.Wo, wo = sp - ho * d.Wo;
+    const int h0 = ho * d.sh - d.ph, w0 = wo * d.sw - d.pw;
+    yo[t] = vok ? (unsigned)(sp * d.ldy + q * 4) * 2u : kOOB;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int tp = tab_s[ks * 4 + q];
+      const int dh = (tp >> 8) & 255, dw = tp >> 16;
+      const int hi = h0 + dh, wi = w0 + dw;
+      const bool rok = vok && tp >= 0 && (unsigned)hi < (unsigned)d.Hi;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bool ok = rok && (unsigned)(wi + e) < (unsigned)d.Wi && dw + e < d.kw;
+        xo[t][ks][e] = ok ? (unsigned)((hi * d.Wi + wi + e) * 4) * 2u : kOOB;
+      }
+    }
+  }
+  const unsigned x_frame = (unsigned)(d.Hi * d.Wi * 4) * 2u, y_frame = (unsigned)(S_sp * d.ldy) * 2u;
+  const unsigned x_clip = (unsigned)b * (unsigned)d.x_bs * 2u, y_clip = (unsigned)b * (unsigned)d.y_bs * 2u;
+
+  // ---- temporal taps, folded BN: channels a*16 + 4q .. +3 ----
+  f32x4 wt[DK][NT], sc[NT], sh[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = a * 16 + q * 4 + j;
+      const bool ok = c < d.cout;
+      sc[a][j] = ok ? (d.scale ? d.scale[c] : 1.f) : 0.f;
+      sh[a][j] = ok ? (d.shift ? d.shift[c] : 0.f) : 0.f;
+#pragma unroll
+      for (int k = 0; k < DK; ++k) wt[k][a][j] = ok ? d.dwt_w[k * cout_p8 + c] : 0.f;
+    }
+
+  u32x2 xr[TM][KS][2];
+  auto load_frame = [&](int t) {
+    const unsigned fb = x_clip + (unsigned)t * x_frame;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          xr[i][ks][e] = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)(xo[i][ks][e] + fb), 0, 0);   // kOOB + fb stays out of range
+  };
+
+  f32x4 ring[DK][NT][TM];
+#pragma unroll
+  for (int k = 0; k < DK; ++k)
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ring[k][a][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto step = [&](auto Rc, int t) {
+    constexpr int R = decltype(Rc)::value;   // t mod DK
+    if (t < d.Ti) {
+      f32x4 h[NT][TM];
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) h[a][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w_s + (a * 16 + n16) * WLD + ks * 32 + q * 8);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const u32x4 u = {xr[i][ks][0][0], xr[i][ks][0][1], xr[i][ks][1][0], xr[i][ks][1][1]};
+            h[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, u), h[a][i], 0, 0, 0);
+          }
+        }
+      if (t + 1 < d.Ti) load_frame(t + 1);   // next frame's loads fly under this frame's FMAs and stores
+      // frame t feeds output t + HALF - k with tap k
+#pragma unroll
+      for (int k = 0; k < DK; ++k) {
+        const int slot = (R + HALF - k + DK) % DK;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) ring[slot][a][i] += wt[k][a] * h[a][i];
+      }
+    }
+    // output t - HALF is complete after frame t; its ring slot is recycled for output t + HALF + 1
+    // (also for the "outputs" before the first frame, which only exist as garbage in the ring)
+    const int to = t - HALF;
+    constexpr int slot = (R - HALF + DK) % DK;
+    if (to >= 0 && to < d.To) {
+      const unsigned fb = y_clip + (unsigned)to * y_frame;
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const bool cok = a * 16 + q * 4 < cout_p8;   // padding channels up to the 8-multiple are written as zeros
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          f32x4 v = ring[slot][a][i] * sc[a] + sh[a];
+          if (ACT == PV_ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          const unsigned off = cok ? yo[i] + a * 32u + fb : kOOB;   // kOOB + anything stays out of range
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, (int)off, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ring[slot][a][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  load_frame(0);
+  for (int t0 = 0; t0 < d.Ti + HALF; t0 += DK) {
+    step(IntC<0>{}, t0);
+    step(IntC<1>{}, t0 + 1);
+    step(IntC<2>{}, t0 + 2);
+    if (DK > 3) {
+      step(IntC<3 % DK>{}, t0 + 3);
+      step(IntC<4 % DK>{}, t0 + 4);
+    }
+  }
+}
+
+template <int NT, int TM, int KS, int DK> int launch_stem_dwt(const pv_conv3d_desc& d, hipStream_t s) {
+  const long S_sp = (long)d.Ho * d.Wo;
+  const long gpc = pv_ceil_div(S_sp, 4 * TM * 16);
+  if (gpc * d.B > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)NT * 16 * (KS * 32 + 8) * 2 + (size_t)KS * 4 * 4;
+  dim3 grid((unsigned)(gpc * d.B)), block(kThreads);
+  if (d.act == PV_ACT_RELU) hipLaunchKernelGGL((stem_c4_dwt_kernel<NT, TM, KS, DK, PV_ACT_RELU>), grid, block, lds, s, d, (int)gpc);
+  else hipLaunchKernelGGL((stem_c4_dwt_kernel<NT, TM, KS, DK, PV_ACT_NONE>), grid, block, lds, s, d, (int)gpc);
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
 }  // namespace
+
+// geometry test for the fused temporal conv: first-layer 1 x kh x kw conv whose K fits two MFMA steps
+// (3x3 taps), at most 32 output channels, 3 or 5 temporal taps
+int pv_stem_dwt_supported(const pv_conv3d_desc& d) {
+  if (d.dtype != PV_BF16 || d.cin != 4 || d.ldx != 4 || d.y_f32) return 0;
+  if (d.kt != 1 || d.st != 1 || d.pt != 0 || d.To != d.Ti) return 0;
+  if (d.dwt_k != 3 && d.dwt_k != 5) return 0;
+  if (d.act != PV_ACT_NONE && d.act != PV_ACT_RELU) return 0;
+  if (d.cout > 32 || d.kh * ((d.kw + 1) & ~1) * 4 > 64 || d.kh > 255 || d.kw > 255) return 0;
+  return 1;
+}
 
 // pv_conv3d with cin == 4 (see include/pv_mi355x.h): bf16 input with 4 channels per voxel, weights
 // packed [cout][kt][kh][round_up(kw,2)][4].
@@ -189,6 +398,11 @@ int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s) {
   const int KWP = (d.kw + 1) & ~1;
   const int K = d.kt * d.kh * KWP * 4;
   const int ksteps = (K + 31) / 32;
+  if (d.dwt_w) {   // fused depthwise temporal conv (X3D stem)
+    if (!pv_stem_dwt_supported(d)) return PV_ERR_UNSUPPORTED;
+    if ((long)d.B * d.y_bs > 0x3fffffffL) return PV_ERR_UNSUPPORTED;
+    return d.dwt_k == 5 ? launch_stem_dwt<2, 2, 2, 5>(d, s) : launch_stem_dwt<2, 2, 2, 3>(d, s);
+  }
   if (ksteps * 4 > kMaxPairs || d.kt > 255 || d.kh > 255 || d.kw > 255) return PV_ERR_UNSUPPORTED;
   const int cout_p8 = pv_round_up(d.cout, 8);
   if (cout_p8 <= 16) return launch_stem<1, 4>(d, ksteps, s);

@@ -267,6 +267,46 @@ def test_first_layer_conv_on_c4_layout(B, T, H, W, cout, k, s, p, f32out):
     assert torch.all(y[..., cout:] == 0)
 
 
+@pytest.mark.parametrize("B,T,H,W,cout,dk,act", [
+    (2, 16, 30, 34, 24, 5, L.ACT_RELU),   # X3D stem: 1x3x3 s(1,2,2) 3->24, then depthwise 5x1x1, BN, ReLU
+    (1, 4, 18, 22, 24, 5, L.ACT_RELU),    # clip shorter than one unrolled ring turn
+    (3, 7, 9, 70, 20, 3, L.ACT_NONE),     # 3 temporal taps, T not a multiple of anything, ragged voxel tiles
+])
+def test_x3d_stem_conv_xy_and_temporal_depthwise_in_one_launch(B, T, H, W, cout, dk, act):
+    """models/x3d.py:66-88: Conv2plus1d(conv_xy -> conv_t depthwise, nothing in between) + norm + act."""
+    x = _rand((B, 3, T, H, W), 71, torch.bfloat16)
+    w = _rand((cout, 3, 1, 3, 3), 72, torch.bfloat16, 27 ** -0.5)
+    wt = _rand((cout, 1, dk, 1, 1), 73, torch.float32, 0.5)
+    scale, shift = _rand((cout,), 74, torch.float32) * 0.2 + 1.0, _rand((cout,), 75, torch.float32) * 0.5
+    h = F.conv3d(x.float(), w.float(), None, stride=(1, 2, 2), padding=(0, 1, 1))
+    pre = F.conv3d(h, wt, None, padding=(dk // 2, 0, 0), groups=cout)
+    pre = pre * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+    want = F.relu(pre) if act == L.ACT_RELU else pre
+    To, Ho, Wo = want.shape[2:]
+    x4 = torch.zeros(B, T, H, W, 4, dtype=torch.bfloat16, device="cuda")
+    x4[..., :3] = x.permute(0, 2, 3, 4, 1)
+    wp = torch.zeros(cout, 1, 3, 4, 4, dtype=torch.bfloat16, device="cuda")
+    wp[:, :, :, :3, :3] = w.permute(0, 2, 3, 4, 1)
+    cp = (cout + 7) // 8 * 8
+    taps = torch.zeros(dk, cp, device="cuda")
+    taps[:, :cout] = wt.reshape(cout, dk).t()
+    y = torch.full((B, To, Ho, Wo, cp), 5.0, dtype=torch.bfloat16, device="cuda")
+    d = L.Conv3dDesc()
+    d.x, d.w, d.y, d.scale, d.shift = x4.data_ptr(), wp.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr()
+    d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * 4, To * Ho * Wo * cp, 4, cp
+    d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, 4, To, Ho, Wo, cout
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = 1, 3, 3, 1, 2, 2, 0, 1, 1
+    d.act, d.a_act, d.dtype = act, L.ACT_NONE, L.PV_BF16
+    d.dwt_w, d.dwt_k = taps.data_ptr(), dk
+    assert L.lib().pv_conv3d_dwt_supported(C.byref(d)) == 1
+    call("pv_conv3d", d)
+    assert rel_err(y[..., :cout].permute(0, 4, 1, 2, 3), want) <= 1e-2
+    assert torch.all(y[..., cout:] == 0)
+    # the fusion exists for the first-layer layout only: a wide input must be refused, not mis-computed
+    d.cin, d.ldx = 8, 8
+    assert L.lib().pv_conv3d_dwt_supported(C.byref(d)) == 0
+
+
 @pytest.mark.parametrize("rows,Cc", [(1000, 96), (333, 192), (77, 384), (50, 768), (9, 1000)])
 def test_layernorm_fp32_stream_to_bf16_operand(rows, Cc):
     """The bf16 MViT plan normalises its fp32 residual stream into the bf16 GEMM operand."""
