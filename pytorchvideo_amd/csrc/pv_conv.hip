@@ -356,10 +356,12 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
     // PV_CONV_ROUTE (experiments): 1 = prefer the streaming kernel, 2 = prefer the LDS-DMA GEMM, 3 = generic only
     static const int route = getenv("PV_CONV_ROUTE") ? atoi(getenv("PV_CONV_ROUTE")) : 0;
     const int cout_p8 = pv_round_up(d.cout, 8);
-    // HBM-bound widths (X3D): streaming kernel; everything else: LDS-DMA MFMA GEMM
-    // arithmetic intensity of the layer as its own op, K*N/(K+N) FLOP/B (bf16): well below the ridge
-    // (312) the layer is a streaming problem -> streaming kernel; near or above it -> MFMA GEMM
-    const bool small = d.cin <= 64 || cout_p8 <= 64 || ((long)d.cin * cout_p8 < 170L * (d.cin + cout_p8));
+    // Pointwise layers with a short reduction (X3D widths, SlowFast's fast pathway, MViT's first block)
+    // are streaming problems: weights resident in LDS, activations straight into MFMA operands.
+    // From ~192 input channels on the LDS-DMA GEMM wins on every measured shape, narrow outputs included
+    // (profiles/r1: route sweeps on MViT-B and SlowFast-R50).  PV_CONV_SMALL_CIN overrides the threshold.
+    static const int small_cin = getenv("PV_CONV_SMALL_CIN") ? atoi(getenv("PV_CONV_SMALL_CIN")) : 128;
+    const bool small = d.cin <= small_cin;
     if (route != 3) {
       if (pw && (route == 1 || (route == 0 && small))) {
         const int r = pv_pwconv_stream_try(d, s);
@@ -368,7 +370,7 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
       // the 128-channel LDS-DMA tile wastes the matrix core on narrow outputs, and per-chunk tap
       // decoding dominates when a tap is only 8 channels wide (RGB stems): those stay on the
       // generic register-staged kernel
-      const bool gemm_ok = route == 2 || (cout_p8 > 64 && (pw || d.cin >= 32));
+      const bool gemm_ok = route == 2 || pw || (cout_p8 >= 64 && d.cin >= 64);
       int r = gemm_ok ? pv_gemm_glds_try(d, pw, s) : PV_ERR_UNSUPPORTED;
       if (r != PV_ERR_UNSUPPORTED) return r;
       if (pw) {

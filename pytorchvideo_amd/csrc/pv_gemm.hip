@@ -115,13 +115,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
       gg.w_off[j] = n < d.cout ? (long)n * K : -1;
       const long m = gg.m0 + row;
       if (m < M) {
-        const long b = m / S_out;
+        // M < 2^31 (host check): 32-bit divisions, an order of magnitude cheaper than the 64-bit sequence
+        const long b = (long)((unsigned)m / (unsigned)S_out);
         const long sp = m - b * S_out;
         if constexpr (PW) {
           gg.x_off[j] = b * d.x_bs + sp * d.ldx;
           gg.x_t[j] = gg.x_h[j] = gg.x_w[j] = 0;
         } else {
-          const int to = (int)(sp / (d.Ho * d.Wo));
+          const int to = (int)((unsigned)sp / (unsigned)(d.Ho * d.Wo));
           const int r2 = (int)(sp - (long)to * d.Ho * d.Wo);
           const int ho = r2 / d.Wo;
           gg.x_off[j] = b * d.x_bs;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
       const long m = cur.m0 + wm * 64 + v * 32 + l31;
       e_ok[v] = m < M;
       const long mm = e_ok[v] ? m : 0;
-      e_b[v] = mm / S_out;
+      e_b[v] = (long)((unsigned)mm / (unsigned)S_out);
       e_sp[v] = mm - e_b[v] * S_out;
     }
     // finish the accumulators in place, one channel tile at a time (scale/shift and residual loads of
@@ -280,25 +281,67 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
             }
           }
       }
-      float sc[16], sh[16];
+      // Every choice below (scale or bias only, residual kind, activation, ragged last channel tile) is
+      // wave-uniform and decided once per tile around straight-line 16-element loops -- the epilogue is
+      // a fixed cost per tile that rivals the MFMA time of the short-K (K = 192 / 384) MViT layers.
+      // (scale pass, then shift pass: one 16-register table live at a time)
+      if (d.scale != nullptr) {
+        float sc[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok = cb + r < d.cout;
-        sc[r] = ok ? (d.scale ? d.scale[cb + r] : 1.f) : 0.f;
-        sh[r] = ok ? (d.shift ? d.shift[cb + r] : 0.f) : 0.f;
+        for (int r = 0; r < 16; ++r) sc[r] = cb + r < d.cout ? d.scale[cb + r] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] *= sc[r];
       }
+      if (d.shift != nullptr) {
+        float sh[16];
 #pragma unroll
-      for (int v = 0; v < 2; ++v) {
+        for (int r = 0; r < 16; ++r) sh[r] = cb + r < d.cout ? d.shift[cb + r] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float o = acc[a][v][r] * sc[r] + sh[r];
-          if (d.residual != nullptr) {
-            if (d.r_f32) o += res[v][r >> 3][(r >> 2) & 1][r & 3];
-            else o += (float)__builtin_bit_cast(bf16x8, res[v][r >> 3][0])[r & 7];
-          }
-          o = pv_apply_act(o, d.act);
-          acc[a][v][r] = cb + r < d.cout ? o : 0.f;
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] += sh[r];
+      }
+      if (d.residual != nullptr) {
+        if (d.r_f32) {
+#pragma unroll
+          for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][v][r] += res[v][r >> 3][(r >> 2) & 1][r & 3];
+        } else {
+#pragma unroll
+          for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][v][r] += (float)__builtin_bit_cast(bf16x8, res[v][r >> 3][0])[r & 7];
         }
+      }
+      if (d.act == PV_ACT_RELU) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] = fmaxf(acc[a][v][r], 0.f);
+      } else if (d.act == PV_ACT_GELU) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] = pv_gelu_fast(acc[a][v][r]);
+      } else if (d.act == PV_ACT_SWISH) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] *= pv_sigmoid(acc[a][v][r]);
+      } else if (d.act == PV_ACT_SIGMOID) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] = pv_sigmoid(acc[a][v][r]);
+      }
+      if (cb + 16 > d.cout) {   // ragged last channel tile: the padding up to the 8-multiple is written as zeros
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] = cb + r < d.cout ? acc[a][v][r] : 0.f;
       }
     }
     // ... then nothing but stores
@@ -347,7 +390,7 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   const long tiles_m = pv_ceil_div(M, BM);
   const int tiles_n = (int)pv_ceil_div(cout_p8, BN);
   const long total = tiles_m * tiles_n;
-  if (total <= 0 || total > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
+  if (total <= 0 || total > 0x7fffffffL || M > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
   if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return PV_ERR_UNSUPPORTED;   // 31-bit buffer offsets
   const float inv_cin = 1.0f / (float)d.cin;
   // two persistent workgroups per CU (64 KB of LDS each), in multiples of the 8 XCDs

@@ -31,7 +31,7 @@ struct PwRows {  // per-lane geometry of one wave tile group: clip index and vox
 };
 
 template <int NT, int TM, bool XFORM, int KS, bool F32>
-__global__ __launch_bounds__(kThreads, 4) void pw_stream_kernel(const pv_conv3d_desc d, int ksteps_rt, int ngroups,
+__global__ __launch_bounds__(kThreads, (KS >= 4 && NT >= 4) ? 3 : 4) void pw_stream_kernel(const pv_conv3d_desc d, int ksteps_rt, int ngroups,
                                                                 int nchunks, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ksteps = KS > 0 ? KS : ksteps_rt;
@@ -151,13 +151,17 @@ __global__ __launch_bounds__(kThreads, 4) void pw_stream_kernel(const pv_conv3d_
       }
     }
   };
+  // The filter fragments are loop-invariant across voxel groups; hoisting all NT x KS of them out of the
+  // group loop (what LICM would do) costs more registers than the kernel has, so the LDS offset is made
+  // opaque once per group and the reads stay where they are used.
+  int w_opaque = 0;
   auto mma = [&](f32x4 (&acc)[NT][TM], const bf16x8 (&src)[KSR][TM], int ks0) {
 #pragma unroll
     for (int kk = 0; kk < KSR; ++kk) {
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
         if ((a >> 1) < live_pairs) {
-          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w_s + (a * 16 + n16) * WLD + (ks0 + kk) * 32 + q * 8);
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w_s + w_opaque + (a * 16 + n16) * WLD + (ks0 + kk) * 32 + q * 8);
 #pragma unroll
           for (int t = 0; t < TM; ++t)
             acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, src[kk][t], acc[a][t], 0, 0, 0);
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(kThreads, 4) void pw_stream_kernel(const pv_conv3d_
       for (int t = 0; t < TM; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     refresh_gate(g);
     rows_of(g + nchunks, nxt);
+    asm volatile("" : "+v"(w_opaque));
     if constexpr (KS > 0) {
       if (XFORM) xform(xf, cur, 0);
       mma(acc, xf, 0);
@@ -297,7 +302,7 @@ int launch_pw_x(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) 
   if constexpr (NT <= 4) {
     if (ksteps == 3) return launch_pw_k<NT, TM, XFORM, 3>(d, ksteps, lds, s);
   }
-  if constexpr (NT <= 2) {
+  if constexpr (NT <= 4) {
     if (ksteps == 4) return launch_pw_k<NT, TM, XFORM, 4>(d, ksteps, lds, s);
   }
   return launch_pw_k<NT, TM, XFORM, 0>(d, ksteps, lds, s);

@@ -35,6 +35,13 @@ SHAPES = [  # (label, B, T,H,W in, cin, cout, k(t,h,w), s(t,h,w), p)
     ("x3d stem 1x3x3 3->24", 32, 16, 224, 224, 8, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     ("x3d conv_a s5 192->432", 32, 16, 7, 7, 192, 432, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("x3d conv_c s4 216->96", 32, 16, 14, 14, 216, 96, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("nsweep M401k K192 N384", 8, 1, 1, 50177, 192, 384, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("nsweep M401k K192 N512", 8, 1, 1, 50177, 192, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("nsweep M401k K192 N576", 8, 1, 1, 50177, 192, 576, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("nsweep M401k K192 N640", 8, 1, 1, 50177, 192, 640, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("nsweep M401k K192 N768", 8, 1, 1, 50177, 192, 768, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("nsweep M200k K192 N576", 4, 1, 1, 50177, 192, 576, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("nsweep M100k K192 N576", 8, 1, 1, 12545, 192, 576, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
 ]
 
 
