@@ -87,6 +87,25 @@ __device__ __forceinline__ float pv_gelu_fast(float x) {
   return h + fabsf(h) * (1.0f - poly * e);
 }
 
+// Activation of a small register array with ONE wave-uniform branch around straight-line loops (a
+// per-element switch on a runtime act code makes the compiler emit a branch tree per element).
+// FAST: bf16 kernels may use the cheap GELU; fp32 kernels keep erff.
+template <bool FAST, int N> __device__ __forceinline__ void pv_apply_act_n(float (&v)[N], int act) {
+  if (act == PV_ACT_RELU) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = fmaxf(v[j], 0.0f);
+  } else if (act == PV_ACT_SWISH) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] *= pv_sigmoid(v[j]);
+  } else if (act == PV_ACT_GELU) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = FAST ? pv_gelu_fast(v[j]) : 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752440f));
+  } else if (act == PV_ACT_SIGMOID) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = pv_sigmoid(v[j]);
+  }
+}
+
 __host__ __device__ __forceinline__ int pv_round_up(int v, int m) { return (v + m - 1) / m * m; }
 __host__ __device__ __forceinline__ long pv_ceil_div(long a, long b) { return (a + b - 1) / b; }
 

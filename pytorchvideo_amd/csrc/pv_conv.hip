@@ -177,8 +177,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const pv_conv3d_de
           f[0] *= g0.x; f[1] *= g0.y; f[2] *= g0.z; f[3] *= g0.w;
           f[4] *= g1.x; f[5] *= g1.y; f[6] *= g1.z; f[7] *= g1.w;
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = pv_apply_act(f[j], d.a_act);
+        pv_apply_act_n<sizeof(T) == 2>(f, d.a_act);
         xr[i].from_f32(f);
       }
       xr[i].store(xs + r * LD + kc * 8);
@@ -285,11 +284,10 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const pv_conv3d_de
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += rf[j];
       }
+      pv_apply_act_n<sizeof(T) == 2>(v, d.act);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[j] = pv_apply_act(v[j], d.act);
+      for (int j = 0; j < 8; ++j)
         if (c0 + j >= d.cout) v[j] = 0.0f;
-      }
       const long yo = (long)b * d.y_bs + sp * d.ldy + c0;
       if (d.y_f32) {
         Chunk8<float> oc;

@@ -139,9 +139,11 @@ __global__ __launch_bounds__(kThreads) void dwconv_kernel(const pv_dwconv3d_desc
       for (int j = 0; j < 8; ++j) {
         v[j] = acc[n][j] * sc[j] + sh[j];
         ps[j] += v[j];
-        v[j] = pv_apply_act(v[j], d.act);
-        if (c0 + j >= d.C) v[j] = 0.f;
       }
+      pv_apply_act_n<sizeof(T) == 2>(v, d.act);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (c0 + j >= d.C) v[j] = 0.f;
       Chunk8<T> o;
       o.from_f32(v);
       o.store(Y + ((long)(to * d.Ho + ho) * d.Wo + wo) * d.ldy);

@@ -146,8 +146,9 @@ __global__ __launch_bounds__(kThreads, (KS >= 4 && NT >= 4) ? 3 : 4) void pw_str
 #pragma unroll
           for (int j = 0; j < 4; ++j) { f[j] *= g0[j]; f[4 + j] *= g1[j]; }
         }
+        pv_apply_act_n<true>(f, d.a_act);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) src[kk][t][j] = (bf16_t)pv_apply_act(f[j], d.a_act);
+        for (int j = 0; j < 8; ++j) src[kk][t][j] = (bf16_t)f[j];
       }
     }
   };
@@ -243,10 +244,11 @@ __global__ __launch_bounds__(kThreads, (KS >= 4 && NT >= 4) ? 3 : 4) void pw_str
             for (int j = 0; j < 8; ++j) v[j] += (float)rb[j];
           }
         }
+        pv_apply_act_n<true>(v, d.act);
+        if (c0 + 8 > d.cout) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          v[j] = pv_apply_act(v[j], d.act);
-          if (c0 + j >= d.cout) v[j] = 0.f;
+          for (int j = 0; j < 8; ++j)
+            if (c0 + j >= d.cout) v[j] = 0.f;
         }
         const long yo = (long)cur.b[t] * d.y_bs + (long)cur.sp[t] * d.ldy + c0;
         if constexpr (F32) {

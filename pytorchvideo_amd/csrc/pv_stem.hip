@@ -146,10 +146,11 @@ __global__ __launch_bounds__(kThreads) void stem_c4_kernel(const pv_conv3d_desc 
         if (!vok[t]) continue;
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = pv_apply_act(acc[a][t][j] * sc[j] + sh[j], d.act);
+        for (int j = 0; j < 4; ++j) v[j] = acc[a][t][j] * sc[j] + sh[j];
+        pv_apply_act_n<true>(v, d.act);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
           if (c0 + j >= d.cout) v[j] = 0.f;
-        }
         if (d.y_f32) {
           *reinterpret_cast<f32x4*>(static_cast<float*>(d.y) + vy[t] + c0) = f32x4{v[0], v[1], v[2], v[3]};
         } else {
