@@ -567,7 +567,10 @@ template <typename T> static int pool_launch(const pv_pool3d_desc& d, hipStream_
   const int taps = d.kt * d.kh * d.kw;
   const long nvox = (long)d.B * d.To * d.Ho * d.Wo;
   if (taps >= 64) {
-    const int cgb = CG < kThreads ? CG : kThreads;
+    // 8 chunks (128 contiguous bytes of a voxel) per block, the window split 32 ways: the head pools
+    // (16x7x7 over 432 channels, 8x7x7 over 2048) have only B..4B output voxels, so the parallelism has
+    // to come from the channel slabs and the taps
+    const int cgb = CG < 8 ? CG : 8;
     if (nvox > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
     dim3 grid((unsigned)nvox, (unsigned)pv_ceil_div(CG, cgb));
     hipLaunchKernelGGL(pool_reduce_kernel<T>, grid, dim3(kThreads), 0, s, d, cgb);

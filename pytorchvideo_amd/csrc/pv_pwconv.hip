@@ -31,7 +31,7 @@ struct PwRows {  // per-lane geometry of one wave tile group: clip index and vox
 };
 
 template <int NT, int TM, bool XFORM, int KS, bool F32>
-__global__ __launch_bounds__(kThreads, (KS >= 4 && NT >= 4) ? 3 : 4) void pw_stream_kernel(const pv_conv3d_desc d, int ksteps_rt, int ngroups,
+__global__ __launch_bounds__(kThreads, KS >= 14 ? 2 : ((NT >= 4 || KS >= 4) ? 3 : 4)) void pw_stream_kernel(const pv_conv3d_desc d, int ksteps_rt, int ngroups,
                                                                 int nchunks, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ksteps = KS > 0 ? KS : ksteps_rt;
@@ -159,6 +159,9 @@ __global__ __launch_bounds__(kThreads, (KS >= 4 && NT >= 4) ? 3 : 4) void pw_str
   auto mma = [&](f32x4 (&acc)[NT][TM], const bf16x8 (&src)[KSR][TM], int ks0) {
 #pragma unroll
     for (int kk = 0; kk < KSR; ++kk) {
+      // long reductions: keep step kk's filter reads behind step kk-1's (the scheduler otherwise clusters
+      // all NT x KS LDS reads at the top of the group and spills hundreds of registers)
+      if (NT * KSR > 8) asm volatile("" : "+v"(w_opaque));
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
         if ((a >> 1) < live_pairs) {
@@ -307,6 +310,10 @@ int launch_pw_x(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) 
   if constexpr (NT <= 4) {
     if (ksteps == 4) return launch_pw_k<NT, TM, XFORM, 4>(d, ksteps, lds, s);
   }
+  if constexpr (TM == 1) {   // X3D res4 / res5 conv_c: 216 and 432 input channels, whole K in registers
+    if (ksteps == 7) return launch_pw_k<NT, TM, XFORM, 7>(d, ksteps, lds, s);
+    if (ksteps == 14) return launch_pw_k<NT, TM, XFORM, 14>(d, ksteps, lds, s);
+  }
   return launch_pw_k<NT, TM, XFORM, 0>(d, ksteps, lds, s);
 }
 
@@ -329,7 +336,7 @@ int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s) {
   if (d.a_gate && S_out < 64) return PV_ERR_UNSUPPORTED;  // a 64-voxel wave tile must span <= 2 clips
   const int cout_p8 = pv_round_up(d.cout, 8);
   const int ksteps = (d.cin + 31) / 32;
-  if (ksteps > 8) return PV_ERR_UNSUPPORTED;
+  if (ksteps > 8 && ksteps != 14) return PV_ERR_UNSUPPORTED;
   int NT = cout_p8 <= 32 ? 2 : (cout_p8 <= 64 ? 4 : 8);
   const size_t lds = (size_t)NT * 16 * (ksteps * 32 + 8) * 2 + (size_t)2 * NT * 16 * 4 +
                      (d.a_gate ? (size_t)4 * 2 * d.cin * 4 : 0);
