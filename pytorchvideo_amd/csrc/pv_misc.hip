@@ -547,6 +547,106 @@ __global__ __launch_bounds__(kThreads) void add_act_kernel(const pv_add_desc d, 
   a.store(static_cast<T*>(d.y) + r * d.ldy + cg * 8);
 }
 
+// The same gate for the sizes X3D uses (C <= 448, reduced width <= 32): this kernel is a chain of four
+// dependent phases on a handful of bytes, so its duration is the sum of their memory latencies.  Every
+// FC weight a thread will need is requested at kernel entry, together with the partial sums, so the
+// phases after the first run out of registers.
+constexpr int kSeMaxCh = 2;     // channels per thread: c_p <= 512
+// CJ: 64-channel strides covering C (<= 7); CRP: reduced width rounded up to 8 / 16 / 32
+template <int CJ, int CRP>
+__global__ __launch_bounds__(kThreads) void se_gate_fast_kernel(const pv_se_gate_desc d) {
+  constexpr int kSeMaxC64 = CJ;
+  constexpr int kSeMaxR = CRP / 4;   // hidden units per wave (4 waves)
+  extern __shared__ float s[];
+  float* s_mean = s;                 // [c_p]
+  float* s_hid = s + d.c_p;          // [32]
+  float* s_part = s + d.c_p + 32;    // [groups][c_p]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  // ---- prefetch: fc1 rows (wave = hidden unit), fc2 rows (thread = channel), biases ----
+  float w1r[kSeMaxR][kSeMaxC64], b1r[kSeMaxR];
+#pragma unroll
+  for (int i = 0; i < kSeMaxR; ++i) {
+    const int r = wave + i * 4;
+    const bool rok = r < d.cr;
+    b1r[i] = (rok && d.b1) ? d.b1[r] : 0.f;
+#pragma unroll
+    for (int j = 0; j < kSeMaxC64; ++j) {
+      const int c = lane + j * 64;
+      const bool ok = rok && c < d.C;
+      const float v = d.w1[ok ? (long)r * d.C + c : 0];
+      w1r[i][j] = ok ? v : 0.f;
+    }
+  }
+  float w2r[kSeMaxCh][CRP], b2r[kSeMaxCh];
+#pragma unroll
+  for (int i = 0; i < kSeMaxCh; ++i) {
+    const int c = tid + i * kThreads;
+    const bool cok = c < d.C;
+    b2r[i] = (cok && d.b2) ? d.b2[c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < CRP; ++r) {
+      const bool ok = cok && r < d.cr;
+      const float v = d.w2[ok ? (long)c * d.cr + r : 0];
+      w2r[i][r] = ok ? v : 0.f;
+    }
+  }
+  // ---- mean over T,H,W from the per-tile partial sums ----
+  const float* ps = d.psum + (long)b * d.nblk * d.c_p;
+  const int cw = d.c_p < kThreads ? d.c_p : kThreads;
+  const int groups = kThreads / cw;
+  const int g = tid / cw, cl = tid - g * cw;
+  for (int c0 = 0; c0 < d.c_p; c0 += cw) {
+    const int c = c0 + cl;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (g < groups && c < d.c_p) {
+      int k = g;
+      for (; k + 3 * groups < d.nblk; k += 4 * groups) {
+        a0 += ps[(long)k * d.c_p + c];
+        a1 += ps[(long)(k + groups) * d.c_p + c];
+        a2 += ps[(long)(k + 2 * groups) * d.c_p + c];
+        a3 += ps[(long)(k + 3 * groups) * d.c_p + c];
+      }
+      for (; k < d.nblk; k += groups) a0 += ps[(long)k * d.c_p + c];
+      s_part[g * d.c_p + c] = (a0 + a1) + (a2 + a3);
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < d.c_p; c += kThreads) {
+    float a = 0.f;
+    for (int gg = 0; gg < groups; ++gg) a += s_part[gg * d.c_p + c];
+    s_mean[c] = a * d.inv_count;
+  }
+  __syncthreads();
+  // ---- fc1 + relu ----
+  float mj[kSeMaxC64];
+#pragma unroll
+  for (int j = 0; j < kSeMaxC64; ++j) mj[j] = lane + j * 64 < d.C ? s_mean[lane + j * 64] : 0.f;
+#pragma unroll
+  for (int i = 0; i < kSeMaxR; ++i) {
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < kSeMaxC64; ++j) a += w1r[i][j] * mj[j];
+    a = pv_wave_sum(a);
+    if (lane == 0 && wave + i * 4 < 32) s_hid[wave + i * 4] = wave + i * 4 < d.cr ? fmaxf(a + b1r[i], 0.f) : 0.f;
+  }
+  __syncthreads();
+  // ---- fc2 + sigmoid ----
+  float hid[CRP];
+#pragma unroll
+  for (int r = 0; r < CRP; ++r) hid[r] = s_hid[r];
+#pragma unroll
+  for (int i = 0; i < kSeMaxCh; ++i) {
+    const int c = tid + i * kThreads;
+    if (c < d.c_p) {
+      float a = b2r[i];
+#pragma unroll
+      for (int r = 0; r < CRP; ++r) a += w2r[i][r] * hid[r];
+      d.gate[(long)b * d.c_p + c] = c < d.C ? pv_sigmoid(a) : 0.f;
+    }
+  }
+}
+
 inline unsigned blocks_for(long total) { return (unsigned)pv_ceil_div(total, kThreads); }
 
 }  // namespace
@@ -556,6 +656,18 @@ extern "C" int pv_se_gate(const pv_se_gate_desc* d, pv_stream_t stream) {
   if (!d || !d->psum || !d->gate || !d->w1 || !d->w2) return PV_ERR_INVALID;
   if (d->B <= 0 || d->C <= 0 || d->cr <= 0 || d->nblk <= 0 || d->c_p < d->C || d->c_p % 8) return PV_ERR_INVALID;
   const int cw = d->c_p < kThreads ? d->c_p : kThreads;
+  if (d->C <= 448 && d->cr <= 32 && d->c_p <= kThreads * kSeMaxCh) {
+    const size_t lds_f = sizeof(float) * ((size_t)d->c_p + 32 + (size_t)(kThreads / cw) * d->c_p);
+    const int cj = (d->C + 63) / 64;
+    dim3 grid(d->B), block(kThreads);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (cj <= 1 && d->cr <= 8) hipLaunchKernelGGL((se_gate_fast_kernel<1, 8>), grid, block, lds_f, st, *d);
+    else if (cj <= 2 && d->cr <= 8) hipLaunchKernelGGL((se_gate_fast_kernel<2, 8>), grid, block, lds_f, st, *d);
+    else if (cj <= 4 && d->cr <= 16) hipLaunchKernelGGL((se_gate_fast_kernel<4, 16>), grid, block, lds_f, st, *d);
+    else hipLaunchKernelGGL((se_gate_fast_kernel<7, 32>), grid, block, lds_f, st, *d);
+    PV_LAUNCH_CHECK();
+    return PV_OK;
+  }
   const size_t lds = sizeof(float) * ((size_t)d->c_p + d->cr + (size_t)(kThreads / cw) * d->c_p);
   hipLaunchKernelGGL(se_gate_kernel, dim3(d->B), dim3(kThreads), lds, static_cast<hipStream_t>(stream), *d);
   PV_LAUNCH_CHECK();

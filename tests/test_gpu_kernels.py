@@ -356,6 +356,31 @@ def test_depthwise_3x3x3_plane_kernel_with_se_partial_sums(B, T, H, W, Cc, strid
     assert rel_err(got_mean, pre.mean(dim=[2, 3, 4])) <= 1e-3   # sums are fp32, before the bf16 rounding
 
 
+# ------------------------------------------------------------------ squeeze-excitation gate
+@pytest.mark.parametrize("B,Cc,cr,nblk", [
+    (3, 54, 8, 56), (2, 108, 8, 14), (2, 216, 16, 4), (4, 432, 32, 2), (2, 40, 8, 1),
+    (2, 600, 40, 3),     # beyond the register-resident variant: generic kernel
+])
+def test_se_gate_from_partial_sums(B, Cc, cr, nblk):
+    """fvcore SqueezeExcitation as used at models/x3d.py:190-198: sigmoid(W2 relu(W1 mean + b1) + b2),
+    the mean assembled from the depthwise kernel's per-tile partial sums."""
+    cp = (Cc + 7) // 8 * 8
+    psum = torch.zeros(B, nblk, cp, device="cuda")
+    psum[..., :Cc] = _rand((B, nblk, Cc), 111, torch.float32, 3.0)
+    w1, b1 = _rand((cr, Cc), 112, torch.float32, Cc ** -0.5), _rand((cr,), 113, torch.float32)
+    w2, b2 = _rand((Cc, cr), 114, torch.float32, cr ** -0.5), _rand((Cc,), 115, torch.float32)
+    count = 777.0
+    mean = psum.sum(1)[:, :Cc] / count
+    want = torch.sigmoid(F.relu(mean @ w1.t() + b1) @ w2.t() + b2)
+    gate = torch.full((B, cp), 9.0, device="cuda")
+    d = L.SeGateDesc()
+    d.psum, d.gate, d.w1, d.b1, d.w2, d.b2 = psum.data_ptr(), gate.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    d.B, d.C, d.c_p, d.cr, d.nblk, d.inv_count = B, Cc, cp, cr, nblk, 1.0 / count
+    call("pv_se_gate", d)
+    assert rel_err(gate[:, :Cc], want) <= 1e-5
+    assert torch.all(gate[:, Cc:] == 0)
+
+
 # ------------------------------------------------------------------ conv_a fused into conv_b (pointwise producer)
 @pytest.mark.parametrize("stride,act", [((1, 1, 1), L.ACT_SWISH), ((1, 2, 2), L.ACT_NONE)])
 @pytest.mark.parametrize("B,T,H,W,Cin,Cc", [
