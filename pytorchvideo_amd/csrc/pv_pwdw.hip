@@ -173,20 +173,21 @@ __global__ __launch_bounds__(kPlaneThreads) void pwdw_plane_kernel(const pv_dwco
   float2 ps = {0.f, 0.f};
 
   unsigned y_off[NW];
+  float y_mask[NW];   // 1 for outputs that exist: the squeeze-excitation sums skip the ragged edge
 #pragma unroll
   for (int n = 0; n < NW; ++n) {
     const int wo = wo_first + n;
     const bool ok = ch_ok && ho < d.Ho && wo < d.Wo;
     y_off[n] = ok ? (unsigned)((ho * d.Wo + wo) * d.ldy + ch) * 2u : kOOB;
+    y_mask[n] = ok ? 1.f : 0.f;
   }
+  const bool has_psum = d.psum != nullptr;
   auto finalize = [&](float2 (&a)[NW], int t) {
     const unsigned tbytes = (unsigned)t * y_plane_bytes;
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
       float v0 = a[n].x * sc.x + sh.x, v1 = a[n].y * sc.y + sh.y;
-      const bool ok = y_off[n] != kOOB;
-      ps.x += ok ? v0 : 0.f;
-      ps.y += ok ? v1 : 0.f;
+      if (has_psum) { ps.x += v0 * y_mask[n]; ps.y += v1 * y_mask[n]; }
       if (ACT == PV_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
       else if (ACT == PV_ACT_SWISH) { v0 *= pv_sigmoid(v0); v1 *= pv_sigmoid(v1); }
       typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
