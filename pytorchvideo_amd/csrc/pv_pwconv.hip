@@ -304,12 +304,8 @@ int launch_pw_x(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) 
   // whole-K register residency (with cross-group prefetch) only where it does not spill
   if (ksteps == 1) return launch_pw_k<NT, TM, XFORM, 1>(d, ksteps, lds, s);
   if (ksteps == 2) return launch_pw_k<NT, TM, XFORM, 2>(d, ksteps, lds, s);
-  if constexpr (NT <= 4) {
-    if (ksteps == 3) return launch_pw_k<NT, TM, XFORM, 3>(d, ksteps, lds, s);
-  }
-  if constexpr (NT <= 4) {
-    if (ksteps == 4) return launch_pw_k<NT, TM, XFORM, 4>(d, ksteps, lds, s);
-  }
+  if (ksteps == 3) return launch_pw_k<NT, TM, XFORM, 3>(d, ksteps, lds, s);
+  if (ksteps == 4) return launch_pw_k<NT, TM, XFORM, 4>(d, ksteps, lds, s);
   if constexpr (TM == 1) {   // X3D res4 / res5 conv_c: 216 and 432 input channels, whole K in registers
     if (ksteps == 7) return launch_pw_k<NT, TM, XFORM, 7>(d, ksteps, lds, s);
     if (ksteps == 14) return launch_pw_k<NT, TM, XFORM, 14>(d, ksteps, lds, s);

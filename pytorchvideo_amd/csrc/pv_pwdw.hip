@@ -84,8 +84,9 @@ __global__ __launch_bounds__(kPlaneThreads) void pwdw_plane_kernel(const pv_dwco
     sh.y = ch + 1 < d.C ? (d.shift ? d.shift[ch + 1] : 0.f) : 0.f;
   }
 
-  // ---- pointwise filter fragments (A operand: row = slab channel nt*16 + n16, k = 8q..8q+7 of step ks)
-  //      and the folded BN of conv_a for the 2 x 4 channels this lane produces ----
+  // ---- pointwise filter fragments (A operand, k = 8q..8q+7 of step ks) and the folded BN of conv_a.
+  //      Row r of MFMA tile nt is slab channel 8*(r>>2) + 4*nt + (r&3): the accumulator rows 4q..4q+3 of the
+  //      two tiles are then the 8 CONSECUTIVE channels 8q..8q+7 of a voxel = one 16-byte LDS write ----
   bf16x8 wa[2][KS];
   {
     const bf16_t* __restrict__ Wa = static_cast<const bf16_t*>(d.pw_w);
@@ -93,26 +94,27 @@ __global__ __launch_bounds__(kPlaneThreads) void pwdw_plane_kernel(const pv_dwco
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
-        wa[nt][ks] = *reinterpret_cast<const bf16x8*>(Wa + (long)(cbase + nt * 16 + n16) * (KS * 32) + ks * 32 + q * 8);
+        wa[nt][ks] = *reinterpret_cast<const bf16x8*>(Wa + (long)(cbase + 8 * (n16 >> 2) + 4 * nt + (n16 & 3)) * (KS * 32) + ks * 32 + q * 8);
   }
   float2 sa[2][2], ha[2][2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int c = cbase + nt * 16 + q * 4 + r;
+      const int c = cbase + q * 8 + nt * 4 + r;
       const bool ok = c < d.C;
       const float s_ = ok ? (d.pw_scale ? d.pw_scale[c] : 1.f) : 0.f;
       const float h_ = ok ? (d.pw_shift ? d.pw_shift[c] : 0.f) : 0.f;
       if (r & 1) { sa[nt][r >> 1].y = s_; ha[nt][r >> 1].y = h_; }
       else { sa[nt][r >> 1].x = s_; ha[nt][r >> 1].x = h_; }
     }
-  const float act_lo = d.pw_act == PV_ACT_RELU ? 0.f : -__builtin_huge_valf();   // ReLU as a max with a scalar
+  // ReLU on the packed pair: a negative bf16 is a negative int16, so max(.,0) per 16-bit half clears it
+  const bool a_relu = d.pw_act == PV_ACT_RELU;
 
   // ---- producer geometry: this wave's column tiles of the halo plane ----
   auto colperm = [](int c) { return c ^ ((c / (NW * S)) & 1); };
   unsigned x_off[MT];     // byte offset of (voxel, channel 8q) inside an input plane, or kOOB
-  int h_lds[MT];          // LDS element index of (voxel, channel 4q); lanes past the tile write the dump row
+  int h_lds[MT];          // LDS element index of (voxel, channel 8q); lanes past the tile write the dump row
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int v = (row + i * kPR) * 16 + n16;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(kPlaneThreads) void pwdw_plane_kernel(const pv_dwco
     const bool in_tile = v < NVOX;
     const bool ok = in_tile && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
     x_off[i] = ok ? (unsigned)((hi * d.Wi + wi) * d.ldx + q * 8) * 2u : kOOB;
-    h_lds[i] = (in_tile ? ih * IWP + colperm(iw) : IH * IWP) * 32 + q * 4;
+    h_lds[i] = (in_tile ? ih * IWP + colperm(iw) : IH * IWP) * 32 + q * 8;
   }
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   u32x4 xa[MT][KS], xb[MT][KS];
@@ -148,20 +150,22 @@ __global__ __launch_bounds__(kPlaneThreads) void pwdw_plane_kernel(const pv_dwco
       }
       // halo voxels outside the image are conv_b's zero padding: mask the packed result
       const unsigned inside = x_off[i] != kOOB ? 0xffffffffu : 0u;
+      u32x4 o;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-        u32x2 o;
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const float v0 = fmaxf(acc[nt][2 * h] * sa[nt][h].x + ha[nt][h].x, act_lo);
-          const float v1 = fmaxf(acc[nt][2 * h + 1] * sa[nt][h].y + ha[nt][h].y, act_lo);
+          const float v0 = acc[nt][2 * h] * sa[nt][h].x + ha[nt][h].x;
+          const float v1 = acc[nt][2 * h + 1] * sa[nt][h].y + ha[nt][h].y;
           const bf16x2_t pk = {(bf16_t)v0, (bf16_t)v1};
-          o[h] = __builtin_bit_cast(unsigned, pk) & inside;
+          s16x2 pi = __builtin_bit_cast(s16x2, pk);
+          if (a_relu) pi = __builtin_elementwise_max(pi, s16x2{0, 0});
+          o[nt * 2 + h] = __builtin_bit_cast(unsigned, pi) & inside;
         }
-        *reinterpret_cast<u32x2*>(dst + h_lds[i] + nt * 16) = o;
       }
+      *reinterpret_cast<u32x4*>(dst + h_lds[i]) = o;
     }
   };
 
