@@ -235,6 +235,9 @@ typedef struct pv_rows_desc {
   float eps;
   int32_t dtype;                          /* of x; y same except mean_rows (fp32) */
   int32_t x_f32;                          /* layernorm: 1 = x is fp32 while y is `dtype` */
+  int32_t g_period;                       /* layernorm: 0, or gamma/beta are [g_period][C] tables and row r */
+                                          /* uses table row r % g_period (per-head norms of several tensors  */
+                                          /* packed side by side, layers/attention.py:202-205); C <= 256    */
 } pv_rows_desc;
 int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream);
 int pv_softmax_rows(const pv_rows_desc* d, pv_stream_t stream);

@@ -58,7 +58,7 @@ LayoutDesc = _struct("LayoutDesc", [
 
 RowsDesc = _struct("RowsDesc", [
     ("x", _p), ("y", _p), ("gamma", _p), ("beta", _p), ("rows", _i64)]
-    + _ints("C", "ldx", "ldy", "rows_per_batch") + [("eps", _f32), ("dtype", _i32), ("x_f32", _i32)])
+    + _ints("C", "ldx", "ldy", "rows_per_batch") + [("eps", _f32), ("dtype", _i32), ("x_f32", _i32), ("g_period", _i32)])
 
 PosencDesc = _struct("PosencDesc", [
     ("x", _p), ("cls_token", _p), ("pos_spatial", _p), ("pos_temporal", _p), ("pos_class", _p)]
@@ -120,7 +120,7 @@ _SYMBOLS = [
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 

@@ -19,6 +19,8 @@ epilogues add an fp32 residual and write fp32 -- so that 16 blocks of bf16 round
 pile up on the stream; every MFMA operand (x_norm, q/k/v, P, attention output, MLP hidden)
 is bf16.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -161,6 +163,56 @@ def _streams_well(ap, x):
     return x.B * T * H * W * x.C >= (1 << 23)
 
 
+def emit_attention_pool_kv(sess, ap_k, ap_v, xkv, heads, label):
+    """pool_k and pool_v of one MultiScaleAttention in ONE depthwise launch + ONE LayerNorm launch.
+    k and v are adjacent channel slices of the fused qkv GEMM's output, so `xkv` (B, N, 2*dim) is a
+    single token tensor whose depthwise filter table is [pool_k's filter x heads | pool_v's x heads] and
+    whose per-head LayerNorm uses a (2*heads)-row gamma/beta table (pv_rows_desc.g_period).  Returns
+    (k, v) as channel slices of the pooled tensor, or None when the two pools differ in geometry."""
+    pk, pv = ap_k.pool, ap_v.pool
+    if not (isinstance(pk, nn.Conv3d) and isinstance(pv, nn.Conv3d)) or xkv.thw is None:
+        return None
+    dim = xkv.C // 2
+    hd = dim // heads
+    same = ("kernel_size", "stride", "padding", "dilation", "groups", "in_channels", "out_channels", "padding_mode")
+    if any(getattr(pk, a) != getattr(pv, a) for a in same) or pk.bias is not None or pv.bias is not None:
+        return None
+    if pk.groups != pk.in_channels or pk.in_channels != hd or hd % 8 or 2 * heads > 16 or 16 % (2 * heads):
+        return None
+    if bool(ap_k.has_cls_embed) != bool(ap_v.has_cls_embed) or bool(ap_k.has_norm) != bool(ap_v.has_norm):
+        return None
+    if ap_k.has_norm:
+        nk, nv = ap_k.norm, ap_v.norm
+        if ap_k.norm_before_pool or ap_v.norm_before_pool or not isinstance(nk, nn.LayerNorm) or not isinstance(nv, nn.LayerNorm):
+            return None
+        if tuple(nk.normalized_shape) != (hd,) or tuple(nv.normalized_shape) != (hd,) or nk.eps != nv.eps:
+            return None
+        if (nk.weight is None) != (nv.weight is None) or (nk.bias is None) != (nv.bias is None):
+            return None
+    # one depthwise conv over 2*dim channels: channel c uses pool_k's filter (c % hd) for c < dim, pool_v's after
+    conv = nn.Conv3d(2 * dim, 2 * dim, pk.kernel_size, pk.stride, pk.padding, groups=2 * dim, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.cat([pk.weight.detach().float().repeat(heads, 1, 1, 1, 1),
+                                     pv.weight.detach().float().repeat(heads, 1, 1, 1, 1)], 0))
+    n_prefix = 1 if ap_k.has_cls_embed else 0
+    y = E.emit_dwconv(sess, conv, xkv, None, L.ACT_NONE, grid=xkv.thw, n_prefix=n_prefix, label=label)
+    if ap_k.has_norm:
+        def table(pk_, pv_):
+            if pk_ is None:
+                return None
+            return sess.add_weight(torch.cat([pk_.detach().float().repeat(heads), pv_.detach().float().repeat(heads)]))
+        n_rows = y.B * y.voxels * 2 * heads
+        f = dict(x=y.ptr, y=y.ptr, gamma=table(ap_k.norm.weight, ap_v.norm.weight), beta=table(ap_k.norm.bias, ap_v.norm.bias),
+                 rows=n_rows, C=hd, ldx=hd, ldy=hd, rows_per_batch=0, eps=float(ap_k.norm.eps), dtype=sess.pv_dtype,
+                 x_f32=0, g_period=2 * heads)
+        sess.add_op(L.OP_LAYERNORM, f, label=label + ".norm", alg_bytes=2 * sess.itemsize * n_rows * hd)
+    k = y.channel_slice(0, dim)
+    v = y.channel_slice(dim, dim)
+    for t in (k, v):
+        t.thw, t.has_cls = y.thw, y.has_cls
+    return y, k, v
+
+
 def emit_attention_pools_fused(sess, pools, xs, heads, label, skip=()):
     """q / k / v pooling of one MultiScaleAttention as ONE launch (pv_token_pool): depthwise conv on
     the token grid + cls pass-through + LayerNorm(head_dim).  `pools` are the _AttentionPool modules,
@@ -279,7 +331,17 @@ def emit_multiscale_attention(sess, attn, xn, residual, label="attn"):
         names = (".pool_q", ".pool_k", ".pool_v")
         outs = list(parts)
         big = [i for i in range(3) if _streams_well(pools[i], parts[i])]
+        kv = None
+        if 1 in big and 2 in big and os.environ.get("PV_FUSE_KV_POOL", "1") != "0":
+            xkv = qkv.channel_slice(attn.dim_out, 2 * attn.dim_out)
+            xkv.thw, xkv.has_cls = xn.thw, xn.has_cls
+            kv = emit_attention_pool_kv(sess, pools[1], pools[2], xkv, heads, label + ".pool_kv")
+        if kv is not None:
+            outs[1], outs[2] = kv[1], kv[2]
+            owned.append(kv[0])
         for i in big:
+            if kv is not None and i in (1, 2):
+                continue
             outs[i] = emit_attention_pool(sess, pools[i], parts[i], heads, label + names[i])
         fused = emit_attention_pools_fused(sess, pools, parts, heads, label + ".pool_qkv", skip=big)
         if fused is not None:
@@ -291,7 +353,7 @@ def emit_multiscale_attention(sess, attn, xn, residual, label="attn"):
                 if i not in big:
                     outs[i] = emit_attention_pool(sess, pools[i], parts[i], heads, label + names[i])
         q, k, v = outs
-        owned += [t for t, p in zip((q, k, v), parts) if t is not p]
+        owned += [t for t, p in zip((q, k, v), parts) if t is not p and (kv is None or (t is not kv[1] and t is not kv[2]))]
         owned.append(qkv)
     o = emit_attention_core(sess, q, k, v, heads, attn.scale, attn.residual_pool, label=label + ".core")
     q_thw = q.thw

@@ -319,13 +319,16 @@ __global__ __launch_bounds__(kThreads) void layernorm16_kernel(const pv_rows_des
   constexpr int RPW = 64 / G;                       // rows per wave per iteration
   const long wave_id = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   const long wave_stride = (long)gridDim.x * (kThreads / 64);
-  // this lane's slice of gamma / beta is the same for every row: load it once
+  // this lane's slice of gamma / beta is the same for every row it will see: load it once.  With a
+  // periodic table (g_period rows) that still holds, because the grid is a multiple of g_period and a
+  // lane group's row index advances by multiples of 8 * gridDim.x.
+  const int prow = d.g_period > 0 ? (int)((wave_id * RPW + sub) % d.g_period) * d.C : 0;
   float gm[8], bt[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = l16 * 8 + j;
-    gm[j] = (c < d.C && d.gamma) ? d.gamma[c] : 1.f;
-    bt[j] = (c < d.C && d.beta) ? d.beta[c] : 0.f;
+    gm[j] = (c < d.C && d.gamma) ? d.gamma[prow + c] : 1.f;
+    bt[j] = (c < d.C && d.beta) ? d.beta[prow + c] : 0.f;
   }
   // grid-stride over row groups, two groups in flight per wave
   for (long g0 = wave_id; g0 * RPW < d.rows; g0 += 2 * wave_stride) {
@@ -787,10 +790,14 @@ extern "C" int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream) {
   if (d->ldx % 8 || d->ldy % 8) return PV_ERR_INVALID;
   const int CG = pv_round_up(d->C, 8) / 8;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d->g_period < 0 || d->g_period > 16) return PV_ERR_INVALID;
+  if (d->g_period > 1 && (CG > 32 || d->x_f32 || 16 % d->g_period)) return PV_ERR_UNSUPPORTED;   // narrow-row kernel only
 #define PV_LN16(G)                                                                                              \
   do {                                                                                                          \
-    const long nb16 = pv_ceil_div(d->rows, (kThreads / 64) * (64 / G) * 2);                                    \
-    dim3 grid16((unsigned)(nb16 < 4096 ? nb16 : 4096)), block16(kThreads);                                    \
+    long nb16 = pv_ceil_div(d->rows, (kThreads / 64) * (64 / G) * 2);                                          \
+    nb16 = nb16 < 4096 ? nb16 : 4096;                                                                           \
+    if (d->g_period > 1) nb16 = pv_ceil_div(nb16, d->g_period) * d->g_period;                                   \
+    dim3 grid16((unsigned)nb16), block16(kThreads);                                                             \
     if (d->dtype == PV_BF16 && d->x_f32)                                                                        \
       hipLaunchKernelGGL((layernorm16_kernel<float, bf16_t, G>), grid16, block16, 0, s, *d);                    \
     else if (d->dtype == PV_BF16)                                                                               \

@@ -157,6 +157,27 @@ def test_layernorm_rows(dtype, rows, Cc):
     assert rel_err(y, want) <= TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tokens,heads,hd", [(785, 4, 96), (50, 8, 96), (333, 1, 64), (77, 2, 128)])
+def test_layernorm_per_head_with_periodic_parameter_table(dtype, tokens, heads, hd):
+    """LayerNorm(head_dim) over k|v packed side by side (2*heads rows of `hd` per token), the first
+    `heads` rows of every token normalised with pool_k's parameters, the rest with pool_v's."""
+    P = 2 * heads
+    x = _rand((tokens, P, hd), 131, dtype, 2.0) + 0.25
+    gk, bk = _rand((hd,), 132, torch.float32), _rand((hd,), 133, torch.float32)
+    gv, bv = _rand((hd,), 134, torch.float32), _rand((hd,), 135, torch.float32)
+    want = torch.cat([F.layer_norm(x[:, :heads].float(), (hd,), gk, bk, 1e-6),
+                      F.layer_norm(x[:, heads:].float(), (hd,), gv, bv, 1e-6)], 1)
+    gam = torch.cat([gk.repeat(heads), gv.repeat(heads)]).contiguous()
+    bet = torch.cat([bk.repeat(heads), bv.repeat(heads)]).contiguous()
+    y = torch.zeros_like(x)
+    d = L.RowsDesc()
+    d.x, d.y, d.gamma, d.beta = x.data_ptr(), y.data_ptr(), gam.data_ptr(), bet.data_ptr()
+    d.rows, d.C, d.ldx, d.ldy, d.eps, d.dtype, d.g_period = tokens * P, hd, hd, hd, 1e-6, pv_dtype(x), P
+    call("pv_layernorm", d)
+    assert rel_err(y, want) <= TOL[dtype]
+
+
 # ------------------------------------------------------------------ GEMM (linear) shapes of MViT
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,K,N,act,res", [
