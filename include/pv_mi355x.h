@@ -97,6 +97,12 @@ typedef struct pv_conv3d_desc {
    * Only for the first-layer layout, where pv_conv3d_dwt_supported(d) is 1. */
   const float* dwt_w;
   int32_t dwt_k;
+  /* First-layer layout with at most 8 output channels (SlowFast's fast stem, models/slowfast.py:55-60):
+   * c4_wpair = 2 makes two W-adjacent outputs one MFMA column, so the 16 filter rows of the matrix
+   * instruction are all used and the overlapping halves of the two windows are loaded once.  Weights
+   * are then packed [2][round_up(cout,8)][kt][kh][round_up(kw+sw,2)][4]: row (j, co) holds co's filter
+   * shifted right by j*sw voxels, zeros elsewhere.  0 / 1 = one output per column (layout above). */
+  int32_t c4_wpair;
 } pv_conv3d_desc;
 int pv_conv3d(const pv_conv3d_desc* d, pv_stream_t stream);
 /* 1 if this geometry (pointers are ignored) can run with the fused temporal conv, else 0 */

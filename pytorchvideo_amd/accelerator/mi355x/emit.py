@@ -136,7 +136,16 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
         raise RuntimeError("conv output buffer geometry mismatch")
     # pack [cout][taps][cin_p]
     w = conv.weight.detach().float().cpu()  # [cout, cin, kt, kh, kw]
-    if c4:   # [cout][kt][kh][round_up(kw,2)][4], zeros in the padding
+    wpair = 0
+    if c4 and pad8(cout) <= 8 and dwt is None and not y_f32 and os.environ.get("PV_STEM_WPAIR", "1") != "0":
+        # <= 8 output channels (SlowFast's fast stem): two W-adjacent outputs per MFMA column; row (j, co) of the
+        # 16-row filter tile is co's filter shifted right by j*sw voxels
+        wpair, cp8 = 2, pad8(cout)
+        wp = torch.zeros(2, cp8, kt, kh, (kw + sw + 1) // 2 * 2, 4, dtype=torch.float32)
+        for j in range(2):
+            wp[j, :cout, :, :, j * sw: j * sw + kw, : x.C] = w.permute(0, 2, 3, 4, 1)
+        wp = wp.reshape(2 * cp8, -1)
+    elif c4:   # [cout][kt][kh][round_up(kw,2)][4], zeros in the padding
         wp = torch.zeros(cout, kt, kh, (kw + 1) // 2 * 2, 4, dtype=torch.float32)
         wp[:, :, :, :kw, : x.C] = w.permute(0, 2, 3, 4, 1)
         wp = wp.reshape(cout, -1)
@@ -158,7 +167,7 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
         B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, cin=cin_p, To=To, Ho=Ho, Wo=Wo, cout=cout,
         kt=kt, kh=kh, kw=kw, st=st, sh=sh, sw=sw, pt=pt, ph=ph, pw=pw,
         act=act, a_act=a_act, dtype=sess.pv_dtype, y_f32=1 if y_f32 else 0,
-        r_f32=1 if (residual is not None and residual.f32) else 0,
+        r_f32=1 if (residual is not None and residual.f32) else 0, c4_wpair=wpair,
     )
     if residual is not None and ((residual.B, residual.T, residual.H, residual.W) != (y.B, y.T, y.H, y.W)
                                  or residual.C != cout):

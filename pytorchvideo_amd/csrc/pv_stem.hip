@@ -19,7 +19,10 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxPairs = 1024;   // K <= 8192
 
-template <int NT, int TM>
+// JP = 2 (c4_wpair): an MFMA column is a PAIR of W-adjacent outputs whose filters -- the same taps shifted
+// by the stride -- occupy rows [0,8) and [8,16) of one filter tile; for an 8-channel layer (SlowFast's
+// fast stem) that doubles the useful rows per instruction and halves the operand loads per output.
+template <int NT, int TM, int JP = 1>
 __global__ __launch_bounds__(kThreads) void stem_c4_kernel(const pv_conv3d_desc d, int ksteps, int ngroups) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int Kp = ksteps * 32;
@@ -31,13 +34,16 @@ __global__ __launch_bounds__(kThreads) void stem_c4_kernel(const pv_conv3d_desc 
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int n16 = lane & 15, q = lane >> 4;
-  const int KWP = (d.kw + 1) & ~1;
+  const int kw_eff = d.kw + (JP - 1) * d.sw;   // columns spanned by the JP windows of an MFMA column
+  const int KWP = (kw_eff + 1) & ~1;
   const int PPR = KWP / 2;                 // voxel pairs per (dt,dh) row
   const int K = d.kt * d.kh * KWP * 4;     // packed K (multiple of 8)
   const int npairs = ksteps * 4;
-  const long S_out = (long)d.To * d.Ho * d.Wo;
+  const int Wo2 = (d.Wo + JP - 1) / JP;    // MFMA columns per output row
+  const long S_out = (long)d.To * d.Ho * Wo2;
   const long M = (long)d.B * S_out;
   const int n0 = blockIdx.y * NT * 16;
+  const int w_rows = JP == 1 ? d.cout : JP * pv_round_up(d.cout, 8);   // filter rows the host packed
 
   {
     const bf16_t* __restrict__ Wt = static_cast<const bf16_t*>(d.w);
@@ -45,7 +51,7 @@ __global__ __launch_bounds__(kThreads) void stem_c4_kernel(const pv_conv3d_desc 
     for (int id = tid; id < NT * 16 * cpr; id += kThreads) {
       const int r = id / cpr, kc = id - r * cpr;
       bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (n0 + r < d.cout && kc * 8 < K) v = *reinterpret_cast<const bf16x8*>(Wt + (long)(n0 + r) * K + kc * 8);
+      if (n0 + r < w_rows && kc * 8 < K) v = *reinterpret_cast<const bf16x8*>(Wt + (long)(n0 + r) * K + kc * 8);
       *reinterpret_cast<bf16x8*>(w_s + r * WLD + kc * 8) = v;
     }
     for (int pi = tid; pi < npairs; pi += kThreads) {
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void stem_c4_kernel(const pv_conv3d_desc 
   for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const long m_base = ((long)g * 4 + wave) * (TM * 16);
     if (m_base >= M) continue;
-    int vb[TM], vt[TM], vh[TM], vw[TM];
+    int vb[TM], vt[TM], vh[TM], vw[TM], vwo[TM];
     long vy[TM];
     bool vok[TM];
 #pragma unroll
@@ -75,14 +81,16 @@ __global__ __launch_bounds__(kThreads) void stem_c4_kernel(const pv_conv3d_desc 
       const long mm = vok[t] ? m : 0;
       const long b = mm / S_out;
       const long sp = mm - b * S_out;
-      const int to = (int)(sp / (d.Ho * d.Wo));
-      const int r2 = (int)(sp - (long)to * d.Ho * d.Wo);
-      const int ho = r2 / d.Wo;
+      const int to = (int)(sp / (d.Ho * Wo2));
+      const int r2 = (int)(sp - (long)to * d.Ho * Wo2);
+      const int ho = r2 / Wo2;
+      const int wo = (r2 - ho * Wo2) * JP;     // first output of the column
       vb[t] = (int)b;
       vt[t] = to * d.st - d.pt;
       vh[t] = ho * d.sh - d.ph;
-      vw[t] = (r2 - ho * d.Wo) * d.sw - d.pw;
-      vy[t] = b * d.y_bs + sp * d.ldy;
+      vw[t] = wo * d.sw - d.pw;
+      vwo[t] = wo;
+      vy[t] = b * d.y_bs + (((long)to * d.Ho + ho) * d.Wo + wo) * d.ldy;
     }
     auto load_step = [&](u32x2 (&dst)[TM][2], int ks) {
       const int tp = tab_s[ks * 4 + q];
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(kThreads) void stem_c4_kernel(const pv_conv3d_desc 
         const unsigned base = (unsigned)vb[t] * (unsigned)d.x_bs + ((unsigned)(ti * d.Hi + hi) * d.Wi + wi) * 4u;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const bool ok = rok && (unsigned)(wi + e) < (unsigned)d.Wi && dw + e < d.kw;
+          const bool ok = rok && (unsigned)(wi + e) < (unsigned)d.Wi && dw + e < kw_eff;
           dst[t][e] = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)(ok ? (base + 4u * e) * 2u : kOOB), 0, 0);
         }
       }
@@ -129,6 +137,31 @@ __global__ __launch_bounds__(kThreads) void stem_c4_kernel(const pv_conv3d_desc 
       }
     }
 
+    if constexpr (JP == 2) {
+      // ---- epilogue, paired columns: rows 4q..4q+3 of the tile = channels 4(q&1)..+3 of output j = q>>1 ----
+      const int co0 = 4 * (q & 1), j = q >> 1;
+      float sc[4], sh[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const bool ok = co0 + jj < d.cout;
+        sc[jj] = ok ? (d.scale ? d.scale[co0 + jj] : 1.f) : 0.f;
+        sh[jj] = ok ? (d.shift ? d.shift[co0 + jj] : 0.f) : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        if (!vok[t] || vwo[t] + j >= d.Wo) continue;
+        float v[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) v[jj] = acc[0][t][jj] * sc[jj] + sh[jj];
+        pv_apply_act_n<true>(v, d.act);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          if (co0 + jj >= d.cout) v[jj] = 0.f;
+        const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(d.y) + vy[t] + (long)j * d.ldy + co0) = o;
+      }
+      continue;
+    }
     // ---- epilogue: lane holds channels n0 + a*16 + q*4 .. +3 of voxel n16 ----
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
@@ -162,14 +195,14 @@ __global__ __launch_bounds__(kThreads) void stem_c4_kernel(const pv_conv3d_desc 
   }
 }
 
-template <int NT, int TM> int launch_stem(const pv_conv3d_desc& d, int ksteps, hipStream_t s) {
-  const long M = (long)d.B * d.To * d.Ho * d.Wo;
+template <int NT, int TM, int JP = 1> int launch_stem(const pv_conv3d_desc& d, int ksteps, hipStream_t s) {
+  const long M = (long)d.B * d.To * d.Ho * ((d.Wo + JP - 1) / JP);
   const long ngroups = pv_ceil_div(M, 4 * TM * 16);
-  const int nsplit = (int)pv_ceil_div(pv_round_up(d.cout, 8), NT * 16);
+  const int nsplit = JP == 1 ? (int)pv_ceil_div(pv_round_up(d.cout, 8), NT * 16) : 1;
   if (ngroups > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
   const size_t lds = (size_t)NT * 16 * (ksteps * 32 + 8) * 2 + (size_t)ksteps * 4 * 4;
   if (lds > 160 * 1024) return PV_ERR_UNSUPPORTED;
-  auto kern = stem_c4_kernel<NT, TM>;
+  auto kern = stem_c4_kernel<NT, TM, JP>;
   if (lds > 64 * 1024)
     PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long gx = ngroups < 4096 ? ngroups : 4096;
@@ -396,7 +429,9 @@ int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s) {
   if (d.residual || d.a_gate || d.a_act != PV_ACT_NONE) return PV_ERR_UNSUPPORTED;
   if ((long)d.B * d.x_bs > 0x3fffffffL) return PV_ERR_UNSUPPORTED;   // 31-bit byte offsets
   if (d.ldy % 4 || d.y_bs % 4) return PV_ERR_INVALID;
-  const int KWP = (d.kw + 1) & ~1;
+  const int jp = d.c4_wpair == 2 ? 2 : 1;
+  if (d.c4_wpair < 0 || d.c4_wpair > 2 || (jp == 2 && (d.cout > 8 || d.y_f32 || d.dwt_w))) return PV_ERR_UNSUPPORTED;
+  const int KWP = (d.kw + (jp - 1) * d.sw + 1) & ~1;
   const int K = d.kt * d.kh * KWP * 4;
   const int ksteps = (K + 31) / 32;
   if (d.dwt_w) {   // fused depthwise temporal conv (X3D stem)
@@ -406,6 +441,7 @@ int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s) {
   }
   if (ksteps * 4 > kMaxPairs || d.kt > 255 || d.kh > 255 || d.kw > 255) return PV_ERR_UNSUPPORTED;
   const int cout_p8 = pv_round_up(d.cout, 8);
+  if (jp == 2) return launch_stem<1, 4, 2>(d, ksteps, s);
   if (cout_p8 <= 16) return launch_stem<1, 4>(d, ksteps, s);
   if (cout_p8 <= 32) return launch_stem<2, 4>(d, ksteps, s);
   if (cout_p8 <= 64) return launch_stem<4, 2>(d, ksteps, s);

@@ -288,6 +288,37 @@ def test_first_layer_conv_on_c4_layout(B, T, H, W, cout, k, s, p, f32out):
     assert torch.all(y[..., cout:] == 0)
 
 
+@pytest.mark.parametrize("B,T,H,W,cout,k,s,p", [
+    (1, 8, 24, 40, 8, (5, 7, 7), (1, 2, 2), (2, 3, 3)),     # SlowFast fast stem
+    (2, 3, 17, 23, 8, (1, 7, 7), (1, 2, 2), (0, 3, 3)),     # odd output width: the last column holds one output
+    (1, 4, 12, 15, 5, (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # stride 1, fewer than 8 channels
+    (1, 2, 10, 31, 8, (1, 5, 4), (1, 2, 3), (0, 2, 1)),     # even kernel width, stride 3
+])
+def test_first_layer_conv_two_outputs_per_mfma_column(B, T, H, W, cout, k, s, p):
+    """c4_wpair = 2 (csrc/pv_stem.hip): same result as the plain first-layer conv and as torch."""
+    x = _rand((B, 3, T, H, W), 141, torch.bfloat16)
+    w = _rand((cout, 3) + k, 142, torch.bfloat16, (3 * k[0] * k[1] * k[2]) ** -0.5)
+    bias = _rand((cout,), 143, torch.float32)
+    want = F.relu(F.conv3d(x.float(), w.float(), bias, stride=s, padding=p))
+    To, Ho, Wo = want.shape[2:]
+    x4 = torch.zeros(B, T, H, W, 4, dtype=torch.bfloat16, device="cuda")
+    x4[..., :3] = x.permute(0, 2, 3, 4, 1)
+    kwp = (k[2] + s[2] + 1) // 2 * 2
+    wp = torch.zeros(2, 8, k[0], k[1], kwp, 4, dtype=torch.bfloat16, device="cuda")
+    for j in range(2):
+        wp[j, :cout, :, :, j * s[2]: j * s[2] + k[2], :3] = w.permute(0, 2, 3, 4, 1)
+    y = torch.full((B, To, Ho, Wo, 8), 5.0, dtype=torch.bfloat16, device="cuda")
+    d = L.Conv3dDesc()
+    d.x, d.w, d.y, d.shift = x4.data_ptr(), wp.data_ptr(), y.data_ptr(), bias.data_ptr()
+    d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * 4, To * Ho * Wo * 8, 4, 8
+    d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, 4, To, Ho, Wo, cout
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *s, *p)
+    d.act, d.a_act, d.dtype, d.c4_wpair = L.ACT_RELU, L.ACT_NONE, L.PV_BF16, 2
+    call("pv_conv3d", d)
+    assert rel_err(y[..., :cout].permute(0, 4, 1, 2, 3), want) <= 1e-2
+    assert torch.all(y[..., cout:] == 0)
+
+
 @pytest.mark.parametrize("B,T,H,W,cout,dk,act", [
     (2, 16, 30, 34, 24, 5, L.ACT_RELU),   # X3D stem: 1x3x3 s(1,2,2) 3->24, then depthwise 5x1x1, BN, ReLU
     (1, 4, 18, 22, 24, 5, L.ACT_RELU),    # clip shorter than one unrolled ring turn
