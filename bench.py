@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-h2d", action="store_true",
+                    help="also time steps that upload the (pinned) host input first; reported as pcie_inclusive, never as value")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,6 +159,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     assert out.shape == (batch * world, 400) and torch.isfinite(out).all()
+
+    pcie = None
+    if args.with_h2d:   # the same steps with the host -> device upload of the batch inside the timed region
+        xs = x if isinstance(x, list) else [x]
+        hs = [t.cpu().pin_memory() for t in xs]
+        for _ in range(2):
+            for t, h in zip(xs, hs):
+                t.copy_(h, non_blocking=True)
+            out = step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            for t, h in zip(xs, hs):
+                t.copy_(h, non_blocking=True)
+            out = step()
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        pcie = {"value": round(batch * args.steps / e1, 2), "unit": "clips/s (this rank)", "ms_per_step": round(e1 / args.steps * 1e3, 4),
+                "upload_bytes_per_step": int(sum(h.numel() * h.element_size() for h in hs))}
 
     # per-kernel device time (HIP events on the launch stream, inside this process)
     sess = model._pv_session
@@ -208,6 +229,8 @@ def main():
                 "model_mfma_frac": round(clips_s / world * wl["gflop"] * 1e9 / (MFMA_PEAK_TFS * 1e12), 4),
             },
         }
+        if pcie is not None:
+            line["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         if os.environ.get("PV_BENCH_VERBOSE") == "2":
