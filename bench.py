@@ -178,6 +178,26 @@ def main():
         e1 = time.perf_counter() - t1
         pcie = {"value": round(batch * args.steps / e1, 2), "unit": "clips/s (this rank)", "ms_per_step": round(e1 / args.steps * 1e3, 4),
                 "upload_bytes_per_step": int(sum(h.numel() * h.element_size() for h in hs))}
+        # ... and with the pre-path transforms fused into the ingest (pytorchvideo_amd.transforms.DevicePacker):
+        # one uint8 clip at the fast frame rate is uploaded, every pathway is subsampled / scaled / normalised
+        # on the device
+        from pytorchvideo_amd.transforms import DevicePacker
+        ratios = (xs[-1].shape[2] // xs[0].shape[2], 1) if len(xs) == 2 else None
+        packer = DevicePacker(model, (0.45,) * 3, (0.225,) * 3, div255=True, frame_ratios=ratios)
+        u8 = torch.randint(0, 256, tuple(xs[-1].shape), dtype=torch.uint8).pin_memory()
+        d8 = torch.empty_like(u8, device=device)
+        for _ in range(2):
+            d8.copy_(u8, non_blocking=True)
+            packer(d8)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            d8.copy_(u8, non_blocking=True)
+            packer(d8)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t2
+        pcie["u8_packed"] = {"value": round(batch * args.steps / e2, 2), "ms_per_step": round(e2 / args.steps * 1e3, 4),
+                             "upload_bytes_per_step": int(u8.numel())}
 
     # per-kernel device time (HIP events on the launch stream, inside this process)
     sess = model._pv_session

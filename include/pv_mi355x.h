@@ -39,7 +39,7 @@ enum pv_status {
   PV_ERR_HIP = -3          /* a HIP runtime call failed; see pv_last_error()          */
 };
 
-enum pv_dtype { PV_F32 = 0, PV_BF16 = 1 };
+enum pv_dtype { PV_F32 = 0, PV_BF16 = 1, PV_U8 = 2 /* source of pv_ingest_ncdhw only: decoded video frames */ };
 
 enum pv_act {
   PV_ACT_NONE = 0,
@@ -208,9 +208,14 @@ int pv_pool3d(const pv_pool3d_desc* d, pv_stream_t stream);
 
 /* ---- layout ingest / egress --------------------------------------------------------
  * The reference API is NCDHW (models/net.py:41-44).  Ingest converts a contiguous
- * [B,C,T,H,W] tensor (fp32 or bf16) to NDHWC `dtype` with C padded to c_p (zeros);
- * t_stride/t_offset select frames (SlowFast PackPathway: transforms/functional.py:134).
- * Egress is the inverse (channels [0,C)), used by block-level forwards and tests.
+ * [B,C,src_T,H,W] tensor (fp32, bf16 or uint8) to NDHWC `dtype` with C padded to c_p (zeros).
+ * The steps that sit immediately before the path in the reference's data pipeline ride along
+ * (SURVEY 8f-1): frame selection -- destination frame t reads source frame t_index[t], the
+ * index_select of uniform_temporal_subsample (transforms/functional.py:19-41), so SlowFast's slow
+ * pathway (uniform_temporal_subsample_repeated, :134-160) is ingested straight from the fast clip --
+ * and a per-channel affine y = x*ch_scale[c] + ch_shift[c] in fp32, which is Div255 + Normalize
+ * (transforms/transforms.py:177-195,414-430) with scale = 1/(255 std), shift = -mean/std.
+ * Egress is the inverse layout change only (channels [0,C)), used by block-level forwards and tests.
  */
 typedef struct pv_layout_desc {
   const void* src; void* dst;
@@ -219,6 +224,11 @@ typedef struct pv_layout_desc {
                                the 4-channel first-layer layout), voxel stride */
   int64_t bs;               /* NDHWC side batch stride                           */
   int32_t src_dtype, dst_dtype;
+  /* ingest only (ignored by egress): */
+  const int32_t* t_index;   /* [T] source frame of every destination frame, or NULL (identity)   */
+  int32_t src_T;            /* frames in the source when t_index is given (else = T)              */
+  const float* ch_scale;    /* [C] or NULL                                                        */
+  const float* ch_shift;    /* [C] or NULL                                                        */
 } pv_layout_desc;
 int pv_ingest_ncdhw(const pv_layout_desc* d, pv_stream_t stream);
 int pv_egress_ncdhw(const pv_layout_desc* d, pv_stream_t stream);

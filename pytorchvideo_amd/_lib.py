@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libpv_mi355x.so")
 
 PV_OK, PV_ERR_UNSUPPORTED, PV_ERR_INVALID, PV_ERR_HIP = 0, -1, -2, -3
-PV_F32, PV_BF16 = 0, 1
+PV_F32, PV_BF16, PV_U8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 POOL_MAX, POOL_AVG = 0, 1
 (OP_CONV3D, OP_DWCONV3D, OP_SE_GATE, OP_POOL3D, OP_LAYERNORM, OP_SOFTMAX_ROWS, OP_MEAN_ROWS,
@@ -54,7 +54,8 @@ Pool3dDesc = _struct("Pool3dDesc", [
 
 LayoutDesc = _struct("LayoutDesc", [
     ("src", _p), ("dst", _p)] + _ints("B", "C", "T", "H", "W", "c_p", "ld")
-    + [("bs", _i64)] + _ints("src_dtype", "dst_dtype"))
+    + [("bs", _i64)] + _ints("src_dtype", "dst_dtype")
+    + [("t_index", _p)] + _ints("src_T") + [("ch_scale", _p), ("ch_shift", _p)])
 
 RowsDesc = _struct("RowsDesc", [
     ("x", _p), ("y", _p), ("gamma", _p), ("beta", _p), ("rows", _i64)]
@@ -120,7 +121,7 @@ _SYMBOLS = [
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 

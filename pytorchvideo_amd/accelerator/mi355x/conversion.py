@@ -139,6 +139,7 @@ def _try_fuse_net(model, lut, batch, sess, dtype, input_tensor=None):
         cur = blk._out_ref
         prev_owned = list(cur) if isinstance(cur, list) else [cur]
     first_in, last = blocks[0]._in_ref, blocks[-1]
+    model.__dict__["_pv_output"] = last._out_ref
 
     def fused_forward(self, x):
         s = self._pv_session
@@ -156,7 +157,16 @@ def _try_fuse_net(model, lut, batch, sess, dtype, input_tensor=None):
         return s.view(out)
 
     model.forward = types.MethodType(fused_forward, model)
+    model.__dict__["_pv_inputs"] = first_in     # arena buffers a forward fills (transforms.DevicePacker)
+    model.__dict__["_pv_result"] = lambda: fused_result(model)
     return True
+
+
+def fused_result(model):
+    s, out = model._pv_session, model._pv_output
+    if out.T == out.H == out.W == 1 and out.f32:
+        return s.view_rows(out)[:, 0, :]
+    return s.view(out)
 
 
 # ------------------------------------------------------------------ whole-MViT fusion
@@ -203,4 +213,6 @@ def _try_fuse_mvit(model, sess, dtype, input_tensor):
         return s.view_rows(out)[:, 0, :]
 
     model.forward = types.MethodType(fused_forward, model)
+    model.__dict__["_pv_inputs"] = first_in
+    model.__dict__["_pv_result"] = lambda: model._pv_session.view_rows(out)[:, 0, :]
     return True

@@ -270,24 +270,33 @@ class Session:
         v = self.view(ref)
         return x.data_ptr() == v.data_ptr() and x.dtype == v.dtype and x.stride() == v.stride() and x.shape == v.shape
 
-    def ingest(self, x, ref, t_stride=1):
-        """Copy a user tensor (NCDHW, any strides) into the channels-last arena buffer `ref`."""
+    def ingest(self, x, ref, t_index=None, ch_scale=None, ch_shift=None):
+        """Copy a user tensor (NCDHW, any strides; fp32, bf16 or uint8) into the channels-last arena
+        buffer `ref`.  `t_index` (int32 device tensor, one source frame per destination frame) selects
+        frames in the same pass; `ch_scale` / `ch_shift` (fp32 device tensors [C]) apply
+        y = x*scale + shift -- see pytorchvideo_amd.transforms.DevicePacker."""
         lib = L.lib()
         if not x.is_cuda:
             x = x.to(self.device, non_blocking=True)
-        if x.dtype not in (torch.float32, torch.bfloat16):
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.uint8):
             x = x.float()
         x = x.contiguous()
-        B, Cc, T, H, W = x.shape
+        B, Cc, Ts, H, W = x.shape
+        T = Ts if t_index is None else int(t_index.numel())
         if (B, Cc, T, H, W) != (ref.B, ref.C, ref.T, ref.H, ref.W):
             raise L.PvError("deploy form was converted for input %s, got %s" %
-                            ((ref.B, ref.C, ref.T, ref.H, ref.W), tuple(x.shape)))
+                            ((ref.B, ref.C, ref.T, ref.H, ref.W), (B, Cc, T, H, W)))
         d = L.LayoutDesc()
         d.src, d.dst = x.data_ptr(), self.arena_t.data_ptr() + ref.off
         d.B, d.C, d.T, d.H, d.W = B, Cc, T, H, W
         d.c_p, d.ld, d.bs = (4 if ref.ld == 4 else pad8(ref.C)), ref.ld, ref.bs
-        d.src_dtype = L.PV_BF16 if x.dtype == torch.bfloat16 else L.PV_F32
+        d.src_dtype = {torch.bfloat16: L.PV_BF16, torch.float32: L.PV_F32, torch.uint8: L.PV_U8}[x.dtype]
         d.dst_dtype = self.pv_dtype
+        if t_index is not None:
+            d.t_index, d.src_T = t_index.data_ptr(), Ts
+        if ch_scale is not None:
+            d.ch_scale = ch_scale.data_ptr()
+            d.ch_shift = ch_shift.data_ptr() if ch_shift is not None else None
         L.check(lib.pv_ingest_ncdhw(C.byref(d), self._stream()), "ingest")
 
     def ingest_rows(self, x, ref):

@@ -205,12 +205,19 @@ __global__ __launch_bounds__(kThreads) void ingest_kernel(const pv_layout_desc d
   const long S3 = (long)d.T * d.H * d.W;
   const int b = (int)(vox / S3);
   const long sp = vox - (long)b * S3;
-  const S* src = static_cast<const S*>(d.src) + (long)b * d.C * S3 + sp;
+  // source voxel: frame t of the destination reads frame t_index[t] of the source clip
+  const long HW = (long)d.H * d.W;
+  const int t = (int)(sp / HW);
+  const long S3s = (long)(d.t_index ? d.src_T : d.T) * HW;
+  const long sps = (long)(d.t_index ? d.t_index[t] : t) * HW + (sp - (long)t * HW);
+  const S* src = static_cast<const S*>(d.src) + (long)b * d.C * S3s + sps;
   float f[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = cg * 8 + j;
-    f[j] = c < d.C ? ld_as_f32(src + (long)c * S3) : 0.f;
+    float v = c < d.C ? ld_as_f32(src + (long)c * S3s) : 0.f;
+    if (c < d.C && d.ch_scale) v = v * d.ch_scale[c] + (d.ch_shift ? d.ch_shift[c] : 0.f);
+    f[j] = v;
   }
   Chunk8<T> o;
   o.from_f32(f);
@@ -225,10 +232,18 @@ __global__ __launch_bounds__(kThreads) void ingest_c4_kernel(const pv_layout_des
   const long S3 = (long)d.T * d.H * d.W;
   const long b = vox / S3;
   const long sp = vox - b * S3;
-  const S* src = static_cast<const S*>(d.src) + b * d.C * S3 + sp;
+  const long HW = (long)d.H * d.W;
+  const int t = (int)(sp / HW);
+  const long S3s = (long)(d.t_index ? d.src_T : d.T) * HW;
+  const long sps = (long)(d.t_index ? d.t_index[t] : t) * HW + (sp - (long)t * HW);
+  const S* src = static_cast<const S*>(d.src) + b * d.C * S3s + sps;
   bf16x4 o;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(j < d.C ? ld_as_f32(src + (long)j * S3) : 0.f);
+  for (int j = 0; j < 4; ++j) {
+    float v = j < d.C ? ld_as_f32(src + (long)j * S3s) : 0.f;
+    if (j < d.C && d.ch_scale) v = v * d.ch_scale[j] + (d.ch_shift ? d.ch_shift[j] : 0.f);
+    o[j] = (bf16_t)v;
+  }
   *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(d.dst) + b * d.bs + sp * 4) = o;
 }
 
@@ -731,8 +746,10 @@ extern "C" int pv_ingest_ncdhw(const pv_layout_desc* d, pv_stream_t stream) {
     const long nvox = (long)d->B * d->T * d->H * d->W;
     dim3 grid(blocks_for(nvox)), block(kThreads);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d->t_index && d->src_T <= 0) return PV_ERR_INVALID;
     if (d->src_dtype == PV_F32) hipLaunchKernelGGL(ingest_c4_kernel<float>, grid, block, 0, s, *d, nvox);
     else if (d->src_dtype == PV_BF16) hipLaunchKernelGGL(ingest_c4_kernel<bf16_t>, grid, block, 0, s, *d, nvox);
+    else if (d->src_dtype == PV_U8) hipLaunchKernelGGL(ingest_c4_kernel<unsigned char>, grid, block, 0, s, *d, nvox);
     else return PV_ERR_UNSUPPORTED;
     PV_LAUNCH_CHECK();
     return PV_OK;
@@ -743,7 +760,12 @@ extern "C" int pv_ingest_ncdhw(const pv_layout_desc* d, pv_stream_t stream) {
   const long total = nvox * (d->c_p / 8);
   dim3 grid(blocks_for(total)), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (d->src_dtype == PV_F32 && d->dst_dtype == PV_F32)
+  if (d->t_index && d->src_T <= 0) return PV_ERR_INVALID;
+  if (d->src_dtype == PV_U8 && d->dst_dtype == PV_F32)
+    hipLaunchKernelGGL((ingest_kernel<unsigned char, float>), grid, block, 0, s, *d, nvox);
+  else if (d->src_dtype == PV_U8 && d->dst_dtype == PV_BF16)
+    hipLaunchKernelGGL((ingest_kernel<unsigned char, bf16_t>), grid, block, 0, s, *d, nvox);
+  else if (d->src_dtype == PV_F32 && d->dst_dtype == PV_F32)
     hipLaunchKernelGGL((ingest_kernel<float, float>), grid, block, 0, s, *d, nvox);
   else if (d->src_dtype == PV_F32 && d->dst_dtype == PV_BF16)
     hipLaunchKernelGGL((ingest_kernel<float, bf16_t>), grid, block, 0, s, *d, nvox);
