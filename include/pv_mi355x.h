@@ -289,6 +289,23 @@ int pv_attention(const pv_attention_desc* d, pv_stream_t stream);
 /* ---- elementwise -------------------------------------------------------------------
  * y = act(a + b) over (rows, C): residual joins that cannot ride in a conv epilogue.
  */
+/* ---- video-level ensembling (the step right after the path) ---------------
+ * pytorchvideo_trainer/module/video_classification.py:244-311: preds = softmax(logits) of every clip
+ * (30 views per video in the model zoo's test protocol) are summed -- or max-ed -- into its video's
+ * score row and the clip is counted: accum[video_index[i]][:] (op)= softmax(logits[i][:]),
+ * counts[video_index[i]] += 1, clips taken in index order (deterministic; no atomics).
+ * The final division by the count is left to the caller (after the cross-rank reduction).
+ */
+typedef struct pv_ensemble_desc {
+  const float* logits;          /* [N][ld] fp32                                  */
+  const int32_t* video_index;   /* [N], each in [0, V)                           */
+  float* accum;                 /* [V][C] fp32, updated in place                 */
+  int32_t* counts;              /* [V], updated in place                         */
+  int32_t N, C, ld, V;
+  int32_t mode;                 /* 0 = sum, 1 = max                              */
+} pv_ensemble_desc;
+int pv_ensemble_scores(const pv_ensemble_desc* d, pv_stream_t stream);
+
 typedef struct pv_add_desc {
   const void* a; const void* b; void* y;
   int64_t rows; int32_t C, lda, ldb, ldy;

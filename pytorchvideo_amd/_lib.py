@@ -43,6 +43,9 @@ DwConv3dDesc = _struct("DwConv3dDesc", [
             "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "w_mod", "act", "dtype", "n_prefix")
     + [("pw_w", _p), ("pw_scale", _p), ("pw_shift", _p)] + _ints("pw_cin", "pw_act"))
 
+EnsembleDesc = _struct("EnsembleDesc", [
+    ("logits", _p), ("video_index", _p), ("accum", _p), ("counts", _p)] + _ints("N", "C", "ld", "V", "mode"))
+
 SeGateDesc = _struct("SeGateDesc", [
     ("psum", _p), ("gate", _p), ("w1", _p), ("b1", _p), ("w2", _p), ("b2", _p)]
     + _ints("B", "C", "c_p", "cr", "nblk") + [("inv_count", _f32)])
@@ -100,6 +103,7 @@ _SYMBOLS = [
     ("pv_dwconv3d_psum_blocks", C.c_int, [C.POINTER(DwConv3dDesc)]),
     ("pv_dwconv3d_pw_supported", C.c_int, [C.POINTER(DwConv3dDesc)]),
     ("pv_se_gate", C.c_int, [C.POINTER(SeGateDesc), _p]),
+    ("pv_ensemble_scores", C.c_int, [C.POINTER(EnsembleDesc), _p]),
     ("pv_pool3d", C.c_int, [C.POINTER(Pool3dDesc), _p]),
     ("pv_ingest_ncdhw", C.c_int, [C.POINTER(LayoutDesc), _p]),
     ("pv_egress_ncdhw", C.c_int, [C.POINTER(LayoutDesc), _p]),
@@ -121,7 +125,7 @@ _SYMBOLS = [
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 

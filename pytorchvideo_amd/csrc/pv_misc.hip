@@ -481,6 +481,38 @@ __global__ __launch_bounds__(kThreads) void softmax_rows_kernel(const pv_rows_de
   for (int c = lane; c < d.C; c += 64) y[c] = (T)(__expf((float)x[c] - mx) * inv);
 }
 
+// Video-level ensembling: one wave per clip.  The wave of the FIRST clip of a video in this batch folds
+// every clip of that video (in index order) into the video's score row, so no two waves touch the same
+// row and the result does not depend on scheduling.
+__global__ __launch_bounds__(kThreads) void ensemble_kernel(const pv_ensemble_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (i >= d.N) return;
+  const int v = d.video_index[i];
+  if (v < 0 || v >= d.V) return;
+  for (int j = 0; j < i; ++j)
+    if (d.video_index[j] == v) return;   // an earlier clip's wave owns this video
+  float* acc = d.accum + (long)v * d.C;
+  int cnt = 0;
+  for (int j = i; j < d.N; ++j) {
+    if (d.video_index[j] != v) continue;
+    const float* x = d.logits + (long)j * d.ld;
+    float mx = -FLT_MAX;
+    for (int c = lane; c < d.C; c += 64) mx = fmaxf(mx, x[c]);
+    mx = pv_wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < d.C; c += 64) s += __expf(x[c] - mx);
+    s = pv_wave_sum(s);
+    const float inv = 1.f / s;
+    for (int c = lane; c < d.C; c += 64) {
+      const float p = __expf(x[c] - mx) * inv;
+      acc[c] = d.mode == 1 ? fmaxf(acc[c], p) : acc[c] + p;   // same lane re-reads what it wrote: ordered
+    }
+    ++cnt;
+  }
+  if (lane == 0) d.counts[v] += cnt;
+}
+
 // y[b][c] = mean over rows_per_batch rows (fp32 out); thread per (b, c)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void mean_rows_kernel(const pv_rows_desc d, int nb) {
@@ -876,6 +908,15 @@ extern "C" int pv_softmax_rows(const pv_rows_desc* d, pv_stream_t stream) {
   if (d->dtype == PV_BF16) hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, block, 0, s, *d);
   else if (d->dtype == PV_F32) hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, block, 0, s, *d);
   else return PV_ERR_UNSUPPORTED;
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
+extern "C" int pv_ensemble_scores(const pv_ensemble_desc* d, pv_stream_t stream) {
+  if (!d || !d->logits || !d->video_index || !d->accum || !d->counts) return PV_ERR_INVALID;
+  if (d->N <= 0 || d->C <= 0 || d->V <= 0 || d->ld < d->C || (d->mode != 0 && d->mode != 1)) return PV_ERR_INVALID;
+  hipLaunchKernelGGL(ensemble_kernel, dim3((unsigned)pv_ceil_div(d->N, kThreads / 64)), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream), *d);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

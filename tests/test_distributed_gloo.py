@@ -62,3 +62,33 @@ def test_shard_range_partitions_the_batch():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _ensemble_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pytorchvideo_amd.ensemble import VideoEnsembler
+    for method in ("sum", "max"):
+        e = VideoEnsembler(5, 7, method=method, device="cpu")
+        # what pv_ensemble_scores leaves on each rank (the kernel itself is covered by the GPU tests)
+        g = torch.Generator().manual_seed(10 + rank)
+        e.accum.copy_(torch.rand(5, 7, generator=g))
+        e.counts.copy_(torch.tensor([rank + 1, 0, 2, 1 - rank, 3], dtype=torch.int32))
+        res = e.merge().result()
+        torch.save((e.accum.clone(), e.counts.clone(), res), os.path.join(out_dir, "%s_r%d.pt" % (method, rank)))
+    dist.destroy_process_group()
+
+
+def test_video_ensembler_merge_is_the_head_collective(tmp_path):
+    """per-video score rows are reduced across ranks (sum or max) and clip counts summed."""
+    mp.spawn(_ensemble_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for method in ("sum", "max"):
+        a0, c0, r0 = torch.load(tmp_path / ("%s_r0.pt" % method))
+        a1, c1, r1 = torch.load(tmp_path / ("%s_r1.pt" % method))
+        assert torch.equal(a0, a1) and torch.equal(c0, c1) and torch.equal(r0, r1)
+        parts = [torch.rand(5, 7, generator=torch.Generator().manual_seed(10 + r)) for r in range(2)]
+        want = torch.maximum(parts[0], parts[1]) if method == "max" else parts[0] + parts[1]
+        assert torch.allclose(a0, want)
+        assert c0.tolist() == [3, 0, 4, 1, 6]
+        assert torch.allclose(r0, want / torch.tensor([3, 1, 4, 1, 6.0]).unsqueeze(1))

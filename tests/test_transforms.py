@@ -96,3 +96,32 @@ def test_device_packer_equals_host_packing_on_slowfast_and_x3d():
     want3 = dep3(x).clone()
     got3 = TR.DevicePacker(dep3, mean, std, div255=True)(clip.cuda())
     assert rel_err(got3, want3) <= 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["sum", "max"])
+def test_video_level_ensembling_matches_the_reference_loop(method):
+    """pytorchvideo_trainer/module/video_classification.py:286-306 restated as the dict loop it is."""
+    from pytorchvideo_amd.ensemble import VideoEnsembler
+    V, Cc = 6, 400
+    g = torch.Generator().manual_seed(21)
+    batches = [(torch.randn(8, Cc, generator=g) * 3, [0, 0, 1, 5, 1, 0, 3, 3]),
+               (torch.randn(5, Cc, generator=g) * 3, [3, 2, 2, 0, 5]),
+               (torch.randn(1, Cc, generator=g) * 3, [4])]
+    preds, cnts = {}, {}
+    for logits, ids in batches:
+        p = torch.softmax(logits, dim=-1)
+        for i, v in enumerate(ids):
+            if v not in preds:
+                preds[v], cnts[v] = torch.zeros(Cc), 0
+            preds[v] = preds[v] + p[i] if method == "sum" else torch.max(preds[v], p[i])
+            cnts[v] += 1
+    want = torch.stack([preds[v] / cnts[v] for v in range(V)])
+    e = VideoEnsembler(V, Cc, method=method)
+    for logits, ids in batches:
+        e.update(logits.cuda(), ids)
+    assert e.counts.tolist() == [cnts[v] for v in range(V)]
+    got = e.merge().result().cpu()
+    assert (got - want).abs().max().item() <= 1e-6
+    with pytest.raises(RuntimeError):
+        e.update(torch.zeros(2, Cc + 1, device="cuda"), [0, 1])
