@@ -20,3 +20,54 @@ slowfast_r50_config = dict(model_depth=50)      # hub/slowfast.py:59-66 (default
 slowfast_r101_config = dict(model_depth=101)    # hub/slowfast.py:69-100
 csn_r101_config = dict(model_depth=101, stem_pool=None)  # hub/csn.py (torch nn.MaxPool3d -> see factory)
 r2plus1d_r50_config = dict(model_depth=50, dropout_rate=0.5)  # hub/r2plus1d.py
+
+
+# --------------------------------------------------------------------------- checkpoint ingest
+# SURVEY 8f-3.  The model zoo stores {"model_state": state_dict, ...}; the reference builders load it
+# with strict key checking (hub/utils.py:39-44, hub/x3d.py:31-32), and MViT checkpoints older than
+# version 2 are remapped by MultiScaleAttention._load_from_state_dict (layers/attention.py:546-575,
+# mirrored in pytorchvideo_amd/layers/attention.py).  There is no network here: `checkpoint` is a local
+# file (torch.save format) or the already loaded dict.  The MI355X deploy form reads its weights from the
+# module tree at convert time, so a loaded checkpoint needs nothing else.
+def load_checkpoint(model, checkpoint, strict=True):
+    """Load a model-zoo style checkpoint into a host-mirror (or reference) model; returns the model."""
+    import torch
+    if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
+        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+    state = checkpoint["model_state"] if isinstance(checkpoint, dict) and "model_state" in checkpoint else checkpoint
+    model.load_state_dict(state, strict=strict)     # RuntimeError on missing / unexpected keys, like the reference
+    return model
+
+
+def hub_model_builder(model_builder_func, pretrained=False, progress=True, checkpoint_path="", default_config=None, **kwargs):
+    """hub/utils.py:11-45 with `checkpoint_path` a local file instead of a URL."""
+    if pretrained:
+        assert len(kwargs) == 0, "Do not change kwargs for pretrained model."
+    if default_config is not None:
+        for argument, value in default_config.items():
+            if kwargs.get(argument) is None:
+                kwargs[argument] = value
+    model = model_builder_func(**kwargs)
+    if pretrained:
+        if not checkpoint_path:
+            raise RuntimeError("pretrained=True needs checkpoint_path: a local copy of the model-zoo file (no network here)")
+        load_checkpoint(model, checkpoint_path)
+    return model
+
+
+def _named(builder_name, module, config):
+    def build(pretrained=False, progress=True, checkpoint_path="", **kwargs):
+        import importlib
+        fn = getattr(importlib.import_module("." + module, __package__), builder_name)
+        return hub_model_builder(fn, pretrained, progress, checkpoint_path, default_config=config, **kwargs)
+    return build
+
+
+x3d_xs = _named("create_x3d", "x3d", x3d_configs["x3d_xs"])
+x3d_s = _named("create_x3d", "x3d", x3d_configs["x3d_s"])
+x3d_m = _named("create_x3d", "x3d", x3d_configs["x3d_m"])
+x3d_l = _named("create_x3d", "x3d", x3d_configs["x3d_l"])
+slowfast_r50 = _named("create_slowfast", "slowfast", slowfast_r50_config)
+slowfast_r101 = _named("create_slowfast", "slowfast", slowfast_r101_config)
+mvit_base_16x4 = _named("create_multiscale_vision_transformers", "vision_transformers", mvit_video_base_config)
+mvit_base_32x3 = _named("create_multiscale_vision_transformers", "vision_transformers", mvit_video_base_32x3_config)
