@@ -171,6 +171,22 @@ def res_basic_head(sd, x, p, pool_kernel=None, softmax=False):
     return x.mean(dim=[2, 3, 4])
 
 
+def resnet_forward(sd, x, head_pool_kernel=(4, 7, 7), stage1_pool_kernel=None, spatial=(1, 2, 2, 2), temporal=(1, 1, 1, 1)):
+    """create_resnet (models/resnet.py:601-1003) as the hub uses it for slow_r50 / c2d_r50 / i3d_r50
+    (models/hub/resnet.py:41-160): stem with pool, four bottleneck stages whose conv_a kernels differ per
+    block (read off the weights), the temporal stride on conv_a and the spatial one on conv_b
+    (resnet.py:905-925), an optional MaxPool3d block after stage 1 (`stage1_pool`, :927-934) and the head."""
+    x = res_basic_stem(sd, x, "blocks.0")
+    b = 1
+    for i in range(4):
+        x = res_stage(sd, x, "blocks.%d" % b, (temporal[i], 1, 1), (1, spatial[i], spatial[i]))
+        b += 1
+        if i == 0 and stage1_pool_kernel is not None:
+            x = F.max_pool3d(x, stage1_pool_kernel, stage1_pool_kernel)
+            b += 1
+    return res_basic_head(sd, x, "blocks.%d" % b, head_pool_kernel)
+
+
 def csn_forward(sd, x, head_pool_kernel=(1, 7, 7), spatial=(1, 2, 2, 2), temporal=(1, 2, 2, 2)):
     """create_csn (models/csn.py:12-191): stem without pool, depthwise 3x3x3 conv_b."""
     x = res_basic_stem(sd, x, "blocks.0", pool=False)

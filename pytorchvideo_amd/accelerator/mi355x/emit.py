@@ -30,6 +30,12 @@ def _cls_name(m):
     return getattr(m, "_orig_cls", type(m)).__name__
 
 
+def _is_a(m, types):
+    """isinstance that sees through an Mi355x block to the class it adopted (a bare nn.MaxPool3d
+    between stages -- create_resnet's stage1_pool -- is wrapped like any other block)."""
+    return issubclass(getattr(m, "_orig_cls", type(m)), types)
+
+
 def act_code(act):
     """Map an activation module to the kernel's enum (None/Identity -> NONE)."""
     if act is None or isinstance(act, nn.Identity):
@@ -343,19 +349,19 @@ def emit_se_gate(sess, se, psum, nblk, B, Cc, count):
 
 def emit_pool(sess, pool, x, n_prefix=0, out=None, label="pool"):
     """nn.MaxPool3d / nn.AvgPool3d / nn.AdaptiveAvgPool3d(1) -> pv_pool3d."""
-    if isinstance(pool, nn.AdaptiveAvgPool3d):
+    if _is_a(pool, nn.AdaptiveAvgPool3d):
         osz = _triple(pool.output_size)
         if any(o not in (1, None) for o in osz):
             raise Unsupported("adaptive pool to %s" % (osz,))
         k = (x.T if osz[0] == 1 else 1, x.H if osz[1] == 1 else 1, x.W if osz[2] == 1 else 1)
         s, p, mode = k, (0, 0, 0), L.POOL_AVG
-    elif isinstance(pool, (nn.MaxPool3d, nn.AvgPool3d)):
+    elif _is_a(pool, (nn.MaxPool3d, nn.AvgPool3d)):
         k = _triple(pool.kernel_size)
         s = _triple(pool.stride if pool.stride is not None else pool.kernel_size)
         p = _triple(pool.padding)
         if getattr(pool, "ceil_mode", False):
             raise Unsupported("ceil_mode pooling")
-        if isinstance(pool, nn.MaxPool3d):
+        if _is_a(pool, nn.MaxPool3d):
             if _triple(pool.dilation) != (1, 1, 1) or pool.return_indices:
                 raise Unsupported("max pool options")
             mode = L.POOL_MAX
@@ -734,6 +740,6 @@ def emit_module(sess, m, x):
         return emit_res_block(sess, m, x)
     if n == "ResNetBasicHead":
         return emit_res_head(sess, m, x)
-    if isinstance(m, (nn.MaxPool3d, nn.AvgPool3d, nn.AdaptiveAvgPool3d)):
+    if _is_a(m, (nn.MaxPool3d, nn.AvgPool3d, nn.AdaptiveAvgPool3d)):
         return emit_pool(sess, m, x)
     raise Unsupported("no emitter for %s" % n)

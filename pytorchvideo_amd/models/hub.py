@@ -71,3 +71,27 @@ slowfast_r50 = _named("create_slowfast", "slowfast", slowfast_r50_config)
 slowfast_r101 = _named("create_slowfast", "slowfast", slowfast_r101_config)
 mvit_base_16x4 = _named("create_multiscale_vision_transformers", "vision_transformers", mvit_video_base_config)
 mvit_base_32x3 = _named("create_multiscale_vision_transformers", "vision_transformers", mvit_video_base_32x3_config)
+
+
+# hub/resnet.py:41-160 -- create_resnet variants
+def slow_r50(pretrained=False, progress=True, checkpoint_path="", **kwargs):
+    from .resnet import create_resnet
+    return hub_model_builder(create_resnet, pretrained, progress, checkpoint_path,
+                             default_config=dict(stem_conv_kernel_size=(1, 7, 7), head_pool_kernel_size=(8, 7, 7), model_depth=50), **kwargs)
+
+
+def c2d_r50(pretrained=False, progress=True, checkpoint_path="", **kwargs):
+    import torch.nn as nn
+    from .resnet import create_resnet
+    return hub_model_builder(create_resnet, pretrained, progress, checkpoint_path,
+                             default_config=dict(stem_conv_kernel_size=(1, 7, 7), stage1_pool=nn.MaxPool3d,
+                                                 stage_conv_a_kernel_size=((1, 1, 1),) * 4), **kwargs)
+
+
+def i3d_r50(pretrained=False, progress=True, checkpoint_path="", **kwargs):
+    import torch.nn as nn
+    from .resnet import create_resnet
+    return hub_model_builder(create_resnet, pretrained, progress, checkpoint_path,
+                             default_config=dict(stem_conv_kernel_size=(5, 7, 7), stage1_pool=nn.MaxPool3d,
+                                                 stage_conv_a_kernel_size=((3, 1, 1), [(3, 1, 1), (1, 1, 1)],
+                                                                           [(3, 1, 1), (1, 1, 1)], [(1, 1, 1), (3, 1, 1)])), **kwargs)
