@@ -38,6 +38,27 @@ class Mi355xBlock(EfficientBlockBase):
     def _original_forward(self, *args, **kwargs):
         return self._orig_cls.forward(self, *args, **kwargs)
 
+    def __getattr__(self, name):
+        # the adopted forward may use helpers defined on the original CLASS (static / class / plain methods,
+        # properties, class constants): resolve them there once the instance lookup has failed
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            oc = self.__dict__.get("_orig_cls")
+            if oc is None or not hasattr(oc, name):
+                raise
+            import inspect
+            attr = inspect.getattr_static(oc, name)
+            if isinstance(attr, staticmethod):
+                return attr.__func__
+            if isinstance(attr, classmethod):
+                return attr.__func__.__get__(oc, oc)
+            if isinstance(attr, property):
+                return attr.fget(self)
+            if inspect.isfunction(attr):
+                return attr.__get__(self, oc)
+            return attr
+
     # -- conversion ------------------------------------------------------------------
     def _emit(self, sess, x_ref):
         return E.emit_module(sess, self, x_ref)

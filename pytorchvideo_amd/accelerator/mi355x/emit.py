@@ -158,7 +158,12 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
     else:
         wp = torch.zeros(cout, kt * kh * kw, cin_p, dtype=torch.float32)
         wp[:, :, : x.C] = w.permute(0, 2, 3, 4, 1).reshape(cout, kt * kh * kw, x.C)
-    wp = wp.to(sess.dtype)
+    # an fp32 operand inside a bf16 plan (e.g. the mean-pooled tokens in front of MViT's head Linear) makes
+    # this one op an fp32 op: fp32 weights, fp32 output
+    f32_op = bool(x.f32) and sess.pv_dtype != L.PV_F32
+    if f32_op and (not y_f32 or c4 or a_gate is not None or (residual is not None and not residual.f32)):
+        raise Unsupported("fp32 operand in a bf16 plan needs an fp32 output")
+    wp = wp.to(torch.float32 if f32_op else sess.dtype)
     bias = conv.bias if dwt is None else dwt.bias
     scale, shift = fold_norm(norm, cout, bias)
     has_affine = norm is not None and not isinstance(norm, nn.Identity)
@@ -172,8 +177,8 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
         ldx=x.ld, ldy=y.ld, ldr=residual.ld if residual is not None else 0,
         B=x.B, Ti=x.T, Hi=x.H, Wi=x.W, cin=cin_p, To=To, Ho=Ho, Wo=Wo, cout=cout,
         kt=kt, kh=kh, kw=kw, st=st, sh=sh, sw=sw, pt=pt, ph=ph, pw=pw,
-        act=act, a_act=a_act, dtype=sess.pv_dtype, y_f32=1 if y_f32 else 0,
-        r_f32=1 if (residual is not None and residual.f32) else 0, c4_wpair=wpair,
+        act=act, a_act=a_act, dtype=L.PV_F32 if f32_op else sess.pv_dtype, y_f32=1 if (y_f32 and not f32_op) else 0,
+        r_f32=1 if (residual is not None and residual.f32 and not f32_op) else 0, c4_wpair=wpair,
     )
     if residual is not None and ((residual.B, residual.T, residual.H, residual.W) != (y.B, y.T, y.H, y.W)
                                  or residual.C != cout):

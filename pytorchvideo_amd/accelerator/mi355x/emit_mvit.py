@@ -460,10 +460,9 @@ def emit_vit_head(sess, norm_embed, head, x):
         sess.add_op(L.OP_MEAN_ROWS, f, label="head.seq_mean")
         if xn is not x:
             sess.release(xn)
-        if sess.pv_dtype != L.PV_F32:
-            raise Unsupported("mean sequence pooling in bf16")  # TODO: bf16 mean output
-        pooled = pooled32
-        pooled.f32 = False
+        pooled = pooled32     # fp32 in every plan: the head Linear then runs as an fp32 op (emit_conv)
+        if sess.pv_dtype == L.PV_F32:
+            pooled.f32 = False
     else:
         raise Unsupported("sequence pool %s" % sp.mode)
     logits = emit_linear(sess, head.proj, pooled, y_f32=True, label="head.proj")

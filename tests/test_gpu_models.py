@@ -128,3 +128,45 @@ def test_hub_resnet_backbones_match_oracle(name, dtype, tol):
     dm, xd = _deploy(m, x, dtype)
     assert dm._pv_session is not None     # converted as a whole: one launch plan
     assert rel_err(dm(xd), want) <= tol
+
+
+_MV = dict(spatial_size=64, temporal_size=4, depth=4, head_num_classes=7, embed_dim_mul=[[1, 2.0], [3, 2.0]],
+           atten_head_mul=[[1, 2.0], [3, 2.0]], pool_q_stride_size=[[1, 1, 2, 2], [3, 1, 2, 2]],
+           pool_kv_stride_adaptive=[1, 4, 4], pool_kvq_kernel=[3, 3, 3])
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("extra", [
+    dict(cls_embed_on=False),                       # no cls token: n_prefix = 0 everywhere, head pools by mean
+    dict(pool_first=True),                          # pool, then project (attention.py:501-520)
+    dict(pooling_mode="max"),
+    dict(pooling_mode="avg", temporal_size=8),      # (torch's avg_pool3d wants T >= kernel: the reference fails at T = 2 too)
+    dict(separate_qkv=False),                       # one qkv Linear in the checkpoint
+    dict(qkv_bias=False, bias_on=False),
+    dict(temporal_size=8, conv_patch_embed_stride=(1, 4, 4), pool_q_stride_size=[[1, 2, 2, 2], [3, 1, 2, 2]]),   # temporal q stride
+], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items())[:40])
+def test_mvit_variants_match_the_host_mirror(extra, dtype, tol):
+    """Factory sweep over create_multiscale_vision_transformers options (the reference sweeps them in
+    tests/test_models_vision_transformers.py:20-150): deploy form vs the original-form forward of the same
+    module tree on the kernels' quantisation of weights and input."""
+    from pytorchvideo_amd.models import create_multiscale_vision_transformers as create
+    cfg = dict(_MV, **extra)
+    torch.manual_seed(0)
+    m = create(**cfg)
+    deterministic_fill(m, 4).eval()
+    x = seeded_input((2, 3, cfg["temporal_size"], 64, 64), 4)
+    ref = create(**cfg).eval()
+    if dtype == torch.bfloat16:
+        sd_q, x_q = quantize_like_kernels(m.state_dict(), x)
+        ref.load_state_dict(sd_q)
+    else:
+        ref.load_state_dict(m.state_dict())
+        x_q = x
+    with torch.no_grad():
+        want = ref(x_q)
+    dm, xd = _deploy(m, x, dtype)
+    got = dm(xd)
+    assert got.shape == want.shape
+    assert rel_err(got, want) <= tol
+    # every one of these is covered by the HIP path: nothing was declined and left on torch
+    assert all(type(b).__name__ == "Mi355xMViTBlock" and b.convert_flag for b in dm.blocks)

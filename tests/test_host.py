@@ -98,3 +98,17 @@ def test_arena_reuses_and_coalesces():
     assert a.peak == peak
     big = a.alloc(2 * peak)               # must not overlap live blocks
     assert big >= o2 + 4096 or big + 2 * peak <= o2
+
+
+def test_block_wrapper_resolves_class_level_helpers_of_the_adopted_module():
+    """The original-form forward of a transmuted MultiScaleBlock uses a staticmethod of its class."""
+    from pytorchvideo_amd.models import create_multiscale_vision_transformers as create
+    m = create(spatial_size=32, temporal_size=4, depth=2, patch_embed_dim=32, num_heads=1, head_num_classes=5,
+               pool_q_stride_size=[[1, 1, 2, 2]], pool_kv_stride_adaptive=[1, 2, 2], pool_kvq_kernel=[3, 3, 3],
+               embed_dim_mul=[[1, 2.0]], atten_head_mul=[[1, 2.0]]).eval()
+    x = torch.randn(1, 3, 4, 32, 32)
+    with torch.no_grad():
+        want = m(x)
+        transmute_model(m, "mi355x")
+        assert type(m.blocks[0]).__name__ == "Mi355xMViTBlock"
+        assert torch.equal(m(x), want)      # original form of the transmuted model: same function
