@@ -97,6 +97,11 @@ def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quant
                           dict(convert_for_quantize=convert_for_quantize,
                                native_conv3d_op_qnnpack=native_conv3d_op_qnnpack))
     sess.finalize()
+    if not fused:
+        # Modules a transmuter declined stay in their original form (reference convention,
+        # transmuter_mobile_cpu.py:21-22) and run as ordinary torch modules between the converted blocks:
+        # they have to live where the activations do, in the plan's storage type.
+        converted.to(device=sess.device, dtype=dtype)
     converted.__dict__["_pv_session"] = sess
     converted.__dict__["_pv_use_graph"] = use_graph
     return converted

@@ -170,3 +170,58 @@ def test_mvit_variants_match_the_host_mirror(extra, dtype, tol):
     assert rel_err(got, want) <= tol
     # every one of these is covered by the HIP path: nothing was declined and left on torch
     assert all(type(b).__name__ == "Mi355xMViTBlock" and b.convert_flag for b in dm.blocks)
+
+
+def _mirror_case(create, cfg, x, dtype):
+    torch.manual_seed(0)
+    m = create(**cfg)
+    deterministic_fill(m, 6).eval()
+    ref = create(**cfg).eval()
+    if dtype == torch.bfloat16:
+        ref.load_state_dict(quantize_like_kernels(m.state_dict()))
+        xq = [t.bfloat16().float() for t in x] if isinstance(x, list) else x.bfloat16().float()
+    else:
+        ref.load_state_dict(m.state_dict())
+        xq = x
+    with torch.no_grad():
+        want = ref([t.clone() for t in xq] if isinstance(xq, list) else xq)
+    dm, xd = _deploy(m, x, dtype)
+    got = dm(list(xd) if isinstance(xd, list) else xd)
+    return got, want, dm
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("extra,alpha", [
+    (dict(slowfast_fusion_conv_kernel_size=(5, 1, 1), slowfast_conv_channel_fusion_ratio=1), 4),
+    (dict(slowfast_channel_reduction_ratio=(4,), stem_dim_outs=(32, 8)), 4),      # beta = 1/4: wider fast pathway
+    (dict(slowfast_fusion_conv_stride=(2, 1, 1)), 2),                              # alpha = 2
+    (dict(head_activation=torch.nn.Softmax), 4),
+], ids=["fuse5x1x1", "beta4", "alpha2", "softmax"])
+def test_slowfast_variants_match_the_host_mirror(extra, alpha, dtype, tol):
+    """create_slowfast option sweep (reference tests/test_models_slowfast.py:20-120) through the plugin boundary."""
+    from pytorchvideo_amd.models import create_slowfast
+    tf = 8
+    cfg = dict(model_depth=18, model_num_class=9, head_pool_kernel_sizes=((tf // alpha, 2, 2), (tf, 2, 2)), **extra)
+    fast = seeded_input((2, 3, tf, 64, 64), 6)
+    idx = torch.linspace(0, tf - 1, tf // alpha).long()
+    got, want, dm = _mirror_case(create_slowfast, cfg, [fast[:, :, idx].clone(), fast], dtype)
+    assert got.shape == want.shape and rel_err(got, want) <= tol
+    assert getattr(dm, "_pv_inputs", None) is not None     # converted as one plan
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("factory,cfg,shape", [
+    ("create_csn", dict(model_depth=50, model_num_class=9, stem_pool=torch.nn.MaxPool3d, head_pool_kernel_size=(1, 1, 1)),
+     (2, 3, 8, 64, 64)),                                                            # ir-CSN with the stem pool of csn_r101
+    ("create_r2plus1d", dict(model_depth=50, model_num_class=9, head_pool_kernel_size=(1, 2, 2),
+                             stage_temporal_stride=(1, 1, 2, 2)), (1, 3, 4, 64, 64)),
+    ("create_resnet", dict(model_depth=50, model_num_class=9, head_pool_kernel_size=(4, 2, 2),
+                           stage_conv_b_dilation=((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 2, 2)),
+                           stage_spatial_h_stride=(1, 2, 2, 1), stage_spatial_w_stride=(1, 2, 2, 1)), (1, 3, 4, 64, 64)),
+], ids=["csn_stem_pool", "r2plus1d_short", "resnet_dilated_res5"])
+def test_resnet_family_variants_match_the_host_mirror(factory, cfg, shape, dtype, tol):
+    """Other builders of the family; the dilated res5 (slow_r50_detection's backbone, hub/resnet.py:72-88) is
+    declined per block where a kernel does not cover it and must still give the right answer."""
+    import pytorchvideo_amd.models as M
+    got, want, dm = _mirror_case(getattr(M, factory), cfg, seeded_input(shape, 6), dtype)
+    assert got.shape == want.shape and rel_err(got.float(), want) <= tol
