@@ -103,6 +103,13 @@ typedef struct pv_conv3d_desc {
    * are then packed [2][round_up(cout,8)][kt][kh][round_up(kw+sw,2)][4]: row (j, co) holds co's filter
    * shifted right by j*sw voxels, zeros elsewhere.  0 / 1 = one output per column (layout above). */
   int32_t c4_wpair;
+  /* First-layer layout with an fp32 output (MViT's patch embedding, models/stem.py:289-338): the position
+   * tables of SpatioTemporalClsPositionalEncoding.forward (layers/positional_encoding.py:112-136) are added
+   * in the epilogue: y[to][ho][wo][c] += pos_spatial[ho*Wo+wo][c] + pos_temporal[to][c]  (separable), or
+   * += pos_spatial[(to*Ho+ho)*Wo+wo][c] when pos_temporal is NULL (full table, cls row skipped by the caller).
+   * Tables are fp32 [rows][cout].  The cls row itself is written by pv_add_posenc(cls_only). */
+  const float* pos_spatial;
+  const float* pos_temporal;
 } pv_conv3d_desc;
 int pv_conv3d(const pv_conv3d_desc* d, pv_stream_t stream);
 /* 1 if this geometry (pointers are ignored) can run with the fused temporal conv, else 0 */
@@ -267,6 +274,7 @@ typedef struct pv_posenc_desc {
   const float* pos_class;     /* [C] or NULL                                        */
   int32_t B, T, HW, C, ld;
   int32_t dtype;
+  int32_t cls_only;           /* 1: write the cls row only (the tables were added by the producing conv) */
 } pv_posenc_desc;
 int pv_add_posenc(const pv_posenc_desc* d, pv_stream_t stream);
 

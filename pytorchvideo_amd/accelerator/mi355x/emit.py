@@ -112,7 +112,7 @@ def is_add_fusion(fn):
 
 # --------------------------------------------------------------------------- conv family
 def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=None, a_act=L.ACT_NONE,
-              out=None, y_f32=False, label="conv", dwt=None):
+              out=None, y_f32=False, label="conv", dwt=None, pos=None):
     """Dense Conv3d (+BN +bias +residual +act) -> pv_conv3d, or depthwise -> pv_dwconv3d.
     `dwt`: a depthwise temporal Conv3d (k,1,1) applied to the conv's output before norm/act inside the
     same launch (X3D stem; only where can_fuse_temporal_dw said so)."""
@@ -183,6 +183,10 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
     if residual is not None and ((residual.B, residual.T, residual.H, residual.W) != (y.B, y.T, y.H, y.W)
                                  or residual.C != cout):
         raise RuntimeError("residual geometry mismatch")
+    if pos is not None:   # (spatial table, temporal table or None): added in the first-layer kernel's fp32 epilogue
+        if not c4 or not y_f32 or wpair:
+            raise Unsupported("position tables ride only in the first-layer conv's fp32 epilogue")
+        f.update(pos_spatial=pos[0], pos_temporal=pos[1])
     if dwt is not None:
         dk = dwt.kernel_size[0]
         taps_t = torch.zeros(dk, pad8(cout), dtype=torch.float32)

@@ -422,18 +422,30 @@ def emit_patch_embed_and_pos(sess, patch_embed, cls_pos, x):
     tok.thw, tok.has_cls = (T, H, W), has_cls
     grid = (tok.row_offset(1) if has_cls else tok).as_grid(T, H, W)
     grid.C = Cc
-    E.emit_conv(sess, conv, x, None, L.ACT_NONE, out=grid, y_f32=True, label="patch_embed")
     sep = bool(cls_pos.sep_pos_embed)
 
     def flat(p):
         return sess.add_weight(p.detach().float().reshape(-1, Cc))
 
+    # In the bf16 plan the conv runs on the first-layer kernel, whose fp32 epilogue adds the position tables
+    # (the full table minus its cls row when they are not separable); only the cls row is left to pos_encoding.
+    in_conv = x.ld == 4 and os.environ.get("PV_FUSE_POSENC", "1") != "0"
+    pos = None
+    if in_conv:
+        full = cls_pos.pos_embed_spatial if sep else cls_pos.pos_embed
+        if not sep and has_cls:
+            full = full.detach().float().reshape(-1, Cc)[1:]
+        pos = (flat(full), flat(cls_pos.pos_embed_temporal) if sep else None)
+    E.emit_conv(sess, conv, x, None, L.ACT_NONE, out=grid, y_f32=True, label="patch_embed", pos=pos)
+    if in_conv and not has_cls:
+        return tok
     f = dict(x=tok.ptr, cls_token=flat(cls_pos.cls_token) if has_cls else None,
              pos_spatial=flat(cls_pos.pos_embed_spatial if sep else cls_pos.pos_embed),
              pos_temporal=flat(cls_pos.pos_embed_temporal) if sep else None,
              pos_class=flat(cls_pos.pos_embed_class) if (sep and has_cls) else None,
-             B=x.B, T=T, HW=H * W, C=Cc, ld=tok.ld, dtype=L.PV_F32)
-    sess.add_op(L.OP_POSENC, f, label="pos_encoding", alg_bytes=2 * 4 * x.B * tok.voxels * pad8(Cc))
+             B=x.B, T=T, HW=H * W, C=Cc, ld=tok.ld, dtype=L.PV_F32, cls_only=1 if in_conv else 0)
+    rows = x.B if in_conv else x.B * tok.voxels
+    sess.add_op(L.OP_POSENC, f, label="pos_encoding", alg_bytes=2 * 4 * rows * pad8(Cc))
     return tok
 
 

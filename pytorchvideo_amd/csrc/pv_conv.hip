@@ -349,7 +349,7 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
   if ((d.a_gate || d.a_act != PV_ACT_NONE) && !pw) return PV_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (c4) return pv_stem_c4(d, s);
-  if (d.dwt_w) return PV_ERR_UNSUPPORTED;   // the fused temporal conv exists for the first-layer layout only
+  if (d.dwt_w || d.pos_spatial || d.pos_temporal) return PV_ERR_UNSUPPORTED;   // first-layer layout only
   if (d.dtype == PV_BF16) {
     // PV_CONV_ROUTE (experiments): 1 = prefer the streaming kernel, 2 = prefer the LDS-DMA GEMM, 3 = generic only
     static const int route = getenv("PV_CONV_ROUTE") ? atoi(getenv("PV_CONV_ROUTE")) : 0;

@@ -537,8 +537,8 @@ __global__ __launch_bounds__(kThreads) void posenc_kernel(const pv_posenc_desc d
   long r = id / CG;
   const int has_cls = d.cls_token != nullptr;
   const long rows = (long)d.T * d.HW + has_cls;
-  const int b = (int)(r / rows);
-  const long n = r - (long)b * rows;
+  const int b = d.cls_only ? (int)r : (int)(r / rows);          // cls_only: one work item per (clip, chunk)
+  const long n = d.cls_only ? 0 : r - (long)b * rows;
   T* x = static_cast<T*>(d.x) + ((long)b * rows + n) * d.ld + cg * 8;
   float f[8];
   if (has_cls && n == 0) {
@@ -939,7 +939,8 @@ extern "C" int pv_add_posenc(const pv_posenc_desc* d, pv_stream_t stream) {
   if (!d || !d->x || !d->pos_spatial) return PV_ERR_INVALID;
   if (d->B <= 0 || d->T <= 0 || d->HW <= 0 || d->C <= 0 || d->ld % 8) return PV_ERR_INVALID;
   const long rows = (long)d->T * d->HW + (d->cls_token ? 1 : 0);
-  const long total = (long)d->B * rows * (pv_round_up(d->C, 8) / 8);
+  if (d->cls_only && !d->cls_token) return PV_ERR_INVALID;
+  const long total = (long)d->B * (d->cls_only ? 1 : rows) * (pv_round_up(d->C, 8) / 8);
   dim3 grid(blocks_for(total)), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d->dtype == PV_BF16) hipLaunchKernelGGL(posenc_kernel<bf16_t>, grid, block, 0, s, *d, total);

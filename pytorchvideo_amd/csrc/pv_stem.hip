@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kThreads) void stem_c4_kernel(const pv_conv3d_desc 
   for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const long m_base = ((long)g * 4 + wave) * (TM * 16);
     if (m_base >= M) continue;
-    int vb[TM], vt[TM], vh[TM], vw[TM], vwo[TM];
+    int vb[TM], vt[TM], vh[TM], vw[TM], vwo[TM], vpt[TM], vps[TM];
     long vy[TM];
     bool vok[TM];
 #pragma unroll
@@ -91,6 +91,8 @@ __global__ __launch_bounds__(kThreads) void stem_c4_kernel(const pv_conv3d_desc 
       vh[t] = ho * d.sh - d.ph;
       vw[t] = wo * d.sw - d.pw;
       vwo[t] = wo;
+      vpt[t] = to;
+      vps[t] = d.pos_temporal ? ho * d.Wo + wo : (to * d.Ho + ho) * d.Wo + wo;   // row of the spatial / full table
       vy[t] = b * d.y_bs + (((long)to * d.Ho + ho) * d.Wo + wo) * d.ldy;
     }
     auto load_step = [&](u32x2 (&dst)[TM][2], int ks) {
@@ -182,6 +184,14 @@ __global__ __launch_bounds__(kThreads) void stem_c4_kernel(const pv_conv3d_desc 
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[a][t][j] * sc[j] + sh[j];
         pv_apply_act_n<true>(v, d.act);
+        if (d.pos_spatial != nullptr) {   // position tables of the token stream (fp32 [rows][cout]); wave-uniform branch
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (c0 + j < d.cout) {
+              v[j] += d.pos_spatial[(long)vps[t] * d.cout + c0 + j];
+              if (d.pos_temporal != nullptr) v[j] += d.pos_temporal[(long)vpt[t] * d.cout + c0 + j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (c0 + j >= d.cout) v[j] = 0.f;
@@ -432,6 +442,7 @@ int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s) {
   if (d.ldy % 4 || d.y_bs % 4) return PV_ERR_INVALID;
   const int jp = d.c4_wpair == 2 ? 2 : 1;
   if (d.c4_wpair < 0 || d.c4_wpair > 2 || (jp == 2 && (d.cout > 8 || d.y_f32 || d.dwt_w))) return PV_ERR_UNSUPPORTED;
+  if ((d.pos_spatial || d.pos_temporal) && (!d.pos_spatial || !d.y_f32 || jp == 2 || d.dwt_w)) return PV_ERR_UNSUPPORTED;
   const int KWP = (d.kw + (jp - 1) * d.sw + 1) & ~1;
   const int K = d.kt * d.kh * KWP * 4;
   const int ksteps = (K + 31) / 32;
