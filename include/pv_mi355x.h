@@ -110,6 +110,10 @@ typedef struct pv_conv3d_desc {
    * Tables are fp32 [rows][cout].  The cls row itself is written by pv_add_posenc(cls_only). */
   const float* pos_spatial;
   const float* pos_temporal;
+  /* Dilation of the taps (create_resnet's stage_conv_b_dilation, models/resnet.py:601-1003: the
+   * detection backbone of models/hub/resnet.py:72-88 dilates res5); 0 means 1.  Dense convs only,
+   * not the first-layer layout; kernel extent (k-1)*dilation+1 enters the output-size check. */
+  int32_t dil_t, dil_h, dil_w;
 } pv_conv3d_desc;
 int pv_conv3d(const pv_conv3d_desc* d, pv_stream_t stream);
 /* 1 if this geometry (pointers are ignored) can run with the fused temporal conv, else 0 */

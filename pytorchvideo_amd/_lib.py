@@ -34,7 +34,8 @@ Conv3dDesc = _struct("Conv3dDesc", [
     ("x_bs", _i64), ("y_bs", _i64), ("r_bs", _i64)]
     + _ints("ldx", "ldy", "ldr", "B", "Ti", "Hi", "Wi", "cin", "To", "Ho", "Wo", "cout",
             "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "act", "a_act", "dtype", "y_f32", "r_f32")
-    + [("dwt_w", _p)] + _ints("dwt_k", "c4_wpair") + [("pos_spatial", _p), ("pos_temporal", _p)])
+    + [("dwt_w", _p)] + _ints("dwt_k", "c4_wpair") + [("pos_spatial", _p), ("pos_temporal", _p)]
+    + _ints("dil_t", "dil_h", "dil_w"))
 
 DwConv3dDesc = _struct("DwConv3dDesc", [
     ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("psum", _p),
@@ -125,7 +126,7 @@ _SYMBOLS = [
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _lib = None
 

@@ -82,20 +82,20 @@ def _triple(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
 
 
-def _conv_out(i, k, s, p):
-    return (i + 2 * p - k) // s + 1
+def _conv_out(i, k, s, p, d=1):
+    return (i + 2 * p - ((k - 1) * d + 1)) // s + 1
 
 
 def check_conv3d(conv):
     if not isinstance(conv, nn.Conv3d):
         raise Unsupported("%s is not nn.Conv3d" % _cls_name(conv))
-    if tuple(conv.dilation) != (1, 1, 1):
-        raise Unsupported("dilated conv")
     if conv.padding_mode != "zeros" or isinstance(conv.padding, str):
         raise Unsupported("padding mode")
     depthwise = conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1
     if conv.groups != 1 and not depthwise:
         raise Unsupported("grouped conv (groups=%d)" % conv.groups)
+    if depthwise and tuple(conv.dilation) != (1, 1, 1):
+        raise Unsupported("dilated depthwise conv")
     return depthwise
 
 
@@ -126,7 +126,8 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
     kt, kh, kw = conv.kernel_size
     st, sh, sw = conv.stride
     pt, ph, pw = _triple(conv.padding)
-    To, Ho, Wo = _conv_out(x.T, kt, st, pt), _conv_out(x.H, kh, sh, ph), _conv_out(x.W, kw, sw, pw)
+    dil = tuple(int(v) for v in conv.dilation)
+    To, Ho, Wo = _conv_out(x.T, kt, st, pt, dil[0]), _conv_out(x.H, kh, sh, ph, dil[1]), _conv_out(x.W, kw, sw, pw, dil[2])
     if min(To, Ho, Wo) <= 0:
         raise RuntimeError("conv output would be empty")
     cout, cin_p = conv.out_channels, pad8(x.C)
@@ -179,7 +180,10 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
         kt=kt, kh=kh, kw=kw, st=st, sh=sh, sw=sw, pt=pt, ph=ph, pw=pw,
         act=act, a_act=a_act, dtype=L.PV_F32 if f32_op else sess.pv_dtype, y_f32=1 if (y_f32 and not f32_op) else 0,
         r_f32=1 if (residual is not None and residual.f32 and not f32_op) else 0, c4_wpair=wpair,
+        dil_t=dil[0], dil_h=dil[1], dil_w=dil[2],
     )
+    if dil != (1, 1, 1) and (c4 or dwt is not None):
+        raise Unsupported("dilated first-layer conv")
     if residual is not None and ((residual.B, residual.T, residual.H, residual.W) != (y.B, y.T, y.H, y.W)
                                  or residual.C != cout):
         raise RuntimeError("residual geometry mismatch")

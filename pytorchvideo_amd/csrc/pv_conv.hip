@@ -74,7 +74,9 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const pv_conv3d_de
       const int r = t - dt * d.kh * d.kw;
       const int dh = r / d.kw;
       const int dw = r - dh * d.kw;
-      s_tap[t] = dt | (dh << 8) | (dw << 16);
+      // offsets in voxels: the dilation is folded into the table, the gather loop does not know about it
+      s_tap[t] = (dt * (d.dil_t > 1 ? d.dil_t : 1)) | ((dh * (d.dil_h > 1 ? d.dil_h : 1)) << 8) |
+                 ((dw * (d.dil_w > 1 ? d.dil_w : 1)) << 16);
     }
     __syncthreads();
   }
@@ -341,9 +343,15 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
   if (d.kt < 1 || d.kh < 1 || d.kw < 1 || d.st < 1 || d.sh < 1 || d.sw < 1) return PV_ERR_INVALID;
   const int taps = d.kt * d.kh * d.kw;
   if (taps > kMaxTaps || d.kt > 255 || d.kh > 255 || d.kw > 255) return PV_ERR_UNSUPPORTED;
+  if (d.dil_t < 0 || d.dil_h < 0 || d.dil_w < 0) return PV_ERR_INVALID;
+  const int et = (d.kt - 1) * (d.dil_t > 1 ? d.dil_t : 1) + 1, eh = (d.kh - 1) * (d.dil_h > 1 ? d.dil_h : 1) + 1,
+            ew = (d.kw - 1) * (d.dil_w > 1 ? d.dil_w : 1) + 1;   // kernel extents
+  if (et > 255 || eh > 255 || ew > 255) return PV_ERR_UNSUPPORTED;
+  const bool dilated = et != d.kt || eh != d.kh || ew != d.kw;
+  if (dilated && c4) return PV_ERR_UNSUPPORTED;
   // output geometry must be what nn.Conv3d would produce (RuntimeError in the reference)
-  if ((d.Ti + 2 * d.pt - d.kt) / d.st + 1 != d.To || (d.Hi + 2 * d.ph - d.kh) / d.sh + 1 != d.Ho ||
-      (d.Wi + 2 * d.pw - d.kw) / d.sw + 1 != d.Wo)
+  if ((d.Ti + 2 * d.pt - et) / d.st + 1 != d.To || (d.Hi + 2 * d.ph - eh) / d.sh + 1 != d.Ho ||
+      (d.Wi + 2 * d.pw - ew) / d.sw + 1 != d.Wo)
     return PV_ERR_INVALID;
   const bool pw = taps == 1 && d.st == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.ph == 0 && d.pw == 0;
   if ((d.a_gate || d.a_act != PV_ACT_NONE) && !pw) return PV_ERR_UNSUPPORTED;

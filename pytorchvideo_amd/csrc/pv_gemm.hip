@@ -87,7 +87,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
       const int dt = t / (d.kh * d.kw);
       const int r = t - dt * d.kh * d.kw;
       const int dh = r / d.kw;
-      s_tap[t] = dt | (dh << 8) | ((r - dh * d.kw) << 16);
+      s_tap[t] = (dt * (d.dil_t > 1 ? d.dil_t : 1)) | ((dh * (d.dil_h > 1 ? d.dil_h : 1)) << 8) |
+                 (((r - dh * d.kw) * (d.dil_w > 1 ? d.dil_w : 1)) << 16);   // voxel offsets, dilation folded in
     }
     __syncthreads();
   }

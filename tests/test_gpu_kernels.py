@@ -206,6 +206,36 @@ def test_linear_as_pointwise_conv(dtype, M, K, N, act, res):
     assert rel_err(y, want) <= TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,k,dil,stride", [
+    (64, 64, (1, 3, 3), (1, 2, 2), (1, 1, 1)),      # slow_r50_detection res5 conv_b (LDS-DMA GEMM kernel in bf16)
+    (16, 24, (3, 3, 3), (2, 1, 3), (1, 2, 1)),      # generic kernel, dilation on T and W, stride on H
+    (128, 96, (3, 1, 1), (2, 1, 1), (1, 1, 1)),     # temporal taps two frames apart
+])
+def test_dilated_dense_conv(dtype, cin, cout, k, dil, stride):
+    """nn.Conv3d(dilation=...) as create_resnet's stage_conv_b_dilation builds it (models/resnet.py:780-791)."""
+    B, T, H, W = 2, 5, 11, 13
+    pad = tuple(d * (kk // 2) for d, kk in zip(dil, k))
+    x = _rand((B, T, H, W, cin), 151, dtype)
+    w = _rand((cout, cin) + k, 152, dtype, (cin * k[0] * k[1] * k[2]) ** -0.5)
+    bias = _rand((cout,), 153, torch.float32)
+    want = F.relu(F.conv3d(x.float().permute(0, 4, 1, 2, 3), w.float(), bias, stride=stride, padding=pad, dilation=dil))
+    To, Ho, Wo = want.shape[2:]
+    y = torch.full((B, To, Ho, Wo, cout), 5.0, dtype=dtype, device="cuda")
+    wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous()
+    d = L.Conv3dDesc()
+    d.x, d.w, d.y, d.shift = x.data_ptr(), wp.data_ptr(), y.data_ptr(), bias.data_ptr()
+    d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * cin, To * Ho * Wo * cout, cin, cout
+    d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, cin, To, Ho, Wo, cout
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *stride, *pad)
+    d.dil_t, d.dil_h, d.dil_w = dil
+    d.act, d.a_act, d.dtype = L.ACT_RELU, L.ACT_NONE, pv_dtype(x)
+    call("pv_conv3d", d)
+    assert rel_err(y.permute(0, 4, 1, 2, 3), want) <= TOL[dtype]
+    d.To += 1     # the output size nn.Conv3d would NOT produce is refused
+    assert L.lib().pv_conv3d(C.byref(d), None) == L.PV_ERR_INVALID
+
+
 # ------------------------------------------------------------------ X3D pointwise convs (streaming kernel)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,S,K,N,gate,res", [

@@ -220,8 +220,8 @@ def test_slowfast_variants_match_the_host_mirror(extra, alpha, dtype, tol):
                            stage_spatial_h_stride=(1, 2, 2, 1), stage_spatial_w_stride=(1, 2, 2, 1)), (1, 3, 4, 64, 64)),
 ], ids=["csn_stem_pool", "r2plus1d_short", "resnet_dilated_res5"])
 def test_resnet_family_variants_match_the_host_mirror(factory, cfg, shape, dtype, tol):
-    """Other builders of the family; the dilated res5 (slow_r50_detection's backbone, hub/resnet.py:72-88) is
-    declined per block where a kernel does not cover it and must still give the right answer."""
+    """Other builders of the family, incl. the dilated res5 of slow_r50_detection's backbone (hub/resnet.py:72-88)."""
     import pytorchvideo_amd.models as M
     got, want, dm = _mirror_case(getattr(M, factory), cfg, seeded_input(shape, 6), dtype)
     assert got.shape == want.shape and rel_err(got.float(), want) <= tol
+    assert getattr(dm, "_pv_inputs", None) is not None     # nothing declined: one launch plan
