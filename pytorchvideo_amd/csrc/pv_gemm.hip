@@ -22,6 +22,7 @@
 //     bias, fp32-or-bf16 residual, activation) stays in registers and leaves as 16-byte stores;
 //   * tiles are numbered so that consecutive workgroups (same XCD -> same L2) share the
 //     activation rows and walk the weight panels.
+#include <stdlib.h>
 #include "pv_common.h"
 
 __device__ __attribute__((aligned(16))) unsigned int pv_zero_page[4] = {0u, 0u, 0u, 0u};
@@ -29,7 +30,7 @@ __device__ __attribute__((aligned(16))) unsigned int pv_zero_page[4] = {0u, 0u, 
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int BM = 128;   // voxels per tile
+constexpr int BM = 128;   // voxels per tile (64 in the VT = 1 variant)
 constexpr int BN = 128;   // output channels per tile
 constexpr int kMaxTaps = 512;
 
@@ -55,12 +56,16 @@ struct GemmGeom {   // per-thread staging geometry of one output tile
 // already in flight, and the next tile's address arithmetic is done under the current tile's MFMAs --
 // for the short-K layers of MViT (K = 384: six steps) the per-tile prologue / epilogue is otherwise
 // as long as the K loop itself.
-template <bool PW>
+// VT = voxel tiles (32 rows) per wave: 2 -> 128 x 128 output tiles; 1 -> 64 x 128, for layers whose tile count
+// sits just above a multiple of the resident workgroups (the second, nearly empty round costs a full tile time).
+template <bool PW, int VT>
 __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles,
                                                                 float inv_cin) {
   constexpr int BK = 64;
   constexpr int TILE_ELEMS = 128 * BK;                          // one operand tile (elements)
   constexpr int NJ = TILE_ELEMS * 2 / (kThreads * 16);          // 16-byte items per thread per operand tile (4)
+  constexpr int NJX = NJ * VT / 2;                               // ... of the voxel tile (64 * VT rows)
+  constexpr int BMV = 64 * VT;                                  // voxels per output tile
   constexpr int CPR = BK / 8;                                   // 16-byte chunks per tile row
   // XOR swizzle of the chunk index that makes ds_read_b128 conflict-free (rows are 128 bytes)
   auto swz = [](int row) { return (row >> 1) & 7; };
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
     const int qn = total_tiles >> 3, rn = total_tiles & 7;
     const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
     const int tile_n = tile % tiles_n;
-    gg.m0 = (long)(tile / tiles_n) * BM;
+    gg.m0 = (long)(tile / tiles_n) * BMV;
     gg.n0 = tile_n * BN;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
       const int n = gg.n0 + chi(row);
       gg.w_off[j] = n < d.cout ? (long)n * K : -1;
       const long m = gg.m0 + row;
-      if (m < M) {
+      if (j < NJX && m < M) {
         // M < 2^31 (host check): 32-bit divisions, an order of magnitude cheaper than the 64-bit sequence
         const long b = (long)((unsigned)m / (unsigned)S_out);
         const long sp = m - b * S_out;
@@ -155,6 +160,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
       const bool kok = k < K;
       __builtin_amdgcn_global_load_lds((gptr_t)pick(kok && gg.w_off[j] >= 0, Wt + (gg.w_off[j] >= 0 ? gg.w_off[j] : 0) + k),
                                        (lptr_t)(wb + (j * kThreads + wave * 64) * 8), 16, 0, 0);
+      if (j >= NJX) continue;   // the voxel tile has fewer rows than the filter tile in the VT = 1 variant
       bool xok = kok && gg.x_off[j] >= 0;
       long xo = gg.x_off[j] >= 0 ? gg.x_off[j] : 0;
       if constexpr (PW) {
@@ -171,12 +177,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
   };
 
   // read-side swizzle of this lane's fragment rows (fixed for the whole kernel)
-  int a_row[2], b_row[2];
+  int a_row[2], b_row[VT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    a_row[t] = wn * 64 + t * 32 + l31;
-    b_row[t] = wm * 64 + t * 32 + l31;
-  }
+  for (int t = 0; t < 2; ++t) a_row[t] = wn * 64 + t * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < VT; ++t) b_row[t] = wm * 32 * VT + t * 32 + l31;
   // s_waitcnt simm16 on gfx9: vmcnt = bits [3:0] | [15:14]; expcnt [6:4] and lgkmcnt [11:8] left at "no wait"
   constexpr auto vm = [](int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); };
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -195,11 +200,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
     const bool has_next = it + (int)gridDim.x < total_tiles;
     if (has_next) geom_of(it + gridDim.x, nxt);
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][VT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int v = 0; v < 2; ++v)
+      for (int v = 0; v < VT; ++v)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][v][r] = 0.f;
 
@@ -209,8 +214,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
       if (first_wait_stores) {
         // the LDS-DMA of this step was issued BEFORE the previous tile's stores (in-order return):
         // leave exactly those stores in flight
-        if (d.y_f32) __builtin_amdgcn_s_waitcnt(vm(16));
-        else __builtin_amdgcn_s_waitcnt(vm(8));
+        if (d.y_f32) __builtin_amdgcn_s_waitcnt(vm(8 * VT));
+        else __builtin_amdgcn_s_waitcnt(vm(4 * VT));
         first_wait_stores = false;
       } else {
         __builtin_amdgcn_s_waitcnt(vm(0));
@@ -221,14 +226,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
       const bf16_t* wb = smem + (gs & 1) * 2 * TILE_ELEMS;
       const bf16_t* xb = wb + TILE_ELEMS;
       // fragment reads are software-pipelined one 16-deep sub-step ahead of the MFMAs that use them
-      bf16x8 af[2][2], bfr[2][2];
+      bf16x8 af[2][2], bfr[2][VT];
       auto read_frags = [&](int slot, int s) {
         const int c = 2 * s + hi;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 2; ++t)
           af[slot][t] = *reinterpret_cast<const bf16x8*>(wb + a_row[t] * BK + ((c ^ swz(a_row[t])) << 3));
+#pragma unroll
+        for (int t = 0; t < VT; ++t)
           bfr[slot][t] = *reinterpret_cast<const bf16x8*>(xb + b_row[t] * BK + ((c ^ swz(b_row[t])) << 3));
-        }
       };
       read_frags(0, 0);
 #pragma unroll
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int v = 0; v < 2; ++v)
+          for (int v = 0; v < VT; ++v)
             acc[a][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][a], bfr[s & 1][v], acc[a][v], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
       }
@@ -250,11 +256,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
     // tile's first wait can then be a counted vmcnt that leaves them in flight.
     // every load of the epilogue (residual rows, scale / shift) is consumed before the first store is
     // issued -- a load consumed after a store would make the compiler drain the store queue
-    long e_b[2], e_sp[2];
-    bool e_ok[2];
+    long e_b[VT], e_sp[VT];
+    bool e_ok[VT];
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const long m = cur.m0 + wm * 64 + v * 32 + l31;
+    for (int v = 0; v < VT; ++v) {
+      const long m = cur.m0 + wm * 32 * VT + v * 32 + l31;
       e_ok[v] = m < M;
       const long mm = e_ok[v] ? m : 0;
       e_b[v] = (long)((unsigned)mm / (unsigned)S_out);
@@ -265,10 +271,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const int cb = cur.n0 + wn * 64 + a * 32 + 16 * hi;
-      f32x4 res[2][2][2];   // [v][h8][half]: 8 channels as 2 x f32x4 (fp32) or 1 x 16 bytes (bf16)
+      f32x4 res[VT][2][2];   // [v][h8][half]: 8 channels as 2 x f32x4 (fp32) or 1 x 16 bytes (bf16)
       if (d.residual != nullptr) {
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < VT; ++v)
 #pragma unroll
           for (int h8 = 0; h8 < 2; ++h8) {
             const bool ok = e_ok[v] && cb + h8 * 8 < cout_p8;
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = cb + r < d.cout ? d.scale[cb + r] : 0.f;
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < VT; ++v)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][v][r] *= sc[r];
       }
@@ -300,47 +306,47 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
 #pragma unroll
         for (int r = 0; r < 16; ++r) sh[r] = cb + r < d.cout ? d.shift[cb + r] : 0.f;
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < VT; ++v)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][v][r] += sh[r];
       }
       if (d.residual != nullptr) {
         if (d.r_f32) {
 #pragma unroll
-          for (int v = 0; v < 2; ++v)
+          for (int v = 0; v < VT; ++v)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][v][r] += res[v][r >> 3][(r >> 2) & 1][r & 3];
         } else {
 #pragma unroll
-          for (int v = 0; v < 2; ++v)
+          for (int v = 0; v < VT; ++v)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][v][r] += (float)__builtin_bit_cast(bf16x8, res[v][r >> 3][0])[r & 7];
         }
       }
       if (d.act == PV_ACT_RELU) {
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < VT; ++v)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][v][r] = fmaxf(acc[a][v][r], 0.f);
       } else if (d.act == PV_ACT_GELU) {
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < VT; ++v)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][v][r] = pv_gelu_fast(acc[a][v][r]);
       } else if (d.act == PV_ACT_SWISH) {
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < VT; ++v)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][v][r] *= pv_sigmoid(acc[a][v][r]);
       } else if (d.act == PV_ACT_SIGMOID) {
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < VT; ++v)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][v][r] = pv_sigmoid(acc[a][v][r]);
       }
       if (cb + 16 > d.cout) {   // ragged last channel tile: the padding up to the 8-multiple is written as zeros
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < VT; ++v)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][v][r] = cb + r < d.cout ? acc[a][v][r] : 0.f;
       }
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
     for (int a = 0; a < 2; ++a) {
       const int cb = cur.n0 + wn * 64 + a * 32 + 16 * hi;
 #pragma unroll
-      for (int v = 0; v < 2; ++v) {
+      for (int v = 0; v < VT; ++v) {
         const unsigned yo = (unsigned)(e_b[v] * d.y_bs + e_sp[v] * d.ldy + cb);   // elements (< 2^31 bytes: host check)
 #pragma unroll
         for (int h8 = 0; h8 < 2; ++h8) {
@@ -388,17 +394,29 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   if (taps > kMaxTaps || d.kt > 255 || d.kh > 255 || d.kw > 255) return PV_ERR_UNSUPPORTED;
   const long M = (long)d.B * d.To * d.Ho * d.Wo;
   const int cout_p8 = pv_round_up(d.cout, 8);
-  const long tiles_m = pv_ceil_div(M, BM);
   const int tiles_n = (int)pv_ceil_div(cout_p8, BN);
+  // two persistent workgroups per CU (64 KB of LDS each)
+  const long resident = 2 * 256;
+  // 64-row tiles only where 128-row tiles leave more than half of the resident slots empty (one workgroup on
+  // fewer than every CU): there the halved tiles double the parallelism for free.  Measured on one box: choosing
+  // them whenever they pack the rounds better costs MViT-B 4 % (a 64-row tile re-stages the same 128-row filter
+  // tile for half the MFMA work); this rule gains SlowFast-R50 1.4 % and MViT-B 0.7 %.
+  const long t128 = pv_ceil_div(M, 128) * tiles_n;
+  static const int force_vt = getenv("PV_GEMM_VT") ? atoi(getenv("PV_GEMM_VT")) : 0;
+  const int vt = force_vt ? force_vt : (2 * t128 <= resident ? 1 : 2);
+  const long tiles_m = pv_ceil_div(M, 64 * vt);
   const long total = tiles_m * tiles_n;
   if (total <= 0 || total > 0x7fffffffL || M > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
   if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return PV_ERR_UNSUPPORTED;   // 31-bit buffer offsets
   const float inv_cin = 1.0f / (float)d.cin;
-  // two persistent workgroups per CU (64 KB of LDS each), in multiples of the 8 XCDs
-  const long resident = 2 * 256;
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads);
-  if (pw) hipLaunchKernelGGL(gemm_glds_kernel<true>, grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-  else hipLaunchKernelGGL(gemm_glds_kernel<false>, grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+  if (vt == 1) {
+    if (pw) hipLaunchKernelGGL((gemm_glds_kernel<true, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+    else hipLaunchKernelGGL((gemm_glds_kernel<false, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+  } else {
+    if (pw) hipLaunchKernelGGL((gemm_glds_kernel<true, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+    else hipLaunchKernelGGL((gemm_glds_kernel<false, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+  }
   PV_LAUNCH_CHECK();
   return PV_OK;
 }
