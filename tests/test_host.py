@@ -112,3 +112,54 @@ def test_block_wrapper_resolves_class_level_helpers_of_the_adopted_module():
         transmute_model(m, "mi355x")
         assert type(m.blocks[0]).__name__ == "Mi355xMViTBlock"
         assert torch.equal(m(x), want)      # original form of the transmuted model: same function
+
+
+def _plan_labels_and_fields(model, sizes, mvit_input=None):
+    """Build the launch plan on the host (no GPU needed until finalize) and return [(label, fields)]."""
+    from pytorchvideo_amd.accelerator.mi355x import conversion as CV
+    transmute_model(model, "mi355x")
+    sess = Session(dtype=torch.bfloat16)
+    if mvit_input is not None:
+        assert CV._is_fusable_mvit(model, mvit_input)
+        assert CV._try_fuse_mvit(model, sess, torch.bfloat16, mvit_input)
+    else:
+        cur = None
+        for i, b in enumerate(model.blocks):
+            b.convert(sizes if i == 0 else None, session=sess, input_ref=cur)
+            cur = b._out_ref
+    return [(o[3], o[2]) for o in sess.ops]
+
+
+def test_slowfast_plan_uses_the_first_layer_layout_and_zero_copy_fusion():
+    from pytorchvideo_amd.models import create_slowfast
+    m = create_slowfast(model_depth=18, model_num_class=7, head_pool_kernel_sizes=((2, 2, 2), (8, 2, 2))).eval()
+    ops = _plan_labels_and_fields(m, [(2, 3, 2, 64, 64), (2, 3, 8, 64, 64)])
+    stems = [f for l, f in ops if l.startswith("stem.conv")]
+    assert len(stems) == 2 and all(f["cin"] == 4 and f["ldx"] == 4 for f in stems)        # RGB in the 4-channel layout
+    fast = [f for f in stems if f["cout"] == 8][0]
+    assert fast["c4_wpair"] == 2                                                           # two outputs per MFMA column
+    laterals = [f for l, f in ops if l.startswith("lateral_fuse")]
+    assert len(laterals) == 4
+    # the lateral conv writes into the slow buffer's channel slice: its row stride is wider than its channel count
+    assert all(f["ldy"] > f["cout"] for f in laterals)
+    assert not any(l.startswith("cat") for l, _ in ops)
+
+
+def test_mvit_plan_fuses_kv_pooling_and_position_tables():
+    from pytorchvideo_amd.models import create_multiscale_vision_transformers as create
+    from pytorchvideo_amd.models.hub import mvit_video_base_config
+    cfg = dict(mvit_video_base_config, temporal_size=4, spatial_size=64, head_num_classes=5)
+    m = create(**cfg).eval()
+    x = torch.zeros(8, 3, 4, 64, 64, dtype=torch.bfloat16)
+    ops = _plan_labels_and_fields(m, None, mvit_input=x)
+    labels = [l.split("|")[0] for l, _ in ops]
+    patch = [f for l, f in ops if l.startswith("patch_embed")][0]
+    assert patch["pos_spatial"] is not None and patch["pos_temporal"] is not None and patch["y_f32"] == 1
+    pos = [f for l, f in ops if l == "pos_encoding"][0]
+    assert pos["cls_only"] == 1
+    assert labels.count("attn.qkv") == 16 and labels.count("attn.core") == 16            # one fused q|k|v GEMM per block
+    assert labels.count("attn.pool_k") + labels.count("attn.pool_v") <= 2 * 16
+    # every stream-producing GEMM keeps the residual stream in fp32
+    assert all(f["y_f32"] == 1 for l, f in ops if l.split("|")[0] in ("attn.proj", "mlp.fc2"))
+    # small token grids: q, k and v of a block are pooled (conv + cls + LayerNorm) by ONE launch
+    assert labels.count("attn.pool_qkv") >= 14 and not any(l.endswith(".norm") and "pool" in l for l in labels)
