@@ -114,10 +114,23 @@ typedef struct pv_conv3d_desc {
    * detection backbone of models/hub/resnet.py:72-88 dilates res5); 0 means 1.  Dense convs only,
    * not the first-layer layout; kernel extent (k-1)*dilation+1 enters the output-size check. */
   int32_t dil_t, dil_h, dil_w;
+  /* Optional second operand concatenated along K -- the projection shortcut of a residual block
+   * (models/resnet.py:428-438 built, :1179-1189 added) folded into conv_c:
+   *   y = act(scale * (W1 . x) + x2_scale * (W2 . x2s) + shift),  x2s[b][to][ho][wo] = x2[b][to*x2_st][ho*x2_sh][wo*x2_sw]
+   * (the shortcut's strided 1x1x1 conv).  Weights [cout][round_up(cin,32) + round_up(x2_cin,32)], both parts
+   * zero padded.  The two products are accumulated separately and joined in the epilogue, so the folded BatchNorm
+   * scales stay fp32 exactly as in the unfused pair (shift = the two shifts added).  a_gate / a_act apply to the
+   * first operand only.  Pointwise convs where pv_conv3d_x2_supported(d) is 1. */
+  const void* x2;
+  const float* x2_scale;     /* [cout] or NULL (=1) */
+  int64_t x2_bs;
+  int32_t x2_ld, x2_cin, x2_Hi, x2_Wi, x2_st, x2_sh, x2_sw;
 } pv_conv3d_desc;
 int pv_conv3d(const pv_conv3d_desc* d, pv_stream_t stream);
 /* 1 if this geometry (pointers are ignored) can run with the fused temporal conv, else 0 */
 int pv_conv3d_dwt_supported(const pv_conv3d_desc* d);
+/* 1 if this geometry (pointers are ignored; x2_cin > 0) can run with the second K operand, else 0 */
+int pv_conv3d_x2_supported(const pv_conv3d_desc* d);
 
 /* ---- depthwise convolution ---------------------------------------------------------
  * Replaces nn.Conv3d(groups=C) [+ BatchNorm3d eval][+ activation]:

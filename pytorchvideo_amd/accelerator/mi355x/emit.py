@@ -111,8 +111,43 @@ def is_add_fusion(fn):
 
 
 # --------------------------------------------------------------------------- conv family
+def _shortcut_geometry(conv_s, x2, out_thw):
+    """Strides of a projection shortcut (1x1x1, no padding) if it maps x2 onto the `out_thw` grid, else None."""
+    if not isinstance(conv_s, nn.Conv3d) or conv_s.kernel_size != (1, 1, 1) or _triple(conv_s.padding) != (0, 0, 0):
+        return None
+    if conv_s.groups != 1 or conv_s.bias is not None or tuple(conv_s.dilation) != (1, 1, 1) or conv_s.in_channels != x2.C:
+        return None
+    st = tuple(int(v) for v in conv_s.stride)
+    if tuple((i - 1) // s + 1 for i, s in zip((x2.T, x2.H, x2.W), st)) != tuple(out_thw):
+        return None
+    return st
+
+
+def can_fold_shortcut(sess, conv_c, conv_s, x2, cin_c):
+    """True when the projection shortcut `conv_s(x2)` can ride in the pointwise conv_c as a second K operand
+    (csrc/pv_pwconv.hip); decided by the library from the geometry.  `cin_c`: conv_c's input channels."""
+    if os.environ.get("PV_FUSE_SHORTCUT", "1") == "0" or sess.itemsize != 2 or x2.f32:
+        return False
+    if not isinstance(conv_c, nn.Conv3d) or not isinstance(conv_s, nn.Conv3d):
+        return False
+    if conv_c.kernel_size != (1, 1, 1) or conv_c.stride != (1, 1, 1) or _triple(conv_c.padding) != (0, 0, 0) \
+            or conv_c.groups != 1 or conv_c.out_channels != conv_s.out_channels:
+        return False
+    st = tuple(int(v) for v in conv_s.stride)
+    out_thw = tuple((i - 1) // s + 1 for i, s in zip((x2.T, x2.H, x2.W), st))
+    if _shortcut_geometry(conv_s, x2, out_thw) is None:
+        return False
+    d = L.Conv3dDesc()
+    d.B, d.To, d.Ho, d.Wo = x2.B, out_thw[0], out_thw[1], out_thw[2]
+    d.Ti, d.Hi, d.Wi = out_thw
+    d.cin, d.cout, d.dtype = pad8(cin_c), conv_c.out_channels, sess.pv_dtype
+    d.kt = d.kh = d.kw = d.st = d.sh = d.sw = 1
+    d.x2_cin, d.x2_ld, d.x2_st, d.x2_sh, d.x2_sw = pad8(x2.C), x2.ld, st[0], st[1], st[2]
+    return L.lib().pv_conv3d_x2_supported(C.byref(d)) == 1
+
+
 def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=None, a_act=L.ACT_NONE,
-              out=None, y_f32=False, label="conv", dwt=None, pos=None):
+              out=None, y_f32=False, label="conv", dwt=None, pos=None, shortcut=None):
     """Dense Conv3d (+BN +bias +residual +act) -> pv_conv3d, or depthwise -> pv_dwconv3d.
     `dwt`: a depthwise temporal Conv3d (k,1,1) applied to the conv's output before norm/act inside the
     same launch (X3D stem; only where can_fuse_temporal_dw said so)."""
@@ -168,6 +203,22 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
     bias = conv.bias if dwt is None else dwt.bias
     scale, shift = fold_norm(norm, cout, bias)
     has_affine = norm is not None and not isinstance(norm, nn.Identity)
+    x2 = None
+    if shortcut is not None:
+        # (conv_s, norm_s, x2): the projection shortcut as a second K operand.  The kernel accumulates the two
+        # products separately and joins them with their own fp32 BatchNorm scales; the shifts add up.
+        conv_s, norm_s, x2 = shortcut
+        st2 = _shortcut_geometry(conv_s, x2, (To, Ho, Wo))
+        if st2 is None or c4 or residual is not None or y_f32 or f32_op or (kt, kh, kw, st, sh, sw) != (1,) * 6:
+            raise Unsupported("shortcut folding")
+        scale2, shift2 = fold_norm(norm_s, cout, None)
+        k1, k2 = (x.C + 31) // 32 * 32, (x2.C + 31) // 32 * 32
+        wcat = torch.zeros(cout, k1 + k2, dtype=torch.float32)
+        wcat[:, : x.C] = w.reshape(cout, x.C)
+        wcat[:, k1: k1 + x2.C] = conv_s.weight.detach().float().cpu().reshape(cout, x2.C)
+        wp = wcat.to(sess.dtype)
+        shift = shift + shift2
+        has_affine2 = norm_s is not None and not isinstance(norm_s, nn.Identity)
     f = dict(
         x=x.ptr, w=sess.add_weight(wp), y=y.ptr,
         scale=sess.add_weight(scale) if has_affine else None,
@@ -182,6 +233,10 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
         r_f32=1 if (residual is not None and residual.f32 and not f32_op) else 0, c4_wpair=wpair,
         dil_t=dil[0], dil_h=dil[1], dil_w=dil[2],
     )
+    if x2 is not None:
+        f.update(shift=sess.add_weight(shift), x2_scale=sess.add_weight(scale2) if has_affine2 else None,
+                 x2=x2.ptr, x2_bs=x2.bs, x2_ld=x2.ld, x2_cin=pad8(x2.C),
+                 x2_Hi=x2.H, x2_Wi=x2.W, x2_st=st2[0], x2_sh=st2[1], x2_sw=st2[2])
     if dil != (1, 1, 1) and (c4 or dwt is not None):
         raise Unsupported("dilated first-layer conv")
     if residual is not None and ((residual.B, residual.T, residual.H, residual.W) != (y.B, y.T, y.H, y.W)
@@ -208,6 +263,10 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
     if dwt is not None:
         flops += 2 * vox_out * cout * dwt.kernel_size[0]
         detail += "+k%dx1x1" % dwt.kernel_size[0]
+    if x2 is not None:
+        alg += sess.itemsize * (vox_out * pad8(x2.C) + cout * x2.C)
+        flops += 2 * vox_out * cout * x2.C
+        detail += " +shortcut c%d" % x2.C
     sess.add_op(L.OP_CONV3D, f, label=label + detail, alg_bytes=alg, flops=flops)
     return y
 
@@ -475,7 +534,7 @@ def emit_conv_b(sess, conv_b, x, norm_b, act_b, producer=None):
     return y, None, L.ACT_NONE
 
 
-def emit_bottleneck(sess, bb, x, residual=None, final_act=L.ACT_NONE, out=None):
+def emit_bottleneck(sess, bb, x, residual=None, final_act=L.ACT_NONE, out=None, shortcut=None):
     """BottleneckBlock.forward (resnet.py:1345-1365) with the block's residual join and
     final activation fused into conv_c's epilogue."""
     for name in ("conv_a", "conv_b", "conv_c"):
@@ -494,7 +553,7 @@ def emit_bottleneck(sess, bb, x, residual=None, final_act=L.ACT_NONE, out=None):
             (bb.conv_c.kernel_size != (1, 1, 1) or bb.conv_c.stride != (1, 1, 1) or _triple(bb.conv_c.padding) != (0, 0, 0)):
         raise Unsupported("SE block whose conv_c is not pointwise")
     c = emit_conv(sess, bb.conv_c, b, bb.norm_c, final_act, residual=residual, a_gate=gate, a_act=deferred,
-                  out=out, label="conv_c")
+                  out=out, label="conv_c", shortcut=shortcut)
     sess.release(b)
     if gate is not None:
         sess.release(gate)
@@ -507,6 +566,12 @@ def emit_res_block(sess, rb, x, out=None):
         raise Unsupported("branch_fusion is not a sum")
     if _cls_name(rb.branch2) != "BottleneckBlock":
         raise Unsupported("branch2 is %s" % _cls_name(rb.branch2))
+    bb = rb.branch2
+    if rb.branch1_conv is not None and isinstance(getattr(bb, "conv_c", None), nn.Conv3d) \
+            and can_fold_shortcut(sess, bb.conv_c, rb.branch1_conv, x, bb.conv_c.in_channels):
+        # the projection shortcut rides in conv_c as a second K operand: no launch, no round trip of its output
+        return emit_bottleneck(sess, bb, x, residual=None, final_act=act_code(rb.activation), out=out,
+                               shortcut=(rb.branch1_conv, rb.branch1_norm, x))
     if rb.branch1_conv is None:
         shortcut = x
     else:

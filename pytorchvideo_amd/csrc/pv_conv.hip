@@ -21,6 +21,7 @@ int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s);      // pv_pwc
 int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);  // pv_gemm.hip
 int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s);                 // pv_stem.hip
 int pv_stem_dwt_supported(const pv_conv3d_desc& d);                     // pv_stem.hip
+int pv_pwconv_x2_supported(const pv_conv3d_desc& d);                    // pv_pwconv.hip
 
 namespace {
 
@@ -331,6 +332,12 @@ extern "C" int pv_conv3d_dwt_supported(const pv_conv3d_desc* d) {
   return pv_stem_dwt_supported(*d);
 }
 
+extern "C" int pv_conv3d_x2_supported(const pv_conv3d_desc* d) {
+  if (!d || d->B <= 0 || d->cout <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
+  if (d->kt * d->kh * d->kw != 1 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt || d->ph || d->pw) return 0;
+  return pv_pwconv_x2_supported(*d);
+}
+
 extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
   if (!dp) return PV_ERR_INVALID;
   const pv_conv3d_desc& d = *dp;
@@ -358,6 +365,10 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (c4) return pv_stem_c4(d, s);
   if (d.dwt_w || d.pos_spatial || d.pos_temporal) return PV_ERR_UNSUPPORTED;   // first-layer layout only
+  if (d.x2) {   // second K operand: streaming pointwise kernel only, no fallback
+    if (!pw || d.dtype != PV_BF16 || !pv_pwconv_x2_supported(d)) return PV_ERR_UNSUPPORTED;
+    return pv_pwconv_stream_try(d, s);
+  }
   if (d.dtype == PV_BF16) {
     // PV_CONV_ROUTE (experiments): 1 = prefer the streaming kernel, 2 = prefer the LDS-DMA GEMM, 3 = generic only
     static const int route = getenv("PV_CONV_ROUTE") ? atoi(getenv("PV_CONV_ROUTE")) : 0;

@@ -28,10 +28,13 @@ constexpr int kKC = 1;  // k-steps (of 32 channels) per register chunk
 struct PwRows {  // per-lane geometry of one wave tile group: clip index and voxel within the clip (-1: none)
   int b[4];
   int sp[4];
+  int sp2[4];   // voxel of the second operand (strided sampling of x2), X2V kernels only
 };
 
-template <int NT, int TM, bool XFORM, int KS, bool F32>
-__global__ __launch_bounds__(kThreads, KS >= 14 ? 2 : ((NT >= 4 || KS >= 4) ? 3 : 4)) void pw_stream_kernel(const pv_conv3d_desc d, int ksteps_rt, int ngroups,
+// X2V: compiled with the second K operand (projection shortcut folded into conv_c); a separate variant so that
+// the common kernels do not carry its registers
+template <int NT, int TM, bool XFORM, int KS, bool F32, bool X2V>
+__global__ __launch_bounds__(kThreads, (KS >= 14 || X2V) ? 2 : ((NT >= 4 || KS >= 4) ? 3 : 4)) void pw_stream_kernel(const pv_conv3d_desc d, int ksteps_rt, int ngroups,
                                                                 int nchunks, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ksteps = KS > 0 ? KS : ksteps_rt;
@@ -40,7 +43,8 @@ __global__ __launch_bounds__(kThreads, KS >= 14 ? 2 : ((NT >= 4 || KS >= 4) ? 3 
   bf16_t* w_s = reinterpret_cast<bf16_t*>(smem_raw);
   float* sc_s = reinterpret_cast<float*>(smem_raw + (size_t)NT * 16 * WLD * 2);
   float* sh_s = sc_s + NT * 16;
-  float* gate_s = sh_s + NT * 16;  // [4 waves][2][cin]
+  float* sc2_s = sh_s + NT * 16;                    // X2V only: scale of the second operand's product
+  float* gate_s = sh_s + NT * 16 * (X2V ? 2 : 1);   // [4 waves][2][cin]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -60,12 +64,13 @@ __global__ __launch_bounds__(kThreads, KS >= 14 ? 2 : ((NT >= 4 || KS >= 4) ? 3 
   {
     const bf16_t* __restrict__ Wt = static_cast<const bf16_t*>(d.w);
     const int cpr = Kp / 8;  // chunks per row
+    const int w_pitch = X2V ? Kp : d.cin;   // two operands: rows are packed at the padded K
     for (int id = tid; id < NT * 16 * cpr; id += kThreads) {
       const int r = id / cpr, kc = id - r * cpr;
       const int tn = r >> 4, ii = r & 15;
       const int c = n0 + (tn >> 1) * 32 + (ii >> 2) * 8 + (tn & 1) * 4 + (ii & 3);
       bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (c < d.cout && kc * 8 < d.cin) v = *reinterpret_cast<const bf16x8*>(Wt + (long)c * d.cin + kc * 8);
+      if (c < d.cout && kc * 8 < w_pitch) v = *reinterpret_cast<const bf16x8*>(Wt + (long)c * w_pitch + kc * 8);
       *reinterpret_cast<bf16x8*>(w_s + r * WLD + kc * 8) = v;
     }
     for (int i = tid; i < NT * 16; i += kThreads) {
@@ -73,11 +78,14 @@ __global__ __launch_bounds__(kThreads, KS >= 14 ? 2 : ((NT >= 4 || KS >= 4) ? 3 
       const bool ok = c < d.cout;
       sc_s[i] = ok ? (d.scale ? d.scale[c] : 1.f) : 0.f;
       sh_s[i] = ok ? (d.shift ? d.shift[c] : 0.f) : 0.f;
+      if constexpr (X2V) sc2_s[i] = ok ? (d.x2_scale ? d.x2_scale[c] : 1.f) : 0.f;
     }
   }
   __syncthreads();
 
   const bf16_t* __restrict__ X = static_cast<const bf16_t*>(d.x);
+  const bf16_t* __restrict__ X2 = X2V ? static_cast<const bf16_t*>(d.x2) : nullptr;
+  const int ks1 = X2V ? (d.cin + 31) / 32 : 1 << 20;   // k-steps [ks1, ..) read the second operand
   const bool has_gate = XFORM && d.a_gate != nullptr;
   const bool has_res = d.residual != nullptr;
   float* my_gate = gate_s + wave * 2 * d.cin;
@@ -96,11 +104,27 @@ __global__ __launch_bounds__(kThreads, KS >= 14 ? 2 : ((NT >= 4 || KS >= 4) ? 3 
       const long b = mm / S_out;
       r.b[t] = (int)b;
       r.sp[t] = ok ? (int)(mm - b * S_out) : -1;
+      if constexpr (X2V) {
+        const int sp = ok ? r.sp[t] : 0;
+        const int to = sp / (d.Ho * d.Wo), r2 = sp - to * d.Ho * d.Wo;
+        const int ho = r2 / d.Wo, wo = r2 - ho * d.Wo;
+        r.sp2[t] = ((to * d.x2_st) * d.x2_Hi + ho * d.x2_sh) * d.x2_Wi + wo * d.x2_sw;
+      }
     }
   };
   auto load_x = [&](bf16x8 (&dst)[KSR][TM], const PwRows& r, int ks0) {
 #pragma unroll
     for (int kk = 0; kk < KSR; ++kk) {
+      if (X2V && ks0 + kk >= ks1) {   // second operand (wave-uniform): channel k2 of the strided x2 voxel
+        const int k2 = (ks0 + kk - ks1) * 32 + q * 8;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          if (r.sp[t] >= 0 && k2 < d.x2_cin)
+            dst[kk][t] = *reinterpret_cast<const bf16x8*>(X2 + (long)r.b[t] * d.x2_bs + (long)r.sp2[t] * d.x2_ld + k2);
+          else dst[kk][t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        continue;
+      }
       const int k0 = (ks0 + kk) * 32 + q * 8;
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
@@ -133,6 +157,7 @@ __global__ __launch_bounds__(kThreads, KS >= 14 ? 2 : ((NT >= 4 || KS >= 4) ? 3 
   auto xform = [&](bf16x8 (&src)[KSR][TM], const PwRows& r, int ks0) {
 #pragma unroll
     for (int kk = 0; kk < KSR; ++kk) {
+      if (X2V && ks0 + kk >= ks1) continue;   // gate and activation belong to the first operand only
       const int k0 = (ks0 + kk) * 32 + q * 8;
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
@@ -156,9 +181,24 @@ __global__ __launch_bounds__(kThreads, KS >= 14 ? 2 : ((NT >= 4 || KS >= 4) ? 3 
   // group loop (what LICM would do) costs more registers than the kernel has, so the LDS offset is made
   // opaque once per group and the reads stay where they are used.
   int w_opaque = 0;
+  f32x4 acc2[X2V ? NT : 1][X2V ? TM : 1];   // X2V: the second operand's product, joined in the epilogue
   auto mma = [&](f32x4 (&acc)[NT][TM], const bf16x8 (&src)[KSR][TM], int ks0) {
 #pragma unroll
     for (int kk = 0; kk < KSR; ++kk) {
+      if constexpr (X2V) {
+        if (ks0 + kk >= ks1) {   // wave-uniform
+#pragma unroll
+          for (int a = 0; a < NT; ++a) {
+            if ((a >> 1) < live_pairs) {
+              const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w_s + (a * 16 + n16) * WLD + (ks0 + kk) * 32 + q * 8);
+#pragma unroll
+              for (int t = 0; t < TM; ++t)
+                acc2[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, src[kk][t], acc2[a][t], 0, 0, 0);
+            }
+          }
+          continue;
+        }
+      }
       // long reductions: keep step kk's filter reads behind step kk-1's (the scheduler otherwise clusters
       // all NT x KS LDS reads at the top of the group and spills hundreds of registers)
       if (NT * KSR > 8) asm volatile("" : "+v"(w_opaque));
@@ -198,6 +238,12 @@ __global__ __launch_bounds__(kThreads, KS >= 14 ? 2 : ((NT >= 4 || KS >= 4) ? 3 
     for (int a = 0; a < NT; ++a)
 #pragma unroll
       for (int t = 0; t < TM; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (X2V) {
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int t = 0; t < TM; ++t) acc2[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     refresh_gate(g);
     rows_of(g + nchunks, nxt);
     asm volatile("" : "+v"(w_opaque));
@@ -237,6 +283,14 @@ __global__ __launch_bounds__(kThreads, KS >= 14 ? 2 : ((NT >= 4 || KS >= 4) ? 3 
           v[j] = acc[2 * p][t][j] * s0[j] + h0[j];
           v[4 + j] = acc[2 * p + 1][t][j] * s1[j] + h1[j];
         }
+        if constexpr (X2V) {
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(sc2_s + cl), t1 = *reinterpret_cast<const f32x4*>(sc2_s + cl + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] += acc2[2 * p][t][j] * t0[j];
+            v[4 + j] += acc2[2 * p + 1][t][j] * t1[j];
+          }
+        }
         if (has_res) {
           if constexpr (F32) {
 #pragma unroll
@@ -275,7 +329,28 @@ int launch_pw_f(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) 
   const long ngroups = pv_ceil_div(M, 4 * TM * 16);
   const int nsplit = (int)pv_ceil_div(pv_round_up(d.cout, 8), NT * 16);
   if (ngroups > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
-  auto kern = pw_stream_kernel<NT, TM, XFORM, KS, F32>;
+  if (d.x2 != nullptr) {   // second K operand: the variants the residual blocks of X3D / ResNets need
+    if constexpr (!F32 && (KS == 0 || KS == 3)) {
+      const long M2 = (long)d.B * d.To * d.Ho * d.Wo;
+      const long ngroups2 = pv_ceil_div(M2, 4 * TM * 16);
+      const int nsplit2 = (int)pv_ceil_div(pv_round_up(d.cout, 8), NT * 16);
+      if (ngroups2 > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
+      auto kern2 = pw_stream_kernel<NT, TM, XFORM, KS, false, true>;
+      if (lds > 64 * 1024)
+        PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const long per_cu2 = lds > 0 ? (160 * 1024) / (long)(lds + 1024) : 4;
+      const long resident2 = 256 * (per_cu2 < 1 ? 1 : (per_cu2 > 4 ? 4 : per_cu2));
+      long nchunks2 = pv_ceil_div(resident2, nsplit2);
+      if (nchunks2 > ngroups2) nchunks2 = ngroups2;
+      const long blocks2 = pv_ceil_div(nchunks2, 8) * 8 * nsplit2;
+      hipLaunchKernelGGL(kern2, dim3((unsigned)blocks2), dim3(kThreads), lds, s, d, ksteps, (int)ngroups2, (int)nchunks2, nsplit2);
+      PV_LAUNCH_CHECK();
+      return PV_OK;
+    } else {
+      return PV_ERR_UNSUPPORTED;
+    }
+  }
+  auto kern = pw_stream_kernel<NT, TM, XFORM, KS, F32, false>;
   if (lds > 64 * 1024)
     PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // one resident generation of workgroups (what LDS and the 4-waves-per-SIMD register budget admit
@@ -302,6 +377,7 @@ int launch_pw_k(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) 
 template <int NT, int TM, bool XFORM>
 int launch_pw_x(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) {
   // whole-K register residency (with cross-group prefetch) only where it does not spill
+  if (d.x2 != nullptr && ksteps != 3) return launch_pw_k<NT, TM, XFORM, 0>(d, ksteps, lds, s);   // two-operand variants: KS 3 and generic
   if (ksteps == 1) return launch_pw_k<NT, TM, XFORM, 1>(d, ksteps, lds, s);
   if (ksteps == 2) return launch_pw_k<NT, TM, XFORM, 2>(d, ksteps, lds, s);
   if (ksteps == 3) return launch_pw_k<NT, TM, XFORM, 3>(d, ksteps, lds, s);
@@ -321,6 +397,20 @@ int launch_pw(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) {
 
 }  // namespace
 
+// Geometry-only test for the second K operand (pointers ignored; a squeeze-excitation gate is assumed
+// present, which is the larger LDS footprint).
+int pv_pwconv_x2_supported(const pv_conv3d_desc& d) {
+  if (d.dtype != PV_BF16 || d.y_f32 || d.cin <= 0 || d.cin % 8) return 0;
+  if (d.x2_cin <= 0 || d.x2_cin % 8 || d.x2_ld < d.x2_cin || d.x2_st < 1 || d.x2_sh < 1 || d.x2_sw < 1) return 0;
+  if ((long)d.To * d.Ho * d.Wo < 64) return 0;
+  const int ksteps = (d.cin + 31) / 32 + (d.x2_cin + 31) / 32;
+  if (ksteps > 8) return 0;
+  const int cout_p8 = pv_round_up(d.cout, 8);
+  const int NT = cout_p8 <= 32 ? 2 : (cout_p8 <= 64 ? 4 : 8);
+  const size_t lds = (size_t)NT * 16 * (ksteps * 32 + 8) * 2 + (size_t)3 * NT * 16 * 4 + (size_t)4 * 2 * d.cin * 4;
+  return lds <= 96 * 1024;
+}
+
 // Returns PV_OK when the streaming kernel took the op, PV_ERR_UNSUPPORTED to let the caller
 // fall back to the generic implicit-GEMM kernel.
 int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s) {
@@ -331,10 +421,12 @@ int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s) {
   const long S_out = (long)d.To * d.Ho * d.Wo;
   if (d.a_gate && S_out < 64) return PV_ERR_UNSUPPORTED;  // a 64-voxel wave tile must span <= 2 clips
   const int cout_p8 = pv_round_up(d.cout, 8);
-  const int ksteps = (d.cin + 31) / 32;
+  if (d.x2 && (d.x2_cin <= 0 || d.x2_cin % 8 || d.x2_ld < d.x2_cin || d.x2_st < 1 || d.x2_sh < 1 || d.x2_sw < 1 || d.y_f32))
+    return PV_ERR_UNSUPPORTED;
+  const int ksteps = (d.cin + 31) / 32 + (d.x2 ? (d.x2_cin + 31) / 32 : 0);
   if (ksteps > 8 && ksteps != 14) return PV_ERR_UNSUPPORTED;
   int NT = cout_p8 <= 32 ? 2 : (cout_p8 <= 64 ? 4 : 8);
-  const size_t lds = (size_t)NT * 16 * (ksteps * 32 + 8) * 2 + (size_t)2 * NT * 16 * 4 +
+  const size_t lds = (size_t)NT * 16 * (ksteps * 32 + 8) * 2 + (size_t)(d.x2 ? 3 : 2) * NT * 16 * 4 +
                      (d.a_gate ? (size_t)4 * 2 * d.cin * 4 : 0);
   if (lds > 96 * 1024) return PV_ERR_UNSUPPORTED;
   if (NT == 2) return launch_pw<2, 2>(d, ksteps, lds, s);

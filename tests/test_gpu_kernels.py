@@ -438,6 +438,56 @@ def test_depthwise_3x3x3_plane_kernel_with_se_partial_sums(B, T, H, W, Cc, strid
     assert rel_err(got_mean, pre.mean(dim=[2, 3, 4])) <= 1e-3   # sums are fp32, before the bf16 rounding
 
 
+# ------------------------------------------------------------------ projection shortcut as a second K operand
+@pytest.mark.parametrize("B,T,H,W,cin,cout,cin2,stride,gate", [
+    (2, 4, 12, 10, 54, 24, 24, (1, 2, 2), True),      # X3D res2 block 0: SE gate + swish on the first operand only
+    (2, 3, 9, 7, 108, 48, 24, (1, 2, 2), False),      # res3 block 0: 4 + 1 k-steps (generic K loop)
+    (1, 4, 8, 8, 64, 256, 64, (1, 1, 1), False),      # ResNet res2 block 0: unstrided projection, 128-column slabs
+    (3, 2, 6, 6, 40, 24, 16, (2, 2, 2), True),        # temporal stride, ragged channel counts
+])
+def test_pointwise_conv_with_projection_shortcut_as_second_operand(B, T, H, W, cin, cout, cin2, stride, gate):
+    """ResBlock.forward (models/resnet.py:1179-1189) with branch1 folded into conv_c:
+    y = relu(s1*(W1.h') + s2*(W2.x2s) + shift), h' = swish(h*gate) for squeeze-excited blocks, x2s = the block
+    input sampled at the shortcut's stride; the two products keep their own fp32 BatchNorm scales."""
+    st = stride
+    T2, H2, W2 = (T - 1) * st[0] + 1, (H - 1) * st[1] + 1 + (st[1] > 1), (W - 1) * st[2] + 1
+    assert ((T2 - 1) // st[0] + 1, (H2 - 1) // st[1] + 1, (W2 - 1) // st[2] + 1) == (T, H, W)
+    cp1, cp2, cpo = (cin + 7) // 8 * 8, (cin2 + 7) // 8 * 8, (cout + 7) // 8 * 8
+    h = torch.zeros(B, T, H, W, cp1, dtype=torch.bfloat16, device="cuda")
+    h[..., :cin] = _rand((B, T, H, W, cin), 161, torch.bfloat16)
+    x2 = torch.zeros(B, T2, H2, W2, cp2, dtype=torch.bfloat16, device="cuda")
+    x2[..., :cin2] = _rand((B, T2, H2, W2, cin2), 162, torch.bfloat16)
+    w1 = _rand((cout, cin), 163, torch.bfloat16, cin ** -0.5)
+    w2 = _rand((cout, cin2), 164, torch.bfloat16, cin2 ** -0.5)
+    shift = _rand((cout,), 165, torch.float32)
+    s1, s2 = _rand((cout,), 166, torch.float32) * 0.2 + 1.0, _rand((cout,), 167, torch.float32) * 0.2 + 0.7
+    g = (torch.rand(B, cp1, device="cuda") * 0.8 + 0.1) if gate else None
+    hp = h[..., :cin].float()
+    if gate:
+        hp = hp * g[:, :cin].view(B, 1, 1, 1, cin)
+        hp = (hp * torch.sigmoid(hp)).to(torch.bfloat16).float()
+    x2s = x2[:, ::st[0], ::st[1], ::st[2], :cin2].float()
+    want = F.relu((hp @ w1.float().t()) * s1 + (x2s @ w2.float().t()) * s2 + shift)
+    k1, k2 = (cin + 31) // 32 * 32, (cin2 + 31) // 32 * 32
+    wcat = torch.zeros(cout, k1 + k2, dtype=torch.bfloat16, device="cuda")
+    wcat[:, :cin], wcat[:, k1:k1 + cin2] = w1, w2
+    y = torch.full((B, T, H, W, cpo), 5.0, dtype=torch.bfloat16, device="cuda")
+    d = L.Conv3dDesc()
+    d.x, d.w, d.y, d.shift, d.scale, d.x2_scale = h.data_ptr(), wcat.data_ptr(), y.data_ptr(), shift.data_ptr(), s1.data_ptr(), s2.data_ptr()
+    d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * cp1, T * H * W * cpo, cp1, cpo
+    d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, cp1, T, H, W, cout
+    d.kt = d.kh = d.kw = d.st = d.sh = d.sw = 1
+    d.act, d.dtype = L.ACT_RELU, L.PV_BF16
+    if gate:
+        d.a_gate, d.a_act = g.data_ptr(), L.ACT_SWISH
+    d.x2, d.x2_bs, d.x2_ld, d.x2_cin = x2.data_ptr(), T2 * H2 * W2 * cp2, cp2, cp2
+    d.x2_Hi, d.x2_Wi, d.x2_st, d.x2_sh, d.x2_sw = H2, W2, st[0], st[1], st[2]
+    assert L.lib().pv_conv3d_x2_supported(C.byref(d)) == 1
+    call("pv_conv3d", d)
+    assert rel_err(y[..., :cout], want) <= 1e-2
+    assert torch.all(y[..., cout:] == 0)
+
+
 # ------------------------------------------------------------------ squeeze-excitation gate
 @pytest.mark.parametrize("B,Cc,cr,nblk", [
     (3, 54, 8, 56), (2, 108, 8, 14), (2, 216, 16, 4), (4, 432, 32, 2), (2, 40, 8, 1),
