@@ -311,9 +311,6 @@ typedef struct pv_attention_desc {
 } pv_attention_desc;
 int pv_attention(const pv_attention_desc* d, pv_stream_t stream);
 
-/* ---- elementwise -------------------------------------------------------------------
- * y = act(a + b) over (rows, C): residual joins that cannot ride in a conv epilogue.
- */
 /* ---- video-level ensembling (the step right after the path) ---------------
  * pytorchvideo_trainer/module/video_classification.py:244-311: preds = softmax(logits) of every clip
  * (30 views per video in the model zoo's test protocol) are summed -- or max-ed -- into its video's
@@ -331,12 +328,40 @@ typedef struct pv_ensemble_desc {
 } pv_ensemble_desc;
 int pv_ensemble_scores(const pv_ensemble_desc* d, pv_stream_t stream);
 
+/* ---- elementwise -------------------------------------------------------------------
+ * y = act(a + b) over (rows, C): residual joins that cannot ride in a conv epilogue.
+ */
 typedef struct pv_add_desc {
   const void* a; const void* b; void* y;
   int64_t rows; int32_t C, lda, ldb, ldy;
   int32_t act, dtype;
 } pv_add_desc;
 int pv_add_act(const pv_add_desc* d, pv_stream_t stream);
+
+/* ---- RoIAlign (+ the whole-window max pool that follows it in the detection head) ---------
+ * ResNetRoIHead.forward, models/head.py:437-482: x.squeeze(T) -> roi_layer(x, bboxes) -> pool_spatial.
+ * roi_layer is torchvision.ops.RoIAlign (a third-party op, default of create_res_roi_pooling_head,
+ * models/head.py:212): for box n = (batch index, x1, y1, x2, y2) and output bin (ph, pw) the mean of
+ * grid_h x grid_w bilinear samples of the feature map, grid = sampling_ratio, or ceil(roi size / bins)
+ * when sampling_ratio <= 0; `aligned` = 0 is torchvision's default (no half-pixel shift, roi size >= 1).
+ * pool_max = 1 additionally takes the maximum over all ph x pw bins (MaxPool2d(resolution, stride=1),
+ * models/head.py:317) and writes one row per box: the [R, C, ph, pw] tensor is never stored.
+ * Boxes are read on the device at launch time (their VALUES may change between graph replays, their
+ * count may not).  A box whose batch index is outside [0, B) produces zeros.
+ */
+typedef struct pv_roi_align_desc {
+  const void* x;        /* [B][H][W][ldx] features (temporal dim already pooled to 1) */
+  const float* boxes;   /* [R][5] fp32: batch index, x1, y1, x2, y2 in input-image pixels */
+  void* y;              /* pool_max ? [R][ldy] : [R][ph][pw][ldy]                     */
+  int64_t x_bs;         /* elements between batch items of x                          */
+  int32_t ldx, ldy;
+  int32_t B, H, W, C, R;
+  int32_t ph, pw;       /* output resolution (head_spatial_resolution)               */
+  int32_t sampling_ratio, aligned, pool_max;
+  float spatial_scale;
+  int32_t dtype;        /* storage type of x and y                                    */
+} pv_roi_align_desc;
+int pv_roi_align(const pv_roi_align_desc* d, pv_stream_t stream);
 
 /* ---- execution plan ----------------------------------------------------------------
  * A deploy-form model is specialised to one input size (reference contract:
@@ -347,7 +372,8 @@ int pv_add_act(const pv_add_desc* d, pv_stream_t stream);
 enum pv_op_kind {
   PV_OP_CONV3D = 1, PV_OP_DWCONV3D = 2, PV_OP_SE_GATE = 3, PV_OP_POOL3D = 4,
   PV_OP_LAYERNORM = 5, PV_OP_SOFTMAX_ROWS = 6, PV_OP_MEAN_ROWS = 7, PV_OP_POSENC = 8,
-  PV_OP_ATTENTION = 9, PV_OP_ADD_ACT = 10, PV_OP_INGEST = 11, PV_OP_EGRESS = 12, PV_OP_TOKEN_POOL = 13
+  PV_OP_ATTENTION = 9, PV_OP_ADD_ACT = 10, PV_OP_INGEST = 11, PV_OP_EGRESS = 12, PV_OP_TOKEN_POOL = 13,
+  PV_OP_ROI_ALIGN = 14
 };
 typedef struct pv_plan pv_plan;
 pv_plan* pv_plan_create(void);

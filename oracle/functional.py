@@ -125,7 +125,7 @@ def res_basic_stem(sd, x, p, stride=(1, 2, 2), pool=True):
     return x
 
 
-def bottleneck_res_block(sd, x, p, stride_a, stride_b):
+def bottleneck_res_block(sd, x, p, stride_a, stride_b, dilation_b=(1, 1, 1)):
     """create_res_block (resnet.py:326-462) + create_bottleneck_block (:17-148) +
     BottleneckBlock.forward (:1345-1365) + ResBlock.forward (:1179-1189).  conv_b may be
     dense, depthwise (CSN, csn.py:169) or a Conv2plus1d (R(2+1)D, convolutions.py:232-237)."""
@@ -145,18 +145,24 @@ def bottleneck_res_block(sd, x, p, stride_a, stride_b):
     else:
         w = sd[b + ".conv_b.weight"]
         groups = y.shape[1] // w.shape[1]
-        y = _conv_same(y, w, stride_b, groups=groups)
+        if tuple(dilation_b) == (1, 1, 1):
+            y = _conv_same(y, w, stride_b, groups=groups)
+        else:  # dilated conv_b: the spatial padding follows the dilation (resnet.py:797-811)
+            k = w.shape[2:]
+            pad = (k[0] // 2, dilation_b[1] if dilation_b[1] > 1 else k[1] // 2,
+                   dilation_b[2] if dilation_b[2] > 1 else k[2] // 2)
+            y = F.conv3d(y, w, None, stride=stride_b, padding=pad, dilation=tuple(dilation_b), groups=groups)
     y = F.relu(_bn(y, sd, b + ".norm_b"))
     y = _bn(F.conv3d(y, sd[b + ".conv_c.weight"]), sd, b + ".norm_c")
     return F.relu(sc + y)
 
 
-def res_stage(sd, x, p, stride_a, stride_b):
+def res_stage(sd, x, p, stride_a, stride_b, dilation_b=(1, 1, 1)):
     i = 0
     while (p + ".res_blocks.%d.branch2.conv_a.weight" % i) in sd:
         first = i == 0
         x = bottleneck_res_block(sd, x, p + ".res_blocks.%d" % i, stride_a if first else (1, 1, 1),
-                                 stride_b if first else (1, 1, 1))
+                                 stride_b if first else (1, 1, 1), dilation_b)
         i += 1
     return x
 
@@ -235,6 +241,125 @@ def slowfast_forward(sd, slow, fast, head_pool_kernels=((8, 7, 7), (32, 7, 7)), 
     y = res_basic_head(sd, x, "blocks.6")
     outs.append(y)
     return (y, outs) if return_blocks else y
+
+
+# ----------------------------------------------------------------------------- detection (RoI head)
+def roi_align(x, boxes, output_size, spatial_scale, sampling_ratio=0, aligned=False):
+    """torchvision.ops.roi_align restated sample by sample (third-party: the reference imports it at
+    models/head.py:8 and builds it at head.py:318-322 with torchvision's default aligned=False; torchvision
+    is un-pinned in the reference's setup.py and absent here -- PARITY UNPINNED for this op).
+    Published definition (torchvision/csrc/ops/cpu/roi_align_kernel.cpp, roi_align_common.h): box
+    (batch, x1, y1, x2, y2) is scaled by spatial_scale (minus 0.5 if aligned); its size is clamped to >= 1
+    when not aligned; every output bin averages grid_h x grid_w bilinear samples at
+    start + bin*bin_size + (i + .5) * bin_size / grid, grid = sampling_ratio or ceil(roi / bins); a sample
+    with y < -1 or y > H (same for x) contributes 0; coordinates are clamped to >= 0 and, at the last
+    row/column, both neighbours collapse onto it.  x [B,C,H,W] fp32, boxes [R,5] -> [R,C,ph,pw]."""
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    _, C, H, W = x.shape
+    out = torch.zeros((boxes.shape[0], C, ph, pw), dtype=x.dtype)
+    off = 0.5 if aligned else 0.0
+    f32 = lambda v: torch.tensor(v, dtype=torch.float32)  # keep the coordinate arithmetic in fp32 like the kernel
+    for n in range(boxes.shape[0]):
+        bi = int(boxes[n, 0])
+        bx = boxes[n].to(torch.float32)
+        sc = f32(spatial_scale)
+        start_w, start_h = bx[1] * sc - off, bx[2] * sc - off
+        end_w, end_h = bx[3] * sc - off, bx[4] * sc - off
+        roi_w, roi_h = end_w - start_w, end_h - start_h
+        if not aligned:
+            roi_w, roi_h = torch.clamp(roi_w, min=1.0), torch.clamp(roi_h, min=1.0)
+        bin_h, bin_w = roi_h / ph, roi_w / pw
+        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(float(roi_h / ph)))
+        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(float(roi_w / pw)))
+        count = max(gh * gw, 1)
+        feat = x[bi]
+        for i in range(ph):
+            for j in range(pw):
+                acc = torch.zeros(C, dtype=x.dtype)
+                for iy in range(gh):
+                    y = float(start_h + i * bin_h + (iy + 0.5) * bin_h / gh)
+                    for ix in range(gw):
+                        xx = float(start_w + j * bin_w + (ix + 0.5) * bin_w / gw)
+                        if y < -1.0 or y > H or xx < -1.0 or xx > W:
+                            continue
+                        yy, xc = max(y, 0.0), max(xx, 0.0)
+                        y_lo, x_lo = int(yy), int(xc)
+                        if y_lo >= H - 1:
+                            y_hi = y_lo = H - 1
+                            yy = float(y_lo)
+                        else:
+                            y_hi = y_lo + 1
+                        if x_lo >= W - 1:
+                            x_hi = x_lo = W - 1
+                            xc = float(x_lo)
+                        else:
+                            x_hi = x_lo + 1
+                        ly, lx = yy - y_lo, xc - x_lo
+                        hy, hx = 1.0 - ly, 1.0 - lx
+                        acc += (hy * hx * feat[:, y_lo, x_lo] + hy * lx * feat[:, y_lo, x_hi]
+                                + ly * hx * feat[:, y_hi, x_lo] + ly * lx * feat[:, y_hi, x_hi])
+                out[n, :, i, j] = acc / count
+    return out
+
+
+def res_roi_head(sd, x, boxes, p, pool_kernel=None, resolution=(7, 7), spatial_scale=1.0 / 16.0,
+                 sampling_ratio=0, sigmoid=True):
+    """create_res_roi_pooling_head (models/head.py:203-327) + ResNetRoIHead.forward (:437-482): temporal
+    AvgPool3d -> squeeze T -> RoIAlign -> MaxPool2d(resolution, stride 1) -> Linear -> Sigmoid; no global
+    average (head_output_with_global_average=False in both detection builders)."""
+    if pool_kernel is not None:
+        x = F.avg_pool3d(x, pool_kernel, stride=1)
+    if x.shape[2] != 1:
+        raise Exception("Temporal dimension should be 1. Consider modifying the pool layer.")
+    r = roi_align(x[:, :, 0], boxes, resolution, spatial_scale, sampling_ratio)
+    r = F.max_pool2d(r, resolution, stride=1).unsqueeze(-3)
+    y = F.linear(r.permute(0, 2, 3, 4, 1), sd[p + ".proj.weight"], sd[p + ".proj.bias"]).permute(0, 4, 1, 2, 3)
+    if sigmoid:
+        y = torch.sigmoid(y)
+    return y.reshape(y.shape[0], -1)   # DetectionBBoxNetwork.forward (models/net.py:72-74)
+
+
+def resnet_detection_forward(sd, x, boxes, head_pool_kernel=(4, 1, 1), resolution=(7, 7), spatial_scale=1.0 / 16.0,
+                             sampling_ratio=0):
+    """create_resnet_with_roi_head (models/resnet.py:844-1019): stem (1,7,7), stages with spatial strides
+    (1,2,2,1) and conv_b of the last stage dilated (1,2,2), then the RoI head.  state_dict prefixes
+    `model.` / `detection_head.` (DetectionBBoxNetwork, models/net.py:47-74)."""
+    bb = {k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}
+    hd = {k[len("detection_head."):]: v for k, v in sd.items() if k.startswith("detection_head.")}
+    y = res_basic_stem(bb, x, "blocks.0")
+    spatial, dil = (1, 2, 2, 1), ((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 2, 2))
+    for i in range(4):
+        y = res_stage(bb, y, "blocks.%d" % (i + 1), (1, 1, 1), (1, spatial[i], spatial[i]), dil[i])
+    return res_roi_head({"h." + k: v for k, v in hd.items()}, y, boxes, "h", head_pool_kernel, resolution,
+                        spatial_scale, sampling_ratio)
+
+
+def slowfast_detection_forward(sd, slow, fast, boxes, head_pool_kernels=((8, 1, 1), (32, 1, 1)), resolution=(7, 7),
+                               spatial_scale=1.0 / 16.0, sampling_ratio=0):
+    """create_slowfast_with_roi_head (models/slowfast.py:364-582): SlowFast backbone with spatial strides
+    (1,2,2,1), last-stage conv_b dilated (1,2,2), PoolConcatPathway pooling time only, then the RoI head."""
+    bb = {k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}
+    hd = {"h." + k[len("detection_head."):]: v for k, v in sd.items() if k.startswith("detection_head.")}
+
+    def fuse(s, f, p):
+        if (p + ".conv_fast_to_slow.weight") not in bb:
+            return s
+        w = bb[p + ".conv_fast_to_slow.weight"]
+        z = F.conv3d(f, w, stride=(4, 1, 1), padding=(w.shape[2] // 2, 0, 0))
+        return torch.cat([s, F.relu(_bn(z, bb, p + ".norm"))], 1)
+
+    s = res_basic_stem(bb, slow, "blocks.0.multipathway_blocks.0")
+    f = res_basic_stem(bb, fast, "blocks.0.multipathway_blocks.1")
+    s = fuse(s, f, "blocks.0.multipathway_fusion")
+    spatial, dil = (1, 2, 2, 1), ((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 2, 2))
+    for i in range(4):
+        p = "blocks.%d" % (i + 1)
+        s = res_stage(bb, s, p + ".multipathway_blocks.0", (1, 1, 1), (1, spatial[i], spatial[i]), dil[i])
+        f = res_stage(bb, f, p + ".multipathway_blocks.1", (1, 1, 1), (1, spatial[i], spatial[i]), dil[i])
+        s = fuse(s, f, p + ".multipathway_fusion")
+    x = torch.cat([F.avg_pool3d(s, head_pool_kernels[0], stride=1),
+                   F.avg_pool3d(f, head_pool_kernels[1], stride=1)], 1)
+    return res_roi_head(hd, x, boxes, "h", None, resolution, spatial_scale, sampling_ratio)
 
 
 # ----------------------------------------------------------------------------- MViT

@@ -3,7 +3,9 @@
 `/root/reference` is not installed and three of its third-party imports are absent
 (torchvision.ops.RoIAlign, fvcore.nn.weight_init, fvcore.nn.squeeze_excitation).  This
 module injects stand-ins for exactly those symbols so that `import pytorchvideo.models`
-runs the reference's own model code.  It is used by `tests/golden/make_golden.py` to
+runs the reference's own model code (the RoIAlign stand-in evaluates the restatement in
+oracle/functional.py: detection goldens pin the reference's backbone, dilation and head
+wiring, NOT the third-party op itself).  It is used by `tests/golden/make_golden.py` to
 generate golden vectors; nothing in the product imports it and it never travels to the
 GPU box (the reference tree does not exist there).
 
@@ -36,12 +38,15 @@ def install():
     tv = _mod("torchvision")
     tv.ops = _mod("torchvision.ops")
 
-    class RoIAlign(nn.Module):  # default arg of the detection head only (models/head.py:8,212)
-        def __init__(self, output_size=None, spatial_scale=1.0, sampling_ratio=0, **kw):
+    class RoIAlign(nn.Module):  # the detection head's roi layer (models/head.py:8,212,318-322)
+        def __init__(self, output_size=None, spatial_scale=1.0, sampling_ratio=0, aligned=False):
             super().__init__()
+            self.output_size, self.spatial_scale = output_size, spatial_scale
+            self.sampling_ratio, self.aligned = sampling_ratio, aligned
 
         def forward(self, x, boxes):
-            raise NotImplementedError
+            from oracle.functional import roi_align
+            return roi_align(x, boxes, self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned)
 
     tv.ops.RoIAlign = RoIAlign
     fv = _mod("fvcore")

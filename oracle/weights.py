@@ -52,6 +52,21 @@ def deterministic_fill(model, seed=0):
     return model
 
 
+DETECTION_PROJ_SCALE = 0.01
+
+
+@torch.no_grad()
+def detection_fill(model, seed=0):
+    """deterministic_fill for a DetectionBBoxNetwork: the same key-addressed values, with the head projection
+    scaled down so that the scores do not sit in the saturated tails of the sigmoid (the variance-preserving
+    fill drives the pooled features to |x| ~ 100, i.e. logits ~ 150: every score would be exactly 0 or 1 and
+    a comparison of scores would be vacuous)."""
+    deterministic_fill(model, seed)
+    model.detection_head.proj.weight.mul_(DETECTION_PROJ_SCALE)
+    model.detection_head.proj.bias.mul_(DETECTION_PROJ_SCALE)
+    return model
+
+
 def seeded_input(shape, seed=0, dist="randn"):
     g = torch.Generator()
     g.manual_seed(1000 + seed)

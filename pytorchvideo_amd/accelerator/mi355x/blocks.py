@@ -143,6 +143,47 @@ class Mi355xMultiPathBlock(Mi355xBlock):
         return [sess.view(r) for r in out] if isinstance(out, list) else sess.view(out)
 
 
+class Mi355xRoIHeadBlock(Mi355xBlock):
+    """ResNetRoIHead (models/head.py:394-482): forward(x, bboxes).  The deploy form is specialised to the
+    feature size AND the number of boxes; the box values are read on the device at every replay."""
+
+    def convert(self, input_blob_size, *args, session=None, input_ref=None, dtype=None, num_boxes=None, **kwargs):
+        assert self.convert_flag is False, "already converted, cannot be converted again"
+        if num_boxes is None or int(num_boxes) <= 0:
+            raise L.PvError("ResNetRoIHead.convert needs num_boxes (the deploy form is specialised to the box count)")
+        self.eval()
+        sess = session
+        if sess is None:
+            sess = Session(dtype=dtype or torch.bfloat16)
+            self.__dict__["_owns_session"] = True
+        if input_ref is None:
+            B, Cc, T, H, W = [int(v) for v in input_blob_size]
+            input_ref = sess.alloc_act(B, T, H, W, Cc)
+        boxes = sess.alloc_boxes(int(num_boxes))
+        first = len(sess.ops)
+        out_ref = E.emit_roi_head(sess, self, input_ref, boxes, int(num_boxes))
+        self.__dict__.update(_sess=sess, _in_ref=input_ref, _out_ref=out_ref, _op_range=(first, len(sess.ops)),
+                             _boxes=boxes, _num_boxes=int(num_boxes))
+        if self._owns_session:
+            sess.finalize()
+        self.__dict__["convert_flag"] = True
+
+    def _result(self):
+        sess, out = self._sess, self._out_ref
+        if out.T == out.H == out.W == 1:
+            return sess.view_rows(out)[:, 0, :]
+        return sess.view(out)
+
+    def _deploy_forward(self, x, bboxes):
+        sess = self._sess
+        sess.finalize()
+        if not sess.matches(x, self._in_ref):
+            sess.ingest(x, self._in_ref)
+        sess.load_boxes(bboxes, self._boxes, self._num_boxes)
+        sess.launch(*self._op_range)
+        return self._result()
+
+
 # ------------------------------------------------------------------------- transmuters
 _SINGLE_IO = ("ResNetBasicStem", "ResStage", "ResBlock", "ResNetBasicHead")
 
@@ -265,7 +306,18 @@ def transmute_pool(module: nn.Module):
     return None
 
 
-EFFICIENT_BLOCK_TRANSMUTER_MI355X = [transmute_single_io, transmute_multipath, transmute_pool]
+def transmute_roi_head(module: nn.Module):
+    """Detection head (ResNetRoIHead with RoIAlign) -> Mi355xRoIHeadBlock, or None (decline)."""
+    if isinstance(module, EfficientBlockBase) or type(module).__name__ != "ResNetRoIHead":
+        return None
+    try:
+        E.check_roi_head(module)
+    except (E.Unsupported, AttributeError):
+        return None
+    return Mi355xRoIHeadBlock(module)
+
+
+EFFICIENT_BLOCK_TRANSMUTER_MI355X = [transmute_single_io, transmute_multipath, transmute_pool, transmute_roi_head]
 
 
 # ------------------------------------------------------------------------- MViT

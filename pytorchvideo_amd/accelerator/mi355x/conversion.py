@@ -31,6 +31,8 @@ def _record_input_sizes(model, sample):
                 lut[name] = tuple(_in[0].size())
                 if len(_in) > 1 and isinstance(_in[1], (list, tuple)) and len(_in[1]) == 3:
                     lut[name + "#thw"] = tuple(int(v) for v in _in[1])  # MultiScaleBlock(x, thw)
+                if len(_in) > 1 and isinstance(_in[1], torch.Tensor) and _in[1].dim() == 2:
+                    lut[name + "#boxes"] = int(_in[1].shape[0])        # ResNetRoIHead(x, bboxes)
         handles.append(module.register_forward_hook(hook))
         for child_name, child in module.named_children():
             add(child, f"{name}.{child_name}")
@@ -38,7 +40,7 @@ def _record_input_sizes(model, sample):
     add(model, "")
     model.eval()
     with torch.no_grad():
-        model(sample)
+        model(*sample) if isinstance(sample, tuple) else model(sample)
     for h in handles:
         h.remove()
     return lut
@@ -62,6 +64,8 @@ def _convert_children(module, lut, batch, name, sess, dtype, kwargs):
         extra = dict(kwargs)
         if (name + "#thw") in lut:
             extra["thw"] = lut[name + "#thw"]
+        if (name + "#boxes") in lut:
+            extra["num_boxes"] = lut[name + "#boxes"]
         module.convert(size, session=sess, dtype=dtype, **extra)
         return
     for child_name, child in module.named_children():
@@ -73,9 +77,12 @@ def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quant
     """Return a deploy-form copy of a transmuted `model`, specialised to `input_tensor`'s
     shape.  `dtype` (torch.bfloat16 | torch.float32) selects the kernels' storage type and
     defaults to the input tensor's dtype (fp32 input -> fp32 kernels)."""
+    if type(model).__name__ == "DetectionBBoxNetwork":
+        return _convert_detection(model, input_tensor, dtype, use_graph,
+                                  dict(convert_for_quantize=convert_for_quantize,
+                                       native_conv3d_op_qnnpack=native_conv3d_op_qnnpack))
     if dtype is None:
-        t0 = input_tensor if isinstance(input_tensor, torch.Tensor) else input_tensor[0]
-        dtype = torch.bfloat16 if t0.dtype == torch.bfloat16 else torch.float32
+        dtype = _default_dtype(input_tensor)
     L.lib()  # fail early and loudly when the HIP library is not built
     lut = {}
     if not _is_fusable_net(model) and not _is_fusable_mvit(model, input_tensor):
@@ -107,6 +114,12 @@ def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quant
     return converted
 
 
+def _default_dtype(x):
+    while not isinstance(x, torch.Tensor):
+        x = x[0]
+    return torch.bfloat16 if x.dtype == torch.bfloat16 else torch.float32
+
+
 def _is_fusable_net(model):
     from .blocks import Mi355xBlock
     blocks = getattr(model, "blocks", None)
@@ -115,26 +128,23 @@ def _is_fusable_net(model):
 
 
 # ------------------------------------------------------------------ whole-Net fusion
-def _try_fuse_net(model, lut, batch, sess, dtype, input_tensor=None):
-    """`Net` (models/net.py:11-44) whose blocks are all MI355X blocks: chain them inside the
-    plan (block i+1 reads block i's arena buffers directly) and make forward one replay.
-    Handles single-tensor nets (X3D, CSN, R(2+1)D, ResNet) and list-input nets (SlowFast)."""
-    from .blocks import Mi355xBlock
-
-    blocks = getattr(model, "blocks", None)
-    if type(model).__name__ != "Net" or blocks is None or len(blocks) == 0:
-        return False
-    if not all(isinstance(b, Mi355xBlock) for b in blocks):
-        return False
+def _chain_net_blocks(model, batch, sess, dtype, input_tensor):
+    """Emit the blocks of a `Net` (models/net.py:11-44) whose blocks are all MI355X blocks back to back
+    into `sess`: block i+1 reads block i's arena buffers directly.  Returns (input refs, multi-pathway?)
+    or None when the model is not such a net.  Handles single-tensor nets (X3D, CSN, R(2+1)D, ResNet)
+    and list-input nets (SlowFast)."""
+    if not _is_fusable_net(model):
+        return None
+    blocks = model.blocks
     multi = isinstance(input_tensor, (list, tuple))
     if multi:
         size = [tuple(t.shape) for t in input_tensor]
         if any(len(s) != 5 for s in size):
-            return False
+            return None
     else:
         size = tuple(input_tensor.shape)
         if len(size) != 5:
-            return False
+            return None
     cur, prev_owned = None, []
     for i, blk in enumerate(blocks):
         blk.convert(size if i == 0 else None, session=sess, input_ref=cur, dtype=dtype)
@@ -143,28 +153,98 @@ def _try_fuse_net(model, lut, batch, sess, dtype, input_tensor=None):
                 sess.release(r)
         cur = blk._out_ref
         prev_owned = list(cur) if isinstance(cur, list) else [cur]
-    first_in, last = blocks[0]._in_ref, blocks[-1]
-    model.__dict__["_pv_output"] = last._out_ref
+    model.__dict__["_pv_output"] = blocks[-1]._out_ref
+    model.__dict__["_pv_inputs"] = blocks[0]._in_ref     # arena buffers a forward fills (transforms.DevicePacker)
+    return blocks[0]._in_ref, multi
+
+
+def _ingest_inputs(s, x, first_in, multi):
+    if multi:
+        assert isinstance(x, list), "input for MultiPathWayWithFuse needs to be a list of tensors"
+        for t, ref in zip(x, first_in):
+            if not s.matches(t, ref):
+                s.ingest(t, ref)
+    elif not s.matches(x, first_in):
+        s.ingest(x, first_in)
+
+
+def _try_fuse_net(model, lut, batch, sess, dtype, input_tensor=None):
+    """A fusable `Net`: chain its blocks inside the plan and make forward one replay."""
+    chained = _chain_net_blocks(model, batch, sess, dtype, input_tensor)
+    if chained is None:
+        return False
+    first_in, multi = chained
 
     def fused_forward(self, x):
         s = self._pv_session
-        if multi:
-            assert isinstance(x, list), "input for MultiPathWayWithFuse needs to be a list of tensors"
-            for t, ref in zip(x, first_in):
-                if not s.matches(t, ref):
-                    s.ingest(t, ref)
-        elif not s.matches(x, first_in):
-            s.ingest(x, first_in)
+        _ingest_inputs(s, x, first_in, multi)
         s.launch(use_graph=self._pv_use_graph)
-        out = last._out_ref
-        if out.T == out.H == out.W == 1 and out.f32:
-            return s.view_rows(out)[:, 0, :]
-        return s.view(out)
+        return fused_result(self)
 
     model.forward = types.MethodType(fused_forward, model)
-    model.__dict__["_pv_inputs"] = first_in     # arena buffers a forward fills (transforms.DevicePacker)
     model.__dict__["_pv_result"] = lambda: fused_result(model)
     return True
+
+
+# ------------------------------------------------------------------ detection (backbone + RoI head)
+def _convert_detection(model, inputs, dtype, use_graph, kwargs):
+    """DetectionBBoxNetwork (models/net.py:47-74): `inputs` = (x, bboxes) exactly as forward takes them
+    (x a clip, or [slow, fast] for SlowFast; bboxes [R,5]).  When the backbone is a fusable Net and the
+    head an MI355X RoI head, forward(x, bboxes) is one replay of one plan: ingest, backbone, RoIAlign +
+    max pool, projection + sigmoid.  Otherwise every converted block runs on its own, in the original
+    module order."""
+    from .blocks import Mi355xRoIHeadBlock
+    if not (isinstance(inputs, (tuple, list)) and len(inputs) == 2 and isinstance(inputs[1], torch.Tensor)
+            and inputs[1].dim() == 2 and inputs[1].shape[1] == 5):
+        raise RuntimeError("a DetectionBBoxNetwork is converted for (x, bboxes) with bboxes of shape [R, 5]")
+    x, bboxes = inputs
+    n_boxes, batch = int(bboxes.shape[0]), _batch_of(x)
+    if dtype is None:
+        dtype = _default_dtype(x)
+    L.lib()
+    fusable = _is_fusable_net(model.model) and isinstance(model.detection_head, Mi355xRoIHeadBlock)
+    lut = {}
+    if not fusable:
+        probe_boxes = bboxes.detach().float().cpu().clone()
+        probe_boxes[:, 0] = 0                       # the probing forward runs on one clip
+        lut = _record_input_sizes(model, (_one_clip(x), probe_boxes))
+    converted = deepcopy(model)
+    converted.eval()
+    sess = Session(dtype=dtype)
+    if fusable:
+        first_in, multi = _chain_net_blocks(converted.model, batch, sess, dtype, x)
+        features = converted.model._pv_output
+        n_backbone = len(sess.ops)
+        head = converted.detection_head
+        head.convert(None, session=sess, input_ref=features, dtype=dtype, num_boxes=n_boxes)
+        sess.release(features)
+
+        def backbone_forward(self, x):              # model.model on its own: the backbone's share of the plan
+            s = self._pv_session
+            _ingest_inputs(s, x, first_in, multi)
+            s.launch(0, n_backbone)
+            return fused_result(self)
+
+        def fused_forward(self, x, bboxes):
+            s = self._pv_session
+            _ingest_inputs(s, x, first_in, multi)
+            s.load_boxes(bboxes, head._boxes, head._num_boxes)
+            s.launch(use_graph=self._pv_use_graph)
+            out = head._result()
+            return out.reshape(out.shape[0], -1)    # net.py:74
+
+        converted.model.forward = types.MethodType(backbone_forward, converted.model)
+        converted.model.__dict__["_pv_session"] = sess
+        converted.forward = types.MethodType(fused_forward, converted)
+        converted.__dict__["_pv_inputs"] = first_in
+    else:
+        _convert_children(converted, lut, batch, "", sess, dtype, kwargs)
+    sess.finalize()
+    if not fusable:
+        converted.to(device=sess.device, dtype=dtype)
+    converted.__dict__["_pv_session"] = sess
+    converted.__dict__["_pv_use_graph"] = use_graph
+    return converted
 
 
 def fused_result(model):

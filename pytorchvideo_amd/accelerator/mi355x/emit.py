@@ -714,6 +714,106 @@ def emit_res_head(sess, head, x):
     return out
 
 
+# --------------------------------------------------------------------------- detection head
+def _pool2d_geometry(pool):
+    """(kernel, stride, padding, mode) of the nn.MaxPool2d / nn.AvgPool2d that follows the RoI layer."""
+    def pair(v):
+        return (int(v), int(v)) if isinstance(v, int) else tuple(int(e) for e in v)
+    if getattr(pool, "ceil_mode", False):
+        raise Unsupported("ceil_mode pooling")
+    k = pair(pool.kernel_size)
+    s = pair(pool.stride if pool.stride is not None else pool.kernel_size)
+    p = pair(pool.padding)
+    if isinstance(pool, nn.MaxPool2d):
+        if pair(pool.dilation) != (1, 1) or pool.return_indices:
+            raise Unsupported("max pool options")
+        return k, s, p, L.POOL_MAX
+    if isinstance(pool, nn.AvgPool2d):
+        if not pool.count_include_pad or pool.divisor_override is not None:
+            raise Unsupported("avg pool options")
+        return k, s, p, L.POOL_AVG
+    raise Unsupported("spatial pool %s" % _cls_name(pool))
+
+
+def check_roi_head(head):
+    """Structural support check of a ResNetRoIHead (models/head.py:394-482); raises Unsupported."""
+    roi = head.roi_layer
+    if roi is None or _cls_name(roi) != "RoIAlign":
+        raise Unsupported("roi layer %s" % (None if roi is None else _cls_name(roi)))
+    for a in ("output_size", "spatial_scale", "sampling_ratio"):
+        if not hasattr(roi, a):
+            raise Unsupported("RoIAlign without %s" % a)
+    if head.pool is not None and not _is_a(head.pool, (nn.AvgPool3d, nn.MaxPool3d, nn.AdaptiveAvgPool3d)):
+        raise Unsupported("head pool %s" % _cls_name(head.pool))
+    if head.pool_spatial is not None:
+        _pool2d_geometry(head.pool_spatial)
+    if not isinstance(head.proj, nn.Linear):
+        raise Unsupported("head proj %s" % _cls_name(head.proj))
+    if head.dropout is not None and not isinstance(head.dropout, nn.Dropout):
+        raise Unsupported("head dropout %s" % _cls_name(head.dropout))
+    a = head.activation
+    if a is not None and not isinstance(a, (nn.Sigmoid, nn.ReLU)) and not (isinstance(a, nn.Softmax) and a.dim == 1):
+        raise Unsupported("head activation %s" % _cls_name(a))
+    if head.output_pool is not None and not (isinstance(head.output_pool, nn.AdaptiveAvgPool3d)
+                                            and _triple(head.output_pool.output_size) == (1, 1, 1)):
+        raise Unsupported("head output pool")
+
+
+def emit_roi_head(sess, head, x, boxes, n_boxes):
+    """ResNetRoIHead.forward (models/head.py:437-482): pool -> squeeze T -> RoIAlign -> pool_spatial ->
+    dropout (identity) -> proj -> activation [-> global mean].  `boxes` is the arena pointer of the
+    [n_boxes, 5] fp32 box list.  RoIAlign and a MaxPool2d over its whole output (what
+    create_res_roi_pooling_head builds, head.py:317) are one launch whose [R,C,ph,pw] tensor is never
+    stored; the sigmoid rides in the projection's epilogue.  Returns fp32 [R,1,h,w,classes] (or the
+    [R,classes] mean when the head averages)."""
+    check_roi_head(head)
+    cur = x
+    if head.pool is not None:
+        cur = emit_pool(sess, head.pool, x, label="det.pool")
+    if cur.T != 1:
+        raise Exception("Temporal dimension should be 1. Consider modifying the pool layer.")  # head.py:452-455
+    roi = head.roi_layer
+    osz = roi.output_size
+    ph, pw = (int(osz), int(osz)) if isinstance(osz, int) else (int(osz[0]), int(osz[1]))
+    fuse_max, tail = False, None
+    if head.pool_spatial is not None:
+        k, s, p, mode = _pool2d_geometry(head.pool_spatial)
+        if mode == L.POOL_MAX and k == (ph, pw) and p == (0, 0):
+            fuse_max = True          # one window covers the whole RoI output: stride is irrelevant
+        else:
+            tail = (k, s, p, mode)
+    y = sess.alloc_act(n_boxes, 1, 1 if fuse_max else ph, 1 if fuse_max else pw, cur.C, f32=cur.f32)
+    f = dict(x=cur.ptr, boxes=boxes, y=y.ptr, x_bs=cur.bs, ldx=cur.ld, ldy=y.ld, B=cur.B, H=cur.H, W=cur.W,
+             C=cur.C, R=n_boxes, ph=ph, pw=pw, sampling_ratio=int(roi.sampling_ratio),
+             aligned=1 if getattr(roi, "aligned", False) else 0, pool_max=1 if fuse_max else 0,
+             spatial_scale=float(roi.spatial_scale), dtype=L.PV_F32 if cur.f32 else sess.pv_dtype)
+    alg = cur.itemsize * pad8(cur.C) * (cur.B * cur.H * cur.W + n_boxes * y.voxels)
+    sess.add_op(L.OP_ROI_ALIGN, f, label="det.roi_align", alg_bytes=alg)
+    if cur is not x:
+        sess.release(cur)
+    if tail is not None:
+        k, s, p, mode = tail
+        z = emit_pool_raw(sess, y, (1,) + k, (1,) + s, (0,) + p, mode, label="det.pool_spatial")
+        sess.release(y)
+        y = z
+    a = head.activation
+    act = L.ACT_SIGMOID if isinstance(a, nn.Sigmoid) else (L.ACT_RELU if isinstance(a, nn.ReLU) else L.ACT_NONE)
+    logits = _emit_linear_rows(sess, head.proj, y, act=act, y_f32=True, label="det.proj")
+    sess.release(y)
+    if isinstance(a, nn.Softmax):
+        f = dict(x=logits.ptr, y=logits.ptr, gamma=None, beta=None, rows=logits.B * logits.voxels, C=logits.C,
+                 ldx=logits.ld, ldy=logits.ld, rows_per_batch=0, eps=0.0, dtype=L.PV_F32)
+        sess.add_op(L.OP_SOFTMAX_ROWS, f, label="det.softmax")
+    if head.output_pool is None:
+        return logits
+    out = sess.alloc_act(logits.B, 1, 1, 1, logits.C, f32=True)
+    f = dict(x=logits.ptr, y=out.ptr, gamma=None, beta=None, rows=logits.B * logits.voxels, C=logits.C,
+             ldx=logits.ld, ldy=out.ld, rows_per_batch=logits.voxels, eps=0.0, dtype=L.PV_F32)
+    sess.add_op(L.OP_MEAN_ROWS, f, label="det.mean")
+    sess.release(logits)
+    return out
+
+
 # --------------------------------------------------------------------------- SlowFast
 def out_shape(m, x):
     """(T,H,W,C) a single-IO module will produce for input `x`, by emitting into a scratch session."""

@@ -299,6 +299,21 @@ class Session:
             d.ch_shift = ch_shift.data_ptr() if ch_shift is not None else None
         L.check(lib.pv_ingest_ncdhw(C.byref(d), self._stream()), "ingest")
 
+    def alloc_boxes(self, count):
+        """Persistent [count, 5] fp32 buffer for the box list of a detection head.  It lives beside the
+        weights, NOT in the arena: it is filled before the replay starts and read near its end, and every
+        arena offset that is free when the head is emitted is one the backbone writes during the replay."""
+        return self.add_weight(torch.zeros(count, 5, dtype=torch.float32))
+
+    def load_boxes(self, bboxes, ptr, count):
+        """Copy the [R,5] box list of a detection forward into its buffer (read by pv_roi_align at replay
+        time; the deploy form is specialised to the box COUNT like it is to every other size)."""
+        if bboxes.dim() != 2 or tuple(bboxes.shape) != (count, 5):
+            raise L.PvError("deploy form was converted for %d boxes [R,5], got %s" % (count, tuple(bboxes.shape)))
+        assert ptr.space == "weights"
+        dst = self.weights_t[ptr.off: ptr.off + count * 20].view(torch.float32).view(count, 5)
+        dst.copy_(bboxes.to(device=self.device, dtype=torch.float32, non_blocking=True))
+
     def ingest_rows(self, x, ref):
         """Copy a (B, N, C) token tensor into the arena buffer `ref` (no-op when `x` already is it)."""
         v = self.view_rows(ref)

@@ -9,7 +9,7 @@
 
 namespace {
 thread_local std::string g_last_error;
-constexpr int kAbiVersion = 13;
+constexpr int kAbiVersion = 14;
 }  // namespace
 
 int pv_set_hip_error(hipError_t e, const char* what) {
@@ -54,6 +54,7 @@ size_t desc_size(int kind) {
     case PV_OP_INGEST:
     case PV_OP_EGRESS: return sizeof(pv_layout_desc);
     case PV_OP_TOKEN_POOL: return sizeof(pv_token_pool_desc);
+    case PV_OP_ROI_ALIGN: return sizeof(pv_roi_align_desc);
     default: return 0;
   }
 }
@@ -74,6 +75,7 @@ int run_op(const pv_plan::Op& op, pv_stream_t s) {
     case PV_OP_INGEST: return pv_ingest_ncdhw(static_cast<const pv_layout_desc*>(p), s);
     case PV_OP_EGRESS: return pv_egress_ncdhw(static_cast<const pv_layout_desc*>(p), s);
     case PV_OP_TOKEN_POOL: return pv_token_pool(static_cast<const pv_token_pool_desc*>(p), s);
+    case PV_OP_ROI_ALIGN: return pv_roi_align(static_cast<const pv_roi_align_desc*>(p), s);
     default: return PV_ERR_INVALID;
   }
 }

@@ -1,6 +1,8 @@
-"""Heads (reference: pytorchvideo/models/head.py; the RoI head :203-327,:394-482 is out of scope)."""
+"""Heads (reference: pytorchvideo/models/head.py)."""
+import torch
 import torch.nn as nn
 
+from ..layers.roi_align import RoIAlign
 from ..layers.utils import set_attributes
 
 
@@ -64,6 +66,61 @@ def create_res_basic_head(*, in_features, out_features, pool=nn.AvgPool3d, outpu
         proj=nn.Linear(in_features, out_features),
         activation=_head_activation(activation),
         pool=pool_model,
+        dropout=nn.Dropout(dropout_rate) if dropout_rate > 0 else None,
+        output_pool=nn.AdaptiveAvgPool3d(1) if output_with_global_average else None,
+    )
+
+
+class ResNetRoIHead(nn.Module):
+    """Detection head: pool -> RoIAlign on the (T == 1) map -> 2-D pool -> dropout -> per-position Linear
+    -> activation -> optional global mean (reference: head.py:394-482).  `bboxes` is [R, 5]:
+    (batch index, x1, y1, x2, y2) in input-image pixels."""
+
+    def __init__(self, pool=None, pool_spatial=None, roi_layer=None, dropout=None, proj=None,
+                 activation=None, output_pool=None) -> None:
+        super().__init__()
+        set_attributes(self, locals())
+        assert self.proj is not None
+
+    def forward(self, x: torch.Tensor, bboxes: torch.Tensor) -> torch.Tensor:
+        if self.pool is not None:
+            x = self.pool(x)
+        if self.roi_layer is not None:
+            if x.shape[-3] != 1:
+                raise Exception("Temporal dimension should be 1. Consider modifying the pool layer.")
+            x = self.roi_layer(torch.squeeze(x, -3), bboxes)
+            if self.pool_spatial is not None:
+                x = self.pool_spatial(x)
+            x = x.unsqueeze(-3)
+        if self.dropout is not None:
+            x = self.dropout(x)
+        x = self.proj(x.permute((0, 2, 3, 4, 1))).permute((0, 4, 1, 2, 3))
+        if self.activation is not None:
+            x = self.activation(x)
+        if self.output_pool is not None:
+            x = self.output_pool(x)
+            x = x.view(x.shape[0], -1)
+        return x
+
+
+def create_res_roi_pooling_head(*, in_features, out_features, resolution, spatial_scale, sampling_ratio=0,
+                                roi=RoIAlign, pool=nn.AvgPool3d, output_size=(1, 1, 1),
+                                pool_kernel_size=(1, 7, 7), pool_stride=(1, 1, 1), pool_padding=(0, 0, 0),
+                                pool_spatial=nn.MaxPool2d, dropout_rate=0.5, activation=None,
+                                output_with_global_average=True):
+    """(reference: head.py:203-327)"""
+    if pool is None:
+        pool_model = None
+    elif pool == nn.AdaptiveAvgPool3d:
+        pool_model = pool(output_size)
+    else:
+        pool_model = pool(kernel_size=pool_kernel_size, stride=pool_stride, padding=pool_padding)
+    return ResNetRoIHead(
+        proj=nn.Linear(in_features, out_features),
+        activation=_head_activation(activation),
+        pool=pool_model,
+        pool_spatial=pool_spatial(resolution, stride=1) if pool_spatial else None,
+        roi_layer=roi(output_size=resolution, spatial_scale=spatial_scale, sampling_ratio=sampling_ratio),
         dropout=nn.Dropout(dropout_rate) if dropout_rate > 0 else None,
         output_pool=nn.AdaptiveAvgPool3d(1) if output_with_global_average else None,
     )

@@ -24,6 +24,20 @@ class Net(nn.Module):
         return x
 
 
+class DetectionBBoxNetwork(nn.Module):
+    """A backbone followed by a head that also takes bounding boxes (reference: net.py:47-74)."""
+
+    def __init__(self, model: nn.Module, detection_head: nn.Module):
+        super().__init__()
+        self.model = model
+        self.detection_head = detection_head
+
+    def forward(self, x, bboxes: torch.Tensor):
+        features = self.model(x)
+        out = self.detection_head(features, bboxes)
+        return out.view(out.shape[0], -1)
+
+
 class MultiPathWayWithFuse(nn.Module):
     """Per-pathway blocks followed by a cross-pathway fusion (reference: net.py:77-122).
     With `inplace=True` the caller's list is updated in place, exactly like the reference."""

@@ -3,7 +3,7 @@
 Every conv model of the path (X3D, SlowFast, CSN, R(2+1)D, plain ResNet) is assembled from
 `BottleneckBlock` inside `ResBlock` inside `ResStage`; the attribute names below are the
 state_dict keys of the model zoo (`blocks.N.res_blocks.M.branch2.conv_a.weight`, ...).
-The acoustic / RoI variants (resnet.py:151,844,1022) are out of scope.
+The acoustic variants (resnet.py:151,1022) are out of scope.
 """
 from typing import Callable
 
@@ -12,8 +12,8 @@ import torch
 import torch.nn as nn
 
 from ..layers.utils import set_attributes
-from .head import create_res_basic_head
-from .net import Net
+from .head import create_res_basic_head, create_res_roi_pooling_head
+from .net import DetectionBBoxNetwork, Net
 from .stem import _act, _norm, create_res_basic_stem
 
 
@@ -232,3 +232,41 @@ def create_resnet(*, input_channel=3, model_depth=50, model_num_class=400, dropo
             dropout_rate=dropout_rate, activation=head_activation,
             output_with_global_average=head_output_with_global_average))
     return Net(blocks=nn.ModuleList(blocks))
+
+
+def create_resnet_with_roi_head(*, input_channel=3, model_depth=50, model_num_class=80, dropout_rate=0.5,
+                                norm=nn.BatchNorm3d, activation=nn.ReLU, stem_dim_out=64,
+                                stem_conv_kernel_size=(1, 7, 7), stem_conv_stride=(1, 2, 2),
+                                stem_pool=nn.MaxPool3d, stem_pool_kernel_size=(1, 3, 3),
+                                stem_pool_stride=(1, 2, 2), stem=create_res_basic_stem, stage1_pool=None,
+                                stage1_pool_kernel_size=(2, 1, 1),
+                                stage_conv_a_kernel_size=((1, 1, 1), (1, 1, 1), (3, 1, 1), (3, 1, 1)),
+                                stage_conv_b_kernel_size=((1, 3, 3), (1, 3, 3), (1, 3, 3), (1, 3, 3)),
+                                stage_conv_b_num_groups=(1, 1, 1, 1),
+                                stage_conv_b_dilation=((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 2, 2)),
+                                stage_spatial_h_stride=(1, 2, 2, 1), stage_spatial_w_stride=(1, 2, 2, 1),
+                                stage_temporal_stride=(1, 1, 1, 1), bottleneck=create_bottleneck_block,
+                                head=create_res_roi_pooling_head, head_pool=nn.AvgPool3d,
+                                head_pool_kernel_size=(4, 1, 1), head_output_size=(1, 1, 1),
+                                head_activation=nn.Sigmoid, head_output_with_global_average=False,
+                                head_spatial_resolution=(7, 7), head_spatial_scale=1.0 / 16.0,
+                                head_sampling_ratio=0):
+    """Slow-style ResNet for detection (reference: resnet.py:844-1019): the last stage keeps the 1/16 map
+    (stride 1, conv_b dilated by 2) and the head pools every box with RoIAlign.  forward(x, bboxes)."""
+    model = create_resnet(
+        input_channel=input_channel, model_depth=model_depth, model_num_class=model_num_class,
+        dropout_rate=dropout_rate, norm=norm, activation=activation, stem_dim_out=stem_dim_out,
+        stem_conv_kernel_size=stem_conv_kernel_size, stem_conv_stride=stem_conv_stride, stem_pool=stem_pool,
+        stem_pool_kernel_size=stem_pool_kernel_size, stem_pool_stride=stem_pool_stride, stem=stem,
+        stage1_pool=stage1_pool, stage1_pool_kernel_size=stage1_pool_kernel_size,
+        stage_conv_a_kernel_size=stage_conv_a_kernel_size, stage_conv_b_kernel_size=stage_conv_b_kernel_size,
+        stage_conv_b_num_groups=stage_conv_b_num_groups, stage_conv_b_dilation=stage_conv_b_dilation,
+        stage_spatial_h_stride=stage_spatial_h_stride, stage_spatial_w_stride=stage_spatial_w_stride,
+        stage_temporal_stride=stage_temporal_stride, bottleneck=bottleneck, head=None)
+    detection_head = head(
+        in_features=stem_dim_out * 2 ** (len(_MODEL_STAGE_DEPTH[model_depth]) + 1),
+        out_features=model_num_class, pool=head_pool, output_size=head_output_size,
+        pool_kernel_size=head_pool_kernel_size, dropout_rate=dropout_rate, activation=head_activation,
+        output_with_global_average=head_output_with_global_average, resolution=head_spatial_resolution,
+        spatial_scale=head_spatial_scale, sampling_ratio=head_sampling_ratio)
+    return DetectionBBoxNetwork(model, detection_head)

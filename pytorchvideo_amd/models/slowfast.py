@@ -1,13 +1,12 @@
-"""SlowFast (reference: pytorchvideo/models/slowfast.py).  The RoI-head variant
-(slowfast.py:364-582) is out of scope."""
+"""SlowFast (reference: pytorchvideo/models/slowfast.py)."""
 from typing import Callable, List, Optional, Tuple, Union
 
 import torch
 import torch.nn as nn
 
 from ..layers.utils import set_attributes
-from .head import create_res_basic_head
-from .net import MultiPathWayWithFuse, Net
+from .head import create_res_basic_head, create_res_roi_pooling_head
+from .net import DetectionBBoxNetwork, MultiPathWayWithFuse, Net
 from .resnet import _conv_b_padding, _half, create_bottleneck_block, create_res_stage
 from .stem import create_res_basic_stem
 
@@ -175,3 +174,57 @@ def create_slowfast(*, slowfast_channel_reduction_ratio: Union[Tuple[int], int] 
                            activation=head_activation,
                            output_with_global_average=head_output_with_global_average))
     return Net(blocks=nn.ModuleList(stages))
+
+
+def create_slowfast_with_roi_head(*, slowfast_channel_reduction_ratio=(8,), slowfast_conv_channel_fusion_ratio=2,
+                                  slowfast_fusion_conv_kernel_size=(7, 1, 1),
+                                  slowfast_fusion_conv_stride=(4, 1, 1), fusion_builder=None,
+                                  input_channels=(3, 3), model_depth=50, model_num_class=80, dropout_rate=0.5,
+                                  norm=nn.BatchNorm3d, activation=nn.ReLU,
+                                  stem_function=(create_res_basic_stem, create_res_basic_stem),
+                                  stem_dim_outs=(64, 8), stem_conv_kernel_sizes=((1, 7, 7), (5, 7, 7)),
+                                  stem_conv_strides=((1, 2, 2), (1, 2, 2)),
+                                  stem_pool=(nn.MaxPool3d, nn.MaxPool3d),
+                                  stem_pool_kernel_sizes=((1, 3, 3), (1, 3, 3)),
+                                  stem_pool_strides=((1, 2, 2), (1, 2, 2)),
+                                  stage_conv_a_kernel_sizes=(((1, 1, 1), (1, 1, 1), (3, 1, 1), (3, 1, 1)),
+                                                             ((3, 1, 1), (3, 1, 1), (3, 1, 1), (3, 1, 1))),
+                                  stage_conv_b_kernel_sizes=(((1, 3, 3), (1, 3, 3), (1, 3, 3), (1, 3, 3)),
+                                                             ((1, 3, 3), (1, 3, 3), (1, 3, 3), (1, 3, 3))),
+                                  stage_conv_b_num_groups=((1, 1, 1, 1), (1, 1, 1, 1)),
+                                  stage_conv_b_dilations=(((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 2, 2)),
+                                                          ((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 2, 2))),
+                                  stage_spatial_strides=((1, 2, 2, 1), (1, 2, 2, 1)),
+                                  stage_temporal_strides=((1, 1, 1, 1), (1, 1, 1, 1)),
+                                  bottleneck=((create_bottleneck_block,) * 4, (create_bottleneck_block,) * 4),
+                                  head=create_res_roi_pooling_head, head_pool=nn.AvgPool3d,
+                                  head_pool_kernel_sizes=((8, 1, 1), (32, 1, 1)), head_output_size=(1, 1, 1),
+                                  head_activation=nn.Sigmoid, head_output_with_global_average=False,
+                                  head_spatial_resolution=(7, 7), head_spatial_scale=1.0 / 16.0,
+                                  head_sampling_ratio=0) -> nn.Module:
+    """SlowFast for detection (reference: slowfast.py:364-582): the backbone ends in PoolConcatPathway
+    (temporal pooling only), the RoI head works on the 1/16 map.  forward([slow, fast], bboxes).
+    Like the reference (slowfast.py:565), the stages are always built from create_bottleneck_block."""
+    model = create_slowfast(
+        slowfast_channel_reduction_ratio=slowfast_channel_reduction_ratio,
+        slowfast_conv_channel_fusion_ratio=slowfast_conv_channel_fusion_ratio,
+        slowfast_fusion_conv_kernel_size=slowfast_fusion_conv_kernel_size,
+        slowfast_fusion_conv_stride=slowfast_fusion_conv_stride, fusion_builder=fusion_builder,
+        input_channels=input_channels, model_depth=model_depth, model_num_class=model_num_class,
+        dropout_rate=dropout_rate, norm=norm, activation=activation, stem_function=stem_function,
+        stem_dim_outs=stem_dim_outs, stem_conv_kernel_sizes=stem_conv_kernel_sizes,
+        stem_conv_strides=stem_conv_strides, stem_pool=stem_pool,
+        stem_pool_kernel_sizes=stem_pool_kernel_sizes, stem_pool_strides=stem_pool_strides,
+        stage_conv_a_kernel_sizes=stage_conv_a_kernel_sizes, stage_conv_b_kernel_sizes=stage_conv_b_kernel_sizes,
+        stage_conv_b_num_groups=stage_conv_b_num_groups, stage_conv_b_dilations=stage_conv_b_dilations,
+        stage_spatial_strides=stage_spatial_strides, stage_temporal_strides=stage_temporal_strides,
+        bottleneck=create_bottleneck_block, head=None, head_pool=head_pool,
+        head_pool_kernel_sizes=head_pool_kernel_sizes)
+    stage_dim_out = stem_dim_outs[0] * 2 ** (len(_MODEL_STAGE_DEPTH[model_depth]) + 1)
+    slow_fast_beta = stem_dim_outs[0] // stem_dim_outs[1]
+    detection_head = create_res_roi_pooling_head(
+        in_features=stage_dim_out + stage_dim_out // slow_fast_beta, out_features=model_num_class, pool=None,
+        output_size=head_output_size, dropout_rate=dropout_rate, activation=head_activation,
+        output_with_global_average=head_output_with_global_average, resolution=head_spatial_resolution,
+        spatial_scale=head_spatial_scale, sampling_ratio=head_sampling_ratio)
+    return DetectionBBoxNetwork(model, detection_head)
