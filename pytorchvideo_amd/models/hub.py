@@ -95,3 +95,14 @@ def i3d_r50(pretrained=False, progress=True, checkpoint_path="", **kwargs):
                              default_config=dict(stem_conv_kernel_size=(5, 7, 7), stage1_pool=nn.MaxPool3d,
                                                  stage_conv_a_kernel_size=((3, 1, 1), [(3, 1, 1), (1, 1, 1)],
                                                                            [(3, 1, 1), (1, 1, 1)], [(1, 1, 1), (3, 1, 1)])), **kwargs)
+
+
+# hub/resnet.py:73-90 and hub/slowfast.py:150-180 -- the AVA detection models (defaults of the *_with_roi_head builders)
+def slow_r50_detection(pretrained=False, progress=True, checkpoint_path="", **kwargs):
+    from .resnet import create_resnet_with_roi_head
+    return hub_model_builder(create_resnet_with_roi_head, pretrained, progress, checkpoint_path, **kwargs)
+
+
+def slowfast_r50_detection(pretrained=False, progress=True, checkpoint_path="", **kwargs):
+    from .slowfast import create_slowfast_with_roi_head
+    return hub_model_builder(create_slowfast_with_roi_head, pretrained, progress, checkpoint_path, **kwargs)

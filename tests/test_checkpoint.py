@@ -47,3 +47,17 @@ def test_legacy_mvit_checkpoint_keys_are_remapped():
     hub.load_checkpoint(dst, {"model_state": old}, strict=False)   # the old names stay in the dict as unexpected keys
     for k, v in dst.state_dict().items():
         assert torch.equal(v, new[k]), k
+
+
+def test_detection_hub_builders_load_reference_keyed_checkpoints(tmp_path):
+    """slow_r50_detection / slowfast_r50_detection (reference hub/resnet.py:73-90, hub/slowfast.py:150-180): the AVA
+    checkpoints are keyed `model.blocks...` / `detection_head.proj...` (DetectionBBoxNetwork, models/net.py:47-74)."""
+    for build in (hub.slow_r50_detection, hub.slowfast_r50_detection):
+        src = build()
+        keys = list(src.state_dict().keys())
+        assert keys[0].startswith("model.blocks.0.") and keys[-2:] == ["detection_head.proj.weight", "detection_head.proj.bias"]
+        assert src.detection_head.proj.out_features == 80 and src.detection_head.roi_layer.spatial_scale == 1.0 / 16.0
+        path = tmp_path / "det.pyth"
+        torch.save({"model_state": src.state_dict()}, path)
+        dst = build(pretrained=True, checkpoint_path=str(path))
+        assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
