@@ -236,7 +236,9 @@ def _convert_detection(model, inputs, dtype, use_graph, kwargs):
         converted.model.forward = types.MethodType(backbone_forward, converted.model)
         converted.model.__dict__["_pv_session"] = sess
         converted.forward = types.MethodType(fused_forward, converted)
-        converted.__dict__["_pv_inputs"] = first_in
+        converted.__dict__["_pv_inputs"] = first_in   # transforms.DevicePacker: packed clip + boxes -> one replay
+        converted.__dict__["_pv_load_boxes"] = lambda b: sess.load_boxes(b, head._boxes, head._num_boxes)
+        converted.__dict__["_pv_result"] = lambda: head._result().reshape(head._num_boxes, -1)
     else:
         _convert_children(converted, lut, batch, "", sess, dtype, kwargs)
     sess.finalize()

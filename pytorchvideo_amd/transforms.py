@@ -70,7 +70,8 @@ class DevicePacker:
 
     `deployed` is what `convert_to_deployable_form` returned for a whole model (one graph replay per
     forward); `frame_ratios` must be given for multi-pathway models in the order of the model's
-    input list (SlowFast: slow = T/4 frames, fast = T frames), and left None for single-input models."""
+    input list (SlowFast: slow = T/4 frames, fast = T frames), and left None for single-input models.
+    A deployed detection model (DetectionBBoxNetwork) is called as `packer(clip, bboxes)`."""
 
     def __init__(self, deployed, mean=None, std=None, div255=False, frame_ratios=None):
         inputs = getattr(deployed, "_pv_inputs", None)
@@ -108,7 +109,10 @@ class DevicePacker:
         return self._index[key]
 
     @torch.no_grad()
-    def __call__(self, clip):
+    def __call__(self, clip, bboxes=None):
+        load_boxes = getattr(self.model, "_pv_load_boxes", None)
+        if (bboxes is None) != (load_boxes is None):
+            raise RuntimeError("bboxes are given to a detection model and only to a detection model")
         if clip.dim() != 5:
             raise RuntimeError("expected a [B,C,T,H,W] clip, got %s" % (tuple(clip.shape),))
         clip = clip.to(self.sess.device, non_blocking=True)
@@ -117,5 +121,7 @@ class DevicePacker:
             if t_src // ratio != ref.T:
                 raise RuntimeError("pathway with frame ratio %d expects %d frames, the clip gives %d" % (ratio, ref.T, t_src // ratio))
             self.sess.ingest(clip, ref, t_index=self._t_index(t_src, ref), ch_scale=self.scale, ch_shift=self.shift)
+        if load_boxes is not None:
+            load_boxes(bboxes)
         self.sess.launch(use_graph=self.model._pv_use_graph)
         return self.model._pv_result()

@@ -327,3 +327,22 @@ def test_detection_head_converted_on_its_own_takes_torch_features():
     got = blk(x.cuda(), boxes.cuda())
     assert tuple(got.shape) == tuple(want.shape)
     assert (got.cpu() - want).abs().max().item() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_device_packer_feeds_a_detection_model_from_the_decoded_uint8_clip():
+    """SURVEY 8f-1 + 8f-4 together: uint8 frames -> subsample per pathway, /255, normalise, bf16, channels-last in
+    the ingest kernel; boxes uploaded; one graph replay."""
+    from pytorchvideo_amd import transforms as TR
+    g, m, x = _golden("slowfast_det_r50_small")
+    mean, std = (0.45, 0.45, 0.45), (0.225, 0.225, 0.225)
+    clip = torch.randint(0, 256, (1, 3, 16, 96, 96), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
+    norm = TR.Normalize(mean, std)
+    slow, fast = [norm(TR.div_255(t.float())) for t in TR.uniform_temporal_subsample_repeated(clip, (4, 1), 2)]
+    dm, xd = _deploy_detection(m, [slow, fast], g["boxes"], torch.bfloat16)
+    want = dm(list(xd), g["boxes"]).clone()
+    got = TR.DevicePacker(dm, mean, std, div255=True, frame_ratios=(4, 1))(clip.cuda(), g["boxes"])
+    assert tuple(got.shape) == tuple(want.shape)
+    assert (got - want).abs().max().item() <= 2.5e-2           # the two packings agree to one bf16 rounding of the input
+    with pytest.raises(RuntimeError):
+        TR.DevicePacker(dm, mean, std, div255=True, frame_ratios=(4, 1))(clip.cuda())
