@@ -1,0 +1,89 @@
+"""The reference's own layer / factory tests as gates (SURVEY.md 8c "tests to port"), with VALUES instead of
+shapes: every host mirror must produce what the real reference produced for the same key-addressed weights
+and seeded input (tests/golden/layers.pt, made by tests/golden/make_layer_golden.py where the reference
+is importable), expose identical state_dict keys, and raise the reference's exception types."""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+from layer_cases import LAYER_CASES, MVIT_CASES  # noqa: E402
+from make_layer_golden import run_case  # noqa: E402  (no reference import at module level)
+
+GOLD = torch.load(os.path.join(HERE, "golden", "layers.pt"), weights_only=False)
+
+
+def _check(name, module, spec, seed):
+    g = GOLD[name]
+    assert [(k, tuple(v.shape)) for k, v in module.state_dict().items()] == g["state_keys"], "state_dict differs from the reference's"
+    got = run_case(module, spec, seed)
+    assert len(got) == len(g["outputs"])
+    for a, b in zip(got, g["outputs"]):
+        assert tuple(a.shape) == tuple(b.shape)
+        assert (a.float() - b.float()).abs().max().item() <= 1e-5 * max(1.0, b.float().abs().max().item())
+
+
+@pytest.mark.parametrize("idx", range(len(LAYER_CASES)), ids=[c[0] for c in LAYER_CASES])
+def test_layer_matches_the_reference(idx):
+    name, mod, attr, kwargs, spec = LAYER_CASES[idx]
+    m = getattr(importlib.import_module("pytorchvideo_amd." + mod), attr)(**kwargs)
+    _check(name, m, spec, idx)
+
+
+@pytest.mark.parametrize("idx", range(len(MVIT_CASES)), ids=[c[0] for c in MVIT_CASES])
+def test_mvit_input_forms_match_the_reference(idx):
+    """Video [B,C,T,H,W], image [B,C,H,W] with use_2d_patch, pre-embedded tokens [B,N,C] with enable_patch_embed=False
+    (reference tests/test_models_vision_transformers.py:54-93), rectangular crops, mean-pool head."""
+    from pytorchvideo_amd.models import create_multiscale_vision_transformers
+    name, cfg, shape = MVIT_CASES[idx]
+    _check(name, create_multiscale_vision_transformers(**cfg), ("tensor", shape), 100 + idx)
+
+
+def test_error_conventions_follow_the_reference():
+    """wrong channel count -> RuntimeError (tests/test_models_x3d.py:64-67, test_models_csn.py:63-66,
+    test_layers_convolutions.py:76-79); configuration errors -> AssertionError / NotImplementedError at construction."""
+    from pytorchvideo_amd.layers import ConvReduce3D, create_conv_2plus1d
+    from pytorchvideo_amd.models import (create_csn, create_multiscale_vision_transformers, create_r2plus1d, create_resnet,
+                                         create_slowfast)
+    c = ConvReduce3D(in_channels=4, out_channels=8, kernel_size=((1, 1, 1), (1, 3, 3)), padding=((0, 0, 0), (0, 1, 1)))
+    with pytest.raises(RuntimeError):
+        c(torch.rand(1, 8, 3, 7, 7))
+    with pytest.raises(RuntimeError):
+        create_conv_2plus1d(in_channels=4, out_channels=8)(torch.rand(1, 5, 3, 7, 7))
+    for factory, x in ((create_csn, torch.rand(1, 4, 4, 32, 32)), (create_r2plus1d, torch.rand(1, 4, 4, 32, 32)),
+                       (create_resnet, torch.rand(1, 4, 4, 32, 32))):
+        with pytest.raises(RuntimeError), torch.no_grad():
+            factory(model_num_class=4, head_pool_kernel_size=(1, 1, 1)).eval()(x)
+    with pytest.raises(AssertionError):
+        create_slowfast()(torch.rand(1, 3, 8, 64, 64))                         # SlowFast takes a list (net.py:108-110)
+    for depth_factory in (create_csn, create_r2plus1d, create_resnet, create_slowfast):
+        with pytest.raises(AssertionError):
+            depth_factory(model_depth=51)                                      # unknown depth (resnet.py:728-730)
+    with pytest.raises(AssertionError):                                        # use_2d_patch needs temporal_size == 1
+        create_multiscale_vision_transformers(spatial_size=32, temporal_size=4, depth=1, use_2d_patch=True)
+    with pytest.raises(NotImplementedError):                                   # vision_transformers.py:341
+        create_multiscale_vision_transformers(spatial_size=32, temporal_size=4, depth=1, norm="groupnorm")
+
+
+def test_builder_hooks_take_replacement_callables():
+    """Constructor-injection boundary of SURVEY 8b: create_res_basic_stem(conv=, pool=, norm=, activation=),
+    create_x3d(norm=, activation=, inner_act=), create_slowfast(fusion_builder=)."""
+    from pytorchvideo_amd.models import create_res_basic_stem, create_slowfast, create_x3d
+    stem = create_res_basic_stem(in_channels=3, out_channels=8, pool=nn.AvgPool3d, norm=None, activation=nn.ELU)
+    assert isinstance(stem.pool, nn.AvgPool3d) and stem.norm is None and isinstance(stem.activation, nn.ELU)
+    m = create_x3d(input_clip_length=4, input_crop_size=64, norm=nn.BatchNorm3d, activation=nn.ELU, inner_act=nn.SiLU)
+    assert isinstance(m.blocks[0].activation, nn.ELU)
+    calls = []
+
+    def fusion_builder(fusion_dim_in, stage_idx):
+        calls.append((fusion_dim_in, stage_idx))
+        return nn.Identity()
+
+    create_slowfast(model_depth=18, fusion_builder=fusion_builder)
+    assert calls == [(64, 0), (256, 1), (512, 2), (1024, 3), (2048, 4)]       # stem + every stage (slowfast.py:255-330)
