@@ -238,7 +238,7 @@ def _probe(module):
                 return False
             if not isinstance(module.proj, nn.Linear):
                 return False
-            if module.activation is not None and not isinstance(module.activation, nn.Softmax):
+            if module.activation is not None and not isinstance(module.activation, (nn.Softmax, nn.Sigmoid, nn.ReLU)):
                 return False
             if module.dropout is not None and not isinstance(module.dropout, nn.Dropout):
                 return False

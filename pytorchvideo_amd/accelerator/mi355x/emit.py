@@ -686,22 +686,20 @@ def emit_res_head(sess, head, x):
     # dropout is the identity in eval
     if head.dropout is not None and not isinstance(head.dropout, nn.Dropout):
         raise Unsupported("head dropout %s" % _cls_name(head.dropout))
-    logits = _emit_linear_rows(sess, head.proj, cur, y_f32=True, label="head.proj")
+    a = head.activation
+    if a is not None and not isinstance(a, (nn.Softmax, nn.Sigmoid, nn.ReLU)):
+        raise Unsupported("head activation %s" % _cls_name(a))
+    # element-wise activations (Sigmoid: the multi-label heads, ReLU) ride in the projection's epilogue
+    act = L.ACT_SIGMOID if isinstance(a, nn.Sigmoid) else (L.ACT_RELU if isinstance(a, nn.ReLU) else L.ACT_NONE)
+    logits = _emit_linear_rows(sess, head.proj, cur, act=act, y_f32=True, label="head.proj")
     if cur is not x:
         sess.release(cur)
-    a = head.activation
-    if a is not None:
-        rows = logits.B * logits.voxels
-        if isinstance(a, nn.Softmax):
-            if a.dim != 1:
-                raise Unsupported("softmax over dim %s" % a.dim)
-            f = dict(x=logits.ptr, y=logits.ptr, gamma=None, beta=None, rows=rows, C=logits.C,
-                     ldx=logits.ld, ldy=logits.ld, rows_per_batch=0, eps=0.0, dtype=L.PV_F32)
-            sess.add_op(L.OP_SOFTMAX_ROWS, f, label="head.softmax")
-        elif isinstance(a, nn.Sigmoid):
-            raise Unsupported("sigmoid head activation")  # TODO: fold into proj epilogue
-        else:
-            raise Unsupported("head activation %s" % _cls_name(a))
+    if isinstance(a, nn.Softmax):
+        if a.dim != 1:
+            raise Unsupported("softmax over dim %s" % a.dim)
+        f = dict(x=logits.ptr, y=logits.ptr, gamma=None, beta=None, rows=logits.B * logits.voxels, C=logits.C,
+                 ldx=logits.ld, ldy=logits.ld, rows_per_batch=0, eps=0.0, dtype=L.PV_F32)
+        sess.add_op(L.OP_SOFTMAX_ROWS, f, label="head.softmax")
     if head.output_pool is None:
         return logits
     if not isinstance(head.output_pool, nn.AdaptiveAvgPool3d) or _triple(head.output_pool.output_size) != (1, 1, 1):

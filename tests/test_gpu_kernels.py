@@ -183,6 +183,7 @@ def test_layernorm_per_head_with_periodic_parameter_table(dtype, tokens, heads, 
 @pytest.mark.parametrize("M,K,N,act,res", [
     (785 * 2, 768, 3072, L.ACT_GELU, False), (3137, 384, 1152, L.ACT_NONE, False),
     (1001, 96, 288, L.ACT_NONE, True), (785, 3072, 768, L.ACT_NONE, True), (50, 768, 400, L.ACT_NONE, False),
+    (333, 96, 80, L.ACT_SIGMOID, False), (77, 2048, 80, L.ACT_SIGMOID, False),    # multi-label heads: streaming / LDS-DMA kernel
 ])
 def test_linear_as_pointwise_conv(dtype, M, K, N, act, res):
     x = _rand((1, M, K), 41, dtype)
@@ -194,6 +195,8 @@ def test_linear_as_pointwise_conv(dtype, M, K, N, act, res):
         want = want + r.float()
     if act == L.ACT_GELU:
         want = F.gelu(want)
+    if act == L.ACT_SIGMOID:
+        want = torch.sigmoid(want)
     y = torch.zeros(1, M, N, dtype=dtype, device="cuda")
     d = L.Conv3dDesc()
     d.x, d.w, d.y, d.shift = x.data_ptr(), w.data_ptr(), y.data_ptr(), bias.data_ptr()

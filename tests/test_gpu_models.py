@@ -196,7 +196,8 @@ def _mirror_case(create, cfg, x, dtype):
     (dict(slowfast_channel_reduction_ratio=(4,), stem_dim_outs=(32, 8)), 4),      # beta = 1/4: wider fast pathway
     (dict(slowfast_fusion_conv_stride=(2, 1, 1)), 2),                              # alpha = 2
     (dict(head_activation=torch.nn.Softmax), 4),
-], ids=["fuse5x1x1", "beta4", "alpha2", "softmax"])
+    (dict(head_activation=torch.nn.Sigmoid), 4),                                   # multi-label head (Charades / AVA style)
+], ids=["fuse5x1x1", "beta4", "alpha2", "softmax", "sigmoid"])
 def test_slowfast_variants_match_the_host_mirror(extra, alpha, dtype, tol):
     """create_slowfast option sweep (reference tests/test_models_slowfast.py:20-120) through the plugin boundary."""
     from pytorchvideo_amd.models import create_slowfast
