@@ -107,8 +107,11 @@ def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quant
     if not fused:
         # Modules a transmuter declined stay in their original form (reference convention,
         # transmuter_mobile_cpu.py:21-22) and run as ordinary torch modules between the converted blocks:
-        # they have to live where the activations do, in the plan's storage type.
-        converted.to(device=sess.device, dtype=dtype)
+        # they have to live where the activations do, in the plan's storage type -- except around MViT blocks,
+        # whose token stream is fp32 in every plan (position encoding before them, final norm and head after them).
+        from .blocks import Mi355xMViTBlock
+        tokens = any(isinstance(b, Mi355xMViTBlock) for b in converted.modules())
+        converted.to(device=sess.device, dtype=torch.float32 if tokens else dtype)
     converted.__dict__["_pv_session"] = sess
     converted.__dict__["_pv_use_graph"] = use_graph
     return converted
@@ -262,8 +265,8 @@ def _is_fusable_mvit(model, input_tensor):
     blocks = getattr(model, "blocks", None)
     return (type(model).__name__ == "MultiscaleVisionTransformers" and blocks is not None and len(blocks) > 0
             and all(isinstance(b, Mi355xMViTBlock) for b in blocks)
-            and isinstance(input_tensor, torch.Tensor) and input_tensor.dim() == 5
-            and type(model.patch_embed).__name__ == "PatchEmbed")
+            and isinstance(input_tensor, torch.Tensor) and type(model.patch_embed).__name__ == "PatchEmbed"
+            and input_tensor.dim() == (4 if isinstance(model.patch_embed.patch_model, nn.Conv2d) else 5))
 
 
 def _try_fuse_mvit(model, sess, dtype, input_tensor):
@@ -274,7 +277,9 @@ def _try_fuse_mvit(model, sess, dtype, input_tensor):
     from . import emit_mvit as EM
     from ... import _lib as L
 
-    B, Cc, T, H, W = [int(v) for v in input_tensor.shape]
+    # an image model (use_2d_patch, vision_transformers.py:301-312) takes [B,C,H,W]: a clip of one frame
+    image = input_tensor.dim() == 4
+    B, Cc, T, H, W = [int(v) for v in (input_tensor.unsqueeze(2) if image else input_tensor).shape]
     first_in = sess.alloc_input(B, T, H, W, Cc)
     n_ops = len(sess.ops)
     try:
@@ -294,6 +299,10 @@ def _try_fuse_mvit(model, sess, dtype, input_tensor):
 
     def fused_forward(self, x):
         s = self._pv_session
+        if image:
+            if x.dim() != 4:
+                raise L.PvError("deploy form was converted for images [B,C,H,W], got %s" % (tuple(x.shape),))
+            x = x.unsqueeze(2)
         if not s.matches(x, first_in):
             s.ingest(x, first_in)
         s.launch(use_graph=self._pv_use_graph)

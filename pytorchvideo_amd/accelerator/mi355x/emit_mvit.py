@@ -411,8 +411,17 @@ def emit_patch_embed_and_pos(sess, patch_embed, cls_pos, x):
     if _cls_name(patch_embed) != "PatchEmbed":
         raise Unsupported("patch embed %s" % _cls_name(patch_embed))
     conv = patch_embed.patch_model
+    if isinstance(conv, nn.Conv2d):     # use_2d_patch: the same conv on a one-frame clip (x is [B,1,H,W,C] here)
+        if conv.padding_mode != "zeros" or isinstance(conv.padding, str):
+            raise Unsupported("2-D patch embedding padding %s" % (conv.padding,))
+        c3 = nn.Conv3d(conv.in_channels, conv.out_channels, (1,) + tuple(conv.kernel_size), (1,) + tuple(conv.stride),
+                       (0,) + tuple(conv.padding), (1,) + tuple(conv.dilation), conv.groups, conv.bias is not None)
+        c3.weight.data = conv.weight.detach().unsqueeze(2)
+        if conv.bias is not None:
+            c3.bias.data = conv.bias.detach()
+        conv = c3
     if not isinstance(conv, nn.Conv3d):
-        raise Unsupported("2-D patch embedding")
+        raise Unsupported("patch embedding %s" % _cls_name(conv))
     if E.check_conv3d(conv):
         raise Unsupported("depthwise patch embedding")
     T, H, W = cls_pos.patch_embed_shape()

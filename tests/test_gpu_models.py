@@ -172,6 +172,41 @@ def test_mvit_variants_match_the_host_mirror(extra, dtype, tol):
     assert all(type(b).__name__ == "Mi355xMViTBlock" and b.convert_flag for b in dm.blocks)
 
 
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("form", ["image_2d_patch", "pre_embedded_tokens"])
+def test_mvit_other_input_forms_match_the_host_mirror(form, dtype, tol):
+    """The two other input forms of MultiscaleVisionTransformers (reference tests/test_models_vision_transformers.py:54-93):
+    an image [B,C,H,W] with use_2d_patch -- still one launch plan, the Conv2d runs as the conv of a one-frame clip -- and
+    pre-embedded tokens [B,N,C] with enable_patch_embed=False, where the blocks are deployed one by one between the
+    reference's own (torch) position encoding and head."""
+    from pytorchvideo_amd.models import create_multiscale_vision_transformers as create
+    if form == "image_2d_patch":
+        cfg = dict(_MV, temporal_size=1, use_2d_patch=True, conv_patch_embed_kernel=(7, 7), conv_patch_embed_stride=(4, 4),
+                   conv_patch_embed_padding=(3, 3))
+        x = seeded_input((2, 3, 64, 64), 4)
+    else:
+        cfg = dict(_MV, spatial_size=16, temporal_size=2, enable_patch_embed=False, input_channels=96)
+        x = seeded_input((2, 2 * 16 * 16, 96), 4)
+    torch.manual_seed(0)
+    m = create(**cfg)
+    deterministic_fill(m, 4).eval()
+    ref = create(**cfg).eval()
+    if dtype == torch.bfloat16:
+        sd_q, x_q = quantize_like_kernels(m.state_dict(), x)
+        ref.load_state_dict(sd_q)
+    else:
+        ref.load_state_dict(m.state_dict())
+        x_q = x
+    with torch.no_grad():
+        want = ref(x_q)
+    dm, xd = _deploy(m, x, dtype)
+    got = dm(xd)
+    assert got.shape == want.shape
+    assert rel_err(got.float(), want) <= tol
+    assert all(type(b).__name__ == "Mi355xMViTBlock" and b.convert_flag for b in dm.blocks)
+    assert (getattr(dm, "_pv_inputs", None) is not None) == (form == "image_2d_patch")
+
+
 def _mirror_case(create, cfg, x, dtype):
     torch.manual_seed(0)
     m = create(**cfg)
