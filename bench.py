@@ -147,13 +147,19 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # one event per step on the launch stream (a few microseconds each): the spread of the step time, SURVEY 8d
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         out = step()
+        marks[i + 1].record()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: round(step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))], 4)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,7 +239,8 @@ def main():
         line = {
             "metric": "clips/sec forward", "value": round(clips_s, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 4), "step_ms": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9)},
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "per_gpu_batch": batch,
                        "global_batch": batch * world, "parallelism": "dp%d (batch-sharded, logits all_gather)" % world,
