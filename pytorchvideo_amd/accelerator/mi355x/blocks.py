@@ -329,13 +329,19 @@ class Mi355xMViTBlock(Mi355xBlock):
         from . import emit_mvit as EM
         assert self.convert_flag is False, "already converted, cannot be converted again"
         self.eval()
+        if input_ref is None and thw is None:
+            if session is not None:
+                raise L.PvError("MultiScaleBlock.convert needs thw=(T,H,W) of the token grid")
+            # The reference's convert driver records only the size of a module's first input
+            # (model_conversion.py:13-43), not the grid: finish the conversion at the first forward, which
+            # brings thw along (the deploy form is specialised to that grid from then on).
+            self.__dict__.update(_pending=(tuple(int(v) for v in input_blob_size), dtype), convert_flag=True)
+            return
         sess = session
         if sess is None:
             sess = Session(dtype=dtype or torch.bfloat16)
             self.__dict__["_owns_session"] = True
         if input_ref is None:
-            if thw is None:
-                raise L.PvError("MultiScaleBlock.convert needs thw=(T,H,W) of the token grid")
             B, N, Cc = [int(v) for v in input_blob_size]
             input_ref = sess.alloc_act(B, 1, 1, N, Cc, f32=True)  # the residual stream is fp32
             input_ref.thw, input_ref.has_cls = tuple(int(v) for v in thw), bool(self.has_cls_embed)
@@ -347,6 +353,13 @@ class Mi355xMViTBlock(Mi355xBlock):
         self.__dict__["convert_flag"] = True
 
     def _deploy_forward(self, x, thw_shape=None):
+        pending = self.__dict__.pop("_pending", None)
+        if pending is not None:
+            if thw_shape is None:
+                raise L.PvError("the first forward of a lazily converted MultiScaleBlock needs thw_shape")
+            size, dtype = pending
+            self.__dict__["convert_flag"] = False
+            self.convert(size, dtype=dtype, thw=thw_shape)
         sess = self._sess
         sess.finalize()
         ref = self._in_ref

@@ -5,12 +5,19 @@ pytorchvideo/accelerator/deployment/common/model_transmuter.py:16-86).
 `nn.Module -> Optional[nn.Module]`; `transmute_model` walks the children of `model`, asks
 every transmuter of the target device, installs the first non-None answer in place and
 recurses into children nobody claimed.  A transmuter declines by returning None.
+
+Inside a PyTorchVideo installation the registry below IS the reference's dict: importing
+`pytorchvideo_amd.accelerator` registers the "mi355x" target there, and the reference's own
+`transmute_model(model, target_device="mi355x")` works unchanged.
 """
 import logging
 
 import torch.nn as nn
 
-EFFICIENT_BLOCK_TRANSMUTER_REGISTRY = {}
+try:
+    from pytorchvideo.accelerator.deployment.common.model_transmuter import EFFICIENT_BLOCK_TRANSMUTER_REGISTRY
+except ImportError:
+    EFFICIENT_BLOCK_TRANSMUTER_REGISTRY = {}
 
 
 def _first_match(module, transmuters, where):

@@ -82,6 +82,26 @@ def test_mvit_block_standalone_fp32():
         assert list(thw_new) == [2, 8, 8]
 
 
+def test_mvit_block_finishes_its_conversion_at_the_first_forward_when_the_driver_gives_no_grid():
+    """The reference's convert driver passes only the size of a block's first input (model_conversion.py:13-43, 66-71):
+    convert(size, convert_for_quantize=..., native_conv3d_op_qnnpack=...) without thw.  The block then converts itself
+    when the first forward brings the grid."""
+    from pytorchvideo_amd.accelerator import transmute_model
+    from pytorchvideo_amd.models import create_multiscale_vision_transformers
+    g, m, x = _golden_case("mvit_b_small", create_multiscale_vision_transformers)
+    _, outs = OF.mvit_forward(m.state_dict(), x, g["cfg"], return_blocks=True)
+    transmute_model(m, "mi355x")
+    blk = m.blocks[1]                                   # pools q: (2,16,16) -> (2,8,8)
+    blk.convert(tuple(outs[0].shape), convert_for_quantize=False, native_conv3d_op_qnnpack=False, dtype=torch.float32)
+    assert blk.convert_flag and blk._sess is None       # nothing emitted yet
+    y, thw_new = blk(outs[0].cuda(), [2, 16, 16])
+    assert rel_err(y, outs[1]) <= 1e-3 and list(thw_new) == [2, 8, 8]
+    y2, _ = blk(outs[0].cuda(), [2, 16, 16])
+    assert torch.equal(y, y2)
+    with pytest.raises(AssertionError):
+        blk.convert(tuple(outs[0].shape))
+
+
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("name", ["slowfast_r18_small", "slowfast_r50_small"])
 def test_slowfast_matches_oracle(name, dtype, tol):
