@@ -16,8 +16,8 @@ mvit_video_base_config = {  # hub/vision_transformers.py:21-29 (16x4)
 }
 mvit_video_base_32x3_config = dict(mvit_video_base_config, temporal_size=32)  # :31-39
 
-slowfast_r50_config = dict(model_depth=50)      # hub/slowfast.py:59-66 (defaults)
-slowfast_r101_config = dict(model_depth=101)    # hub/slowfast.py:69-100
+slowfast_r50_config = dict(model_depth=50, slowfast_fusion_conv_kernel_size=(7, 1, 1))      # hub/slowfast.py:59-66
+slowfast_r101_config = dict(model_depth=101, slowfast_fusion_conv_kernel_size=(5, 1, 1))    # hub/slowfast.py:92-99
 csn_r101_config = dict(model_depth=101, stem_pool=None)  # hub/csn.py (torch nn.MaxPool3d -> see factory)
 r2plus1d_r50_config = dict(model_depth=50, dropout_rate=0.5)  # hub/r2plus1d.py
 
@@ -106,3 +106,41 @@ def slow_r50_detection(pretrained=False, progress=True, checkpoint_path="", **kw
 def slowfast_r50_detection(pretrained=False, progress=True, checkpoint_path="", **kwargs):
     from .slowfast import create_slowfast_with_roi_head
     return hub_model_builder(create_slowfast_with_roi_head, pretrained, progress, checkpoint_path, **kwargs)
+
+
+# hub/csn.py:20-58, hub/r2plus1d.py:20-56, hub/slowfast.py:101-147, hub/vision_transformers.py:41-54,127-158
+def csn_r101(pretrained=False, progress=True, checkpoint_path="", **kwargs):
+    import torch.nn as nn
+    from .csn import create_csn
+    return hub_model_builder(create_csn, pretrained, progress, checkpoint_path,
+                             default_config=dict(model_depth=101, stem_pool=nn.MaxPool3d, head_pool_kernel_size=(4, 7, 7)), **kwargs)
+
+
+def r2plus1d_r50(pretrained=False, progress=True, checkpoint_path="", **kwargs):
+    from .r2plus1d import create_r2plus1d
+    return hub_model_builder(create_r2plus1d, pretrained, progress, checkpoint_path, default_config=dict(dropout_rate=0.5), **kwargs)
+
+
+def slowfast_16x8_r101_50_50(pretrained=False, progress=True, checkpoint_path="", **kwargs):
+    """SlowFast R101 whose res4 has temporal conv_a kernels in its first 6 blocks only."""
+    from .slowfast import create_slowfast
+    res4 = ((3, 1, 1),) * 6 + ((1, 1, 1),) * (23 - 6)
+    return hub_model_builder(create_slowfast, pretrained, progress, checkpoint_path, default_config=dict(
+        model_depth=101, slowfast_fusion_conv_kernel_size=(5, 1, 1),
+        stage_conv_a_kernel_sizes=(((1, 1, 1), (1, 1, 1), res4, (3, 1, 1)), ((3, 1, 1), (3, 1, 1), res4, (3, 1, 1))),
+        head_pool_kernel_sizes=((16, 7, 7), (64, 7, 7))), **kwargs)
+
+
+mvit_image_base_16_config = {
+    "spatial_size": 224, "temporal_size": 1, "depth": 16, "conv_patch_embed_kernel": [7, 7],
+    "conv_patch_embed_stride": [4, 4], "conv_patch_embed_padding": [3, 3], "use_2d_patch": True,
+    "embed_dim_mul": [[1, 2.0], [3, 2.0], [14, 2.0]], "atten_head_mul": [[1, 2.0], [3, 2.0], [14, 2.0]],
+    "pool_q_stride_size": [[1, 1, 2, 2], [3, 1, 2, 2], [14, 1, 2, 2]], "pool_kv_stride_adaptive": [1, 4, 4],
+    "pool_kvq_kernel": [1, 3, 3],
+}
+mvit_base_16 = _named("create_multiscale_vision_transformers", "vision_transformers", mvit_image_base_16_config)
+
+# the entry points of the reference's hubconf.py that lie on the path (efficient_x3d_* are the mobile_cpu models)
+HUB_ENTRYPOINTS = ["x3d_xs", "x3d_s", "x3d_m", "x3d_l", "slow_r50", "c2d_r50", "i3d_r50", "slow_r50_detection",
+                   "slowfast_r50", "slowfast_r101", "slowfast_16x8_r101_50_50", "slowfast_r50_detection",
+                   "csn_r101", "r2plus1d_r50", "mvit_base_16", "mvit_base_16x4", "mvit_base_32x3"]

@@ -48,6 +48,12 @@ SEEDED = [
 ]
 
 
+# the hub entry points of the reference's hubconf.py that lie on the path (models/hub/*.py), built with their defaults
+HUB = ["x3d_xs", "x3d_s", "x3d_m", "x3d_l", "slow_r50", "c2d_r50", "i3d_r50", "slow_r50_detection", "slowfast_r50",
+       "slowfast_r101", "slowfast_16x8_r101_50_50", "slowfast_r50_detection", "csn_r101", "r2plus1d_r50", "mvit_base_16",
+       "mvit_base_16x4", "mvit_base_32x3"]
+
+
 def _norm(v):
     """A default value without object identity: functions / classes by name (the mirror's callables are its own)."""
     if isinstance(v, (tuple, list)):
