@@ -31,6 +31,23 @@ def test_div255_and_normalize_match_their_definitions():
     assert torch.allclose(yb[0], want, rtol=0, atol=1e-6)
 
 
+def test_host_transforms_equal_the_reference_functions():
+    """uniform_temporal_subsample(_repeated) and div_255 against outputs of the real reference's
+    pytorchvideo/transforms/functional.py:19-41,134-160 (tests/golden/transforms.pt, made by make_transforms_golden.py)."""
+    import os
+    import sys
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold_dir)
+    from make_transforms_golden import CASES, REPEATED, clip
+    g = torch.load(os.path.join(gold_dir, "transforms.pt"), weights_only=False)
+    for i, (shape, n, dim) in enumerate(CASES):
+        assert torch.equal(TR.uniform_temporal_subsample(clip(shape, i), n, dim), g["subsample"][i])
+    for i, (shape, ratios, dim) in enumerate(REPEATED):
+        got = TR.uniform_temporal_subsample_repeated(clip(shape, 50 + i), ratios, dim)
+        assert len(got) == len(g["repeated"][i]) and all(torch.equal(a, b) for a, b in zip(got, g["repeated"][i]))
+    assert torch.equal(TR.div_255(clip((3, 4, 5, 6), 99)), g["div_255"])
+
+
 def test_device_packer_rejects_models_that_were_not_converted_whole():
     with pytest.raises(RuntimeError):
         TR.DevicePacker(torch.nn.Identity())
