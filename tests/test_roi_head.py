@@ -37,6 +37,20 @@ def test_roi_align_hand_computed_case():
     assert OF.roi_align(x, box, 1, 1.0, sampling_ratio=1, aligned=True).item() == pytest.approx(1.0)
 
 
+def test_roi_align_published_known_answer():
+    """The known-answer vectors of detectron2's public ROIAlign test (tests/layers/test_roi_align.py, `test_forward_output`):
+    a 5x5 ramp arange(25), box (1, 1, 3, 3), 4x4 bins, scale 1, sampling_ratio 0.  detectron2.layers.ROIAlign wraps
+    torchvision.ops.roi_align and is the other `roi` the reference's head names (models/head.py:245-247); `old_results`
+    there is aligned=False (what the reference builds), `correct_results` aligned=True."""
+    x = torch.arange(25, dtype=torch.float32).reshape(1, 1, 5, 5)
+    box = torch.tensor([[0, 1.0, 1.0, 3.0, 3.0]])
+    old = torch.tensor([[7.5, 8, 8.5, 9], [10, 10.5, 11, 11.5], [12.5, 13, 13.5, 14], [15, 15.5, 16, 16.5]])
+    new = torch.tensor([[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0], [12.0, 12.5, 13.0, 13.5]])
+    for fn in (OF.roi_align, roi_align):
+        assert torch.allclose(fn(x, box, (4, 4), 1.0, 0, False)[0, 0], old, atol=1e-6)
+        assert torch.allclose(fn(x, box, (4, 4), 1.0, 0, True)[0, 0], new, atol=1e-6)
+
+
 def test_roi_align_is_exact_on_affine_maps_and_zero_outside():
     H, W = 9, 11
     ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
