@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
-from .session import TRef, pad8
+from .session import pad8
 
 
 class Unsupported(Exception):

@@ -1,7 +1,7 @@
 """Multiscale Vision Transformers (reference: pytorchvideo/models/vision_transformers.py).
 `fuse_bn` (:123-170) is not mirrored: it is broken in the reference snapshot."""
 from functools import partial
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, List, Optional
 
 import torch
 import torch.nn as nn

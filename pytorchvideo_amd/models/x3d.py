@@ -4,7 +4,6 @@ plumbing / training), the MI355X deploy form is produced by
 `pytorchvideo_amd.accelerator.transmute_model(model, "mi355x")` + `convert_to_deployable_form`.
 """
 import math
-from typing import Callable, Tuple
 
 import numpy as np
 import torch

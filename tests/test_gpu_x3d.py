@@ -12,7 +12,6 @@ import os
 
 import pytest
 import torch
-import torch.nn.functional as F
 
 from oracle import functional as OF
 from oracle.weights import deterministic_fill, quantize_like_kernels, reference_style_fill, seeded_input

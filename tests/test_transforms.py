@@ -57,7 +57,6 @@ def test_device_packer_rejects_models_that_were_not_converted_whole():
 @pytest.mark.parametrize("c4", [True, False])
 def test_ingest_fuses_frame_selection_scaling_and_normalisation(c4):
     """pv_ingest_ncdhw with t_index / ch_scale / ch_shift on uint8 frames against the host transforms."""
-    import ctypes as C
     from pytorchvideo_amd import _lib as L
     from gpu_util import call
     B, T, H, W, Tout = 2, 16, 9, 11, 4
