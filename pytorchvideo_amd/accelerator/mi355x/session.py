@@ -183,8 +183,22 @@ class Session:
     # ------------------------------------------------------------------ ops
     def add_op(self, kind, fields, label="", alg_bytes=0, flops=0):
         assert not self.finalized
+        self._check_live(fields, label)
         self.ops.append((kind, L.DESC_FOR_OP[kind], fields, label, alg_bytes, flops))
         return len(self.ops) - 1
+
+    def _check_live(self, fields, label):
+        """Ops run in the order they are emitted, so a buffer an op touches must be allocated at the moment the
+        op is emitted: an arena pointer outside every live allocation is a use-after-release (or a write into
+        memory some later tensor will own) in the emitter that produced it."""
+        if not self.reuse:
+            return
+        for name, v in fields.items():
+            for p in (v if isinstance(v, (list, tuple)) else (v,)):
+                if isinstance(p, Ptr) and p.space == "arena" and not any(
+                        o <= p.off < o + n for o, n in self._arena.live.items()):
+                    raise L.PvError("plan emitter bug: op '%s' field '%s' points at arena offset %d, which is not inside a "
+                                    "live allocation (released too early?)" % (label, name, p.off))
 
     # ------------------------------------------------------------------ finalize / run
     def finalize(self):

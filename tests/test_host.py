@@ -163,3 +163,18 @@ def test_mvit_plan_fuses_kv_pooling_and_position_tables():
     assert all(f["y_f32"] == 1 for l, f in ops if l.split("|")[0] in ("attn.proj", "mlp.fc2"))
     # small token grids: q, k and v of a block are pooled (conv + cls + LayerNorm) by ONE launch
     assert labels.count("attn.pool_qkv") >= 14 and not any(l.endswith(".norm") and "pool" in l for l in labels)
+
+
+def test_an_op_that_touches_a_released_buffer_is_rejected_at_emission():
+    """Ops run in emission order, so every arena pointer of an op must lie in a live allocation when the op is
+    emitted; the emitters release a buffer only after its last consumer."""
+    from pytorchvideo_amd import _lib as L
+    sess = Session(dtype=torch.bfloat16)
+    a, b = sess.alloc_act(1, 1, 4, 4, 16), sess.alloc_act(1, 1, 4, 4, 16)
+    f = dict(a=a.ptr, b=b.ptr, y=b.ptr, rows=16, C=16, lda=16, ldb=16, ldy=16, act=L.ACT_NONE, dtype=L.PV_BF16)
+    sess.add_op(L.OP_ADD_ACT, f, label="ok")
+    sess.release(a)
+    with pytest.raises(RuntimeError, match="not inside a live allocation"):
+        sess.add_op(L.OP_ADD_ACT, f, label="stale")
+    f2 = dict(f, a=b.channel_slice(8, 8).ptr)       # a channel slice of a live buffer is fine
+    sess.add_op(L.OP_ADD_ACT, f2, label="slice")
