@@ -17,15 +17,18 @@ def main(per_op, trace, first="stem_c4"):
         if m:
             ops.append((m.group(1).split("|")[0], float(m.group(2))))
     rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
+    starts = []
+    for i, r in enumerate(rows):   # a replay begins at the first-kernel symbol, at least one plan length after the previous one
+        if first in r["Kernel_Name"] and (not starts or i - starts[-1] >= len(ops)):
+            starts.append(i)
     fam = lambda l: l.split(".")[0] if l.startswith(("conv_b", "conv_ab")) else l
     ev, rp, sym, n_replays = collections.OrderedDict(), collections.defaultdict(float), collections.defaultdict(set), 0
     for label, ms in ops:
         ev[fam(label)] = ev.get(fam(label), 0.0) + ms
     for s in starts:
         seg = rows[s:s + len(ops)]
-        if len(seg) < len(ops):
-            continue
+        if len(seg) < len(ops) or any(first in r["Kernel_Name"] for r in seg[len(ops) // 2:]):
+            continue    # truncated, or not a whole replay (another one starts inside it)
         n_replays += 1
         for (label, _), r in zip(ops, seg):
             rp[fam(label)] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
