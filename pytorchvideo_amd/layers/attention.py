@@ -60,19 +60,18 @@ class _AttentionPool(nn.Module):
         if ndim == 3:
             tensor = tensor.unsqueeze(1)
         elif ndim != 4:
-            raise NotImplementedError(f"Unsupported input dimension {tensor.shape}")
-        cls_tok = None
+            raise NotImplementedError("Unsupported input dimension (expected (B,N,C) or (B,heads,N,C) tokens)")
+        cls_tok = tensor[:, :, :1, :]
         if self.has_cls_embed:
-            cls_tok, tensor = tensor[:, :, :1, :], tensor[:, :, 1:, :]
-        B, N, L, C = tensor.shape
-        T, H, W = thw_shape
-        grid = tensor.reshape(B * N, T, H, W, C).permute(0, 4, 1, 2, 3).contiguous()
+            tensor = tensor[:, :, 1:, :]
+        B, N, C = tensor.shape[0], tensor.shape[1], tensor.shape[3]
+        grid = tensor.reshape(B * N, thw_shape[0], thw_shape[1], thw_shape[2], C).permute(0, 4, 1, 2, 3).contiguous()
         if self.norm_before_pool:
             grid = nn.functional.gelu(self.norm(grid))
         grid = self.pool(grid)
         thw_shape = [grid.shape[2], grid.shape[3], grid.shape[4]]
         tensor = grid.reshape(B, N, C, thw_shape[0] * thw_shape[1] * thw_shape[2]).transpose(2, 3)
-        if cls_tok is not None:
+        if self.has_cls_embed:
             tensor = torch.cat((cls_tok, tensor), dim=2)
         if self.has_norm and not self.norm_before_pool:
             tensor = self.norm(tensor)
@@ -81,7 +80,7 @@ class _AttentionPool(nn.Module):
         return tensor, thw_shape
 
 
-def _prod(shape) -> int:
+def _prod(shape: List[int]) -> int:
     p = 1
     for d in shape:
         p *= d
@@ -157,7 +156,7 @@ class MultiScaleAttention(nn.Module):
         self._attention_pool_k = _AttentionPool(self.pool_k, has_cls_embed, getattr(self, "norm_k", None))
         self._attention_pool_v = _AttentionPool(self.pool_v, has_cls_embed, getattr(self, "norm_v", None))
 
-    def _heads(self, t, B, n):
+    def _heads(self, t: torch.Tensor, B: int, n: int) -> torch.Tensor:
         return t.reshape(B, n, self.num_heads, -1).permute(0, 2, 1, 3)
 
     def forward(self, x: torch.Tensor, thw_shape: List[int]) -> Tuple[torch.Tensor, List[int]]:
@@ -245,18 +244,21 @@ class MultiScaleBlock(nn.Module):
             if len(stride_q) > 0 and numpy.prod(stride_q) > 1 else None)
         self._attention_pool = _AttentionPool(self.pool_skip, has_cls_embed=self.has_cls_embed, norm=None)
 
-    @staticmethod
-    def _norm(norm, is_bn1d, x):
-        return norm(x.permute(0, 2, 1)).permute(0, 2, 1) if is_bn1d else norm(x)
-
     def forward(self, x: torch.Tensor, thw_shape: List[int]) -> Tuple[torch.Tensor, List[int]]:
-        x_norm = self._norm(self.norm1, self.norm1_is_batchnorm_1d, x)
+        # BatchNorm1d normalises dim 1, the tokens' channel dim is the last one
+        if self.norm1_is_batchnorm_1d:
+            x_norm = self.norm1(x.permute(0, 2, 1)).permute(0, 2, 1)
+        else:
+            x_norm = self.norm1(x)
         x_block, thw_new = self.attn(x_norm, thw_shape)
         if self.dim_mul_in_att and self.dim != self.dim_out:
             x = self.proj(x_norm)
         x_res, _ = self._attention_pool(x, thw_shape)
         x = x_res + self.drop_path(x_block)
-        x_norm = self._norm(self.norm2, self.norm2_is_batchnorm_1d, x)
+        if self.norm2_is_batchnorm_1d:
+            x_norm = self.norm2(x.permute(0, 2, 1)).permute(0, 2, 1)
+        else:
+            x_norm = self.norm2(x)
         x_mlp = self.mlp(x_norm)
         if not self.dim_mul_in_att and self.dim != self.dim_out:
             x = self.proj(x_norm)

@@ -3,18 +3,18 @@ import torch
 import torch.nn as nn
 
 
-def drop_path(x, drop_prob=0.0, training=False):
+def drop_path(x: torch.Tensor, drop_prob: float = 0.0, training: bool = False) -> torch.Tensor:
     if drop_prob == 0.0 or not training:
         return x
     keep = 1.0 - drop_prob
-    shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+    shape = [x.shape[0]] + [1] * (x.ndim - 1)
     mask = keep + torch.rand(shape, dtype=x.dtype, device=x.device)
     mask.floor_()
     return x.div(keep) * mask
 
 
 class DropPath(nn.Module):
-    def __init__(self, drop_prob=None):
+    def __init__(self, drop_prob: float = 0.0):
         super().__init__()
         self.drop_prob = drop_prob
 

@@ -34,6 +34,7 @@ class SpatioTemporalClsPositionalEncoding(nn.Module):
             self.pos_embed = nn.Parameter(torch.zeros(1, n_tokens, embed_dim))
             self.pos_embed_spatial = self.pos_embed_temporal = self.pos_embed_class = empty
 
+    @torch.jit.export
     def patch_embed_shape(self) -> Tuple[int, int, int]:
         return self._patch_embed_shape
 

@@ -135,9 +135,13 @@ class VisionTransformerBasicHead(nn.Module):
         assert self.proj is not None
 
     def forward(self, x):
-        for stage in (self.sequence_pool, self.dropout, self.proj, self.activation):
-            if stage is not None:
-                x = stage(x)
+        if self.sequence_pool is not None:
+            x = self.sequence_pool(x)
+        if self.dropout is not None:
+            x = self.dropout(x)
+        x = self.proj(x)
+        if self.activation is not None:
+            x = self.activation(x)
         return x
 
 

@@ -29,11 +29,20 @@ class BottleneckBlock(nn.Module):
         if self.norm_c is not None:
             self.norm_c.block_final_bn = True
 
-    def forward(self, x):
-        for name in ("conv_a", "norm_a", "act_a", "conv_b", "norm_b", "act_b", "conv_c", "norm_c"):
-            op = getattr(self, name)
-            if op is not None:
-                x = op(x)
+    def forward(self, x):        # spelled out op by op so that the block stays TorchScript-able like the reference's
+        x = self.conv_a(x)
+        if self.norm_a is not None:
+            x = self.norm_a(x)
+        if self.act_a is not None:
+            x = self.act_a(x)
+        x = self.conv_b(x)
+        if self.norm_b is not None:
+            x = self.norm_b(x)
+        if self.act_b is not None:
+            x = self.act_b(x)
+        x = self.conv_c(x)
+        if self.norm_c is not None:
+            x = self.norm_c(x)
         return x
 
 
@@ -54,7 +63,9 @@ class ResBlock(nn.Module):
             if self.branch1_norm is not None:
                 shortcut = self.branch1_norm(shortcut)
         x = self.branch_fusion(shortcut, self.branch2(x))
-        return x if self.activation is None else self.activation(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
 
 
 class ResStage(nn.Module):

@@ -20,11 +20,14 @@ class ResNetBasicStem(nn.Module):
         set_attributes(self, locals())
         assert self.conv is not None
 
-    def forward(self, x):
+    def forward(self, x):        # spelled out stage by stage: TorchScript compiles absent (None) stages away
         x = self.conv(x)
-        for stage in (self.norm, self.activation, self.pool):
-            if stage is not None:
-                x = stage(x)
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        if self.pool is not None:
+            x = self.pool(x)
         return x
 
 

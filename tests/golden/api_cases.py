@@ -28,7 +28,7 @@ SYMBOLS = [
     ("layers.convolutions", "create_conv_2plus1d"), ("layers.convolutions", "ConvReduce3D"), ("layers.convolutions", "Conv2plus1d"),
     ("layers.attention", "Mlp"), ("layers.attention", "MultiScaleAttention"), ("layers.attention", "MultiScaleBlock"),
     ("layers.positional_encoding", "SpatioTemporalClsPositionalEncoding"),
-    ("layers.swish", "Swish"), ("layers.utils", "round_width"), ("layers.utils", "round_repeats"),
+    ("layers.swish", "Swish"), ("layers.drop_path", "DropPath"), ("layers.utils", "round_width"), ("layers.utils", "round_repeats"),
 ]
 
 _MV = dict(spatial_size=32, temporal_size=4, depth=2, patch_embed_dim=16, num_heads=1, head_num_classes=5)

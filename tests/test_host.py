@@ -101,7 +101,35 @@ def test_arena_reuses_and_coalesces():
 
 
 def test_block_wrapper_resolves_class_level_helpers_of_the_adopted_module():
-    """The original-form forward of a transmuted MultiScaleBlock uses a staticmethod of its class."""
+    """The original-form forward of an adopted module may use static / class methods, properties and constants of
+    its class: the wrapper resolves them on the class it adopted."""
+
+    class Helper(nn.Module):
+        GAIN = 3.0
+
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(4, 4)
+
+        @staticmethod
+        def twice(x):
+            return 2 * x
+
+        @classmethod
+        def gain(cls):
+            return cls.GAIN
+
+        @property
+        def width(self):
+            return self.lin.out_features
+
+        def forward(self, x):
+            return self.twice(self.lin(x)) * self.gain() + self.width
+
+    h = Helper().eval()
+    xin = torch.randn(2, 4)
+    with torch.no_grad():
+        assert torch.equal(Mi355xBlock(h)(xin), h(xin))
     from pytorchvideo_amd.models import create_multiscale_vision_transformers as create
     m = create(spatial_size=32, temporal_size=4, depth=2, patch_embed_dim=32, num_heads=1, head_num_classes=5,
                pool_q_stride_size=[[1, 1, 2, 2]], pool_kv_stride_adaptive=[1, 2, 2], pool_kvq_kernel=[3, 3, 3],

@@ -87,3 +87,40 @@ def test_builder_hooks_take_replacement_callables():
 
     create_slowfast(model_depth=18, fusion_builder=fusion_builder)
     assert calls == [(64, 0), (256, 1), (512, 2), (1024, 3), (2048, 4)]       # stem + every stage (slowfast.py:255-330)
+
+
+@pytest.mark.parametrize("family", ["mvit", "mvit_no_cls_max_pool", "mvit_pool_first", "resnet", "csn"])
+def test_torchscript_parity_where_the_reference_is_scriptable(family):
+    """Style 4 of the reference's tests (tests/test_models_vision_transformers.py:120-168, test_layers_attention.py:127-191):
+    torch.jit.script(model) equals eager.  The reference's MViT, ResNet and CSN script (its X3D, R(2+1)D and SlowFast do
+    not -- numpy ints in pool sizes, a Module used as a bool, ModuleList indexing); the mirrors script where it does."""
+    from pytorchvideo_amd.models import create_csn, create_multiscale_vision_transformers, create_resnet
+    mv = dict(spatial_size=32, temporal_size=4, depth=2, patch_embed_dim=16, num_heads=1, head_num_classes=5,
+              pool_q_stride_size=[[1, 1, 2, 2]], pool_kv_stride_adaptive=[1, 2, 2], pool_kvq_kernel=[3, 3, 3],
+              embed_dim_mul=[[1, 2.0]], atten_head_mul=[[1, 2.0]])
+    torch.manual_seed(0)
+    if family == "resnet":
+        m, x = create_resnet(model_num_class=7, head_pool_kernel_size=(4, 2, 2)), torch.randn(1, 3, 4, 64, 64)
+    elif family == "csn":
+        m, x = create_csn(model_num_class=7, head_pool_kernel_size=(1, 2, 2)), torch.randn(1, 3, 4, 64, 64)
+    else:
+        extra = {"mvit": {}, "mvit_no_cls_max_pool": dict(cls_embed_on=False, sep_pos_embed=False, pooling_mode="max"),
+                 "mvit_pool_first": dict(pool_first=True, separate_qkv=False)}[family]
+        m, x = create_multiscale_vision_transformers(**dict(mv, **extra)), torch.randn(2, 3, 4, 32, 32)
+    m.eval()
+    scripted = torch.jit.script(m)
+    with torch.no_grad():
+        assert torch.equal(scripted(x), m(x))
+
+
+def test_multiscale_block_is_scriptable():
+    from pytorchvideo_amd.layers import MultiScaleBlock
+    for kw in (dict(), dict(dim_mul_in_att=True), dict(kernel_q=(3, 3, 3), stride_q=(2, 2, 1), pool_mode="avg"),
+               dict(has_cls_embed=False, separate_qkv=False, residual_pool=True, bias_on=False, depthwise_conv=False,
+                    kernel_kv=(3, 3, 3), stride_kv=(1, 2, 5))):
+        blk = MultiScaleBlock(10, 20, 2, **kw).eval()
+        n = 80 + (1 if kw.get("has_cls_embed", True) else 0)
+        x = torch.randn(2, n, 10)
+        y, thw = blk(x, [4, 4, 5])
+        ys, thws = torch.jit.script(blk)(x, [4, 4, 5])
+        assert torch.equal(y, ys) and list(thw) == list(thws)
