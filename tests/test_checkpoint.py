@@ -61,3 +61,20 @@ def test_detection_hub_builders_load_reference_keyed_checkpoints(tmp_path):
         torch.save({"model_state": src.state_dict()}, path)
         dst = build(pretrained=True, checkpoint_path=str(path))
         assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
+
+
+def test_torch_hub_load_from_the_local_repo():
+    """The reference's hub tests (tests/test_models_x3d.py:82-119, test_models_slowfast.py:19-41,
+    test_models_hub_vision_transformers.py:16-38): torch.hub.load(<repo root>, source="local", model=name,
+    pretrained=False) then a forward."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name, x in (("x3d_xs", torch.rand(1, 3, 4, 160, 160)), ("mvit_base_16", None)):
+        m = torch.hub.load(repo_or_dir=root, source="local", model=name, pretrained=False).eval()
+        if x is not None:
+            with torch.no_grad():
+                assert m(x).shape == (1, 400)
+        else:
+            assert type(m).__name__ == "MultiscaleVisionTransformers" and isinstance(m.patch_embed.patch_model, torch.nn.Conv2d)
+    import hubconf
+    assert all(callable(getattr(hubconf, n)) for n in ("x3d_m", "slowfast_r50", "slow_r50_detection", "mvit_base_32x3"))
