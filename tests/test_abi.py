@@ -61,3 +61,15 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("expected PvError")
+
+
+def test_random_descriptors_never_crash_the_library(pv_lib):
+    """1500 random descriptors over all 15 compute entry points, then 600 geometrically consistent conv / depthwise
+    descriptors that get past validation into the host-side routing: every call returns a non-positive status."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "abi_fuzz.py"), "7", "100"],
+                       capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=root, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+    assert r.returncode == 0 and r.stdout.startswith("ok 1500 calls") and "structured ok" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
