@@ -3,7 +3,6 @@ layer_cases.py -> tests/golden/layers.pt.  Runs only where /root/reference exist
 
     python tests/golden/make_layer_golden.py
 """
-import importlib
 import os
 import sys
 
@@ -13,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 
-from layer_cases import LAYER_CASES, MVIT_CASES  # noqa: E402
+from layer_cases import LAYER_CASES, MVIT_CASES, build_case  # noqa: E402
 from oracle import ref_shim  # noqa: E402
 from oracle.weights import deterministic_fill, seeded_input  # noqa: E402
 
@@ -25,6 +24,9 @@ def run_case(module, spec, seed):
         if spec[0] == "tokens":
             y, thw = module(seeded_input(spec[1], seed), list(spec[2]))
             return [y, torch.tensor(list(thw))]
+        if spec[0] == "list":
+            out = module([seeded_input(s, seed + j) for j, s in enumerate(spec[1])])
+            return list(out) if isinstance(out, (list, tuple)) else [out]
         return [module(seeded_input(spec[1], seed))]
 
 
@@ -32,7 +34,7 @@ def main():
     ref_shim.install()
     out = {}
     for i, (name, mod, attr, kwargs, spec) in enumerate(LAYER_CASES):
-        m = getattr(importlib.import_module("pytorchvideo." + mod), attr)(**kwargs)
+        m = build_case("pytorchvideo", mod, attr, kwargs)
         out[name] = {"outputs": run_case(m, spec, i), "state_keys": [(k, tuple(v.shape)) for k, v in m.state_dict().items()]}
     from pytorchvideo.models.vision_transformers import create_multiscale_vision_transformers
     for i, (name, cfg, shape) in enumerate(MVIT_CASES):

@@ -2,7 +2,6 @@
 shapes: every host mirror must produce what the real reference produced for the same key-addressed weights
 and seeded input (tests/golden/layers.pt, made by tests/golden/make_layer_golden.py where the reference
 is importable), expose identical state_dict keys, and raise the reference's exception types."""
-import importlib
 import os
 import sys
 
@@ -13,7 +12,7 @@ import torch.nn as nn
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
-from layer_cases import LAYER_CASES, MVIT_CASES  # noqa: E402
+from layer_cases import LAYER_CASES, MVIT_CASES, build_case  # noqa: E402
 from make_layer_golden import run_case  # noqa: E402  (no reference import at module level)
 
 GOLD = torch.load(os.path.join(HERE, "golden", "layers.pt"), weights_only=False)
@@ -32,8 +31,7 @@ def _check(name, module, spec, seed):
 @pytest.mark.parametrize("idx", range(len(LAYER_CASES)), ids=[c[0] for c in LAYER_CASES])
 def test_layer_matches_the_reference(idx):
     name, mod, attr, kwargs, spec = LAYER_CASES[idx]
-    m = getattr(importlib.import_module("pytorchvideo_amd." + mod), attr)(**kwargs)
-    _check(name, m, spec, idx)
+    _check(name, build_case("pytorchvideo_amd", mod, attr, kwargs), spec, idx)
 
 
 @pytest.mark.parametrize("idx", range(len(MVIT_CASES)), ids=[c[0] for c in MVIT_CASES])
