@@ -54,6 +54,16 @@ HUB = ["x3d_xs", "x3d_s", "x3d_m", "x3d_l", "slow_r50", "c2d_r50", "i3d_r50", "s
        "mvit_base_16x4", "mvit_base_32x3"]
 
 
+def rounding_table(root):
+    """round_width / round_repeats (layers/utils.py:19-49) over the ranges the factories use and beyond."""
+    u = importlib.import_module(root + ".layers.utils")
+    widths = [[w, m, mn, dv, c, u.round_width(w, m, mn, dv, c)]
+              for w in (1, 3, 8, 12, 24, 54, 96, 100, 192, 432, 2048) for m in (0.0, 0.0625, 0.25, 0.9, 1.0, 1.5, 2.0, 2.25, 5.0)
+              for mn, dv in ((8, 8), (1, 1), (None, 8), (16, 4)) for c in (False, True)]
+    repeats = [[r, m, u.round_repeats(r, m)] for r in (1, 2, 3, 5, 11, 25) for m in (0.0, 0.5, 1.0, 2.2, 5.0)]
+    return {"round_width": widths, "round_repeats": repeats}
+
+
 def _norm(v):
     """A default value without object identity: functions / classes by name (the mirror's callables are its own)."""
     if isinstance(v, (tuple, list)):

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 
-from api_cases import HUB, SEEDED, SYMBOLS, resolve, seeded_fingerprint, signature_of  # noqa: E402
+from api_cases import HUB, SEEDED, SYMBOLS, resolve, rounding_table, seeded_fingerprint, signature_of  # noqa: E402
 from oracle import ref_shim  # noqa: E402
 
 
@@ -19,7 +19,8 @@ def main():
     ref_shim.install()
     out = {"signatures": {"%s.%s" % (m, n): signature_of(resolve("pytorchvideo", m, n)) for m, n in SYMBOLS},
            "seeded": {tag: seeded_fingerprint("pytorchvideo", m, n, cfg) for tag, m, n, cfg in SEEDED},
-           "hub": {n: seeded_fingerprint("pytorchvideo", "models.hub", n, {}, seed=1) for n in HUB}}
+           "hub": {n: seeded_fingerprint("pytorchvideo", "models.hub", n, {}, seed=1) for n in HUB},
+           "rounding": rounding_table("pytorchvideo")}
     path = os.path.join(HERE, "api_surface.json")
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     print("wrote", path, len(out["signatures"]), "signatures,", len(out["seeded"]), "seeded constructions,", len(out["hub"]), "hub models")

@@ -11,7 +11,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
-from api_cases import HUB, SEEDED, SYMBOLS, resolve, seeded_fingerprint, signature_of  # noqa: E402
+from api_cases import HUB, SEEDED, SYMBOLS, resolve, rounding_table, seeded_fingerprint, signature_of  # noqa: E402
 
 GOLD = json.load(open(os.path.join(HERE, "golden", "api_surface.json")))
 
@@ -44,3 +44,10 @@ def test_hub_entry_point_builds_the_reference_model(name):
     want = GOLD["hub"][name]
     got = seeded_fingerprint("pytorchvideo_amd", "models.hub", name, {}, seed=1)
     assert (got["n_tensors"], got["next_rand"], got["sha256"]) == (want["n_tensors"], want["next_rand"], want["sha256"])
+
+
+def test_width_and_depth_rounding_tables_equal_the_reference():
+    """round_width / round_repeats decide every channel count and block count of X3D and MViT (layers/utils.py:19-49)."""
+    got = rounding_table("pytorchvideo_amd")
+    assert got["round_width"] == GOLD["rounding"]["round_width"] and len(got["round_width"]) == 792
+    assert got["round_repeats"] == GOLD["rounding"]["round_repeats"]
