@@ -9,20 +9,24 @@ resident in HBM in the reference's own layout ([B,3,T,H,W], bf16); every rank pr
 fixed per-GPU batch (weak scaling) and the step ends with the single head collective
 (all_gather of the [B_local, 400] fp32 logits).  Rank 0 prints ONE JSON line.
 
-N=1 default workload = BASELINE.json configs[1]: X3D-M, bf16, [32,3,16,224,224].
+`--gpus N` without a torchrun environment (WORLD_SIZE unset) re-executes this file under
+`torch.distributed.run` with N ranks on 127.0.0.1, so `python bench.py --gpus 8` is the same
+job as the explicit launcher line above.
+
+N=1 default workload = BASELINE.json configs[1]: X3D-M, bf16, [32,3,16,224,224]; the same line carries
+MViT-B 32x3 (configs[3], the other model BASELINE.json's metric names) under "secondary".
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFS = 2500.0    # dense bf16
@@ -37,33 +41,47 @@ WORKLOADS = {
                          desc="create_slowfast(model_depth=50) slow [B,3,8,256,256] + fast [B,3,32,256,256]"),
     "mvit_b_32x3": dict(batch=8, gflop=339.92, mb=1465.0, bound="mfma",
                         desc="create_multiscale_vision_transformers(**mvit_video_base_32x3_config) [B,3,32,224,224]"),
+    # launcher check only (tests/test_bench_launcher.py): tiny clip, original-form model on the host, gloo
+    "x3d_xs_dry": dict(batch=2, gflop=1.211, mb=0.0, bound="hbm",
+                       desc="create_x3d(input_clip_length=4,input_crop_size=160) [B,3,4,160,160]"),
 }
 
 
 def make_model(name):
-    """(original-form model, input shape(s), oracle forward) of a workload."""
-    from oracle import functional as OF  # only used by the cpu_baseline leg
-    if name in ("x3d_m", "x3d_l"):
+    """(original-form model, input shape(s)) of a workload."""
+    if name in ("x3d_m", "x3d_l", "x3d_xs_dry"):
         from pytorchvideo_amd.models import create_x3d
         kw = dict(input_clip_length=16, input_crop_size=224)
         if name == "x3d_l":
             kw["depth_factor"] = 5.0
-        return create_x3d(**kw), (3, 16, 224, 224), lambda sd, x: OF.x3d_forward(sd, x, 16, 224)
+        if name == "x3d_xs_dry":
+            kw = dict(input_clip_length=4, input_crop_size=160)
+        return create_x3d(**kw), (3, kw["input_clip_length"], kw["input_crop_size"], kw["input_crop_size"])
     if name == "slowfast_r50":
         from pytorchvideo_amd.models import create_slowfast
-        return (create_slowfast(model_depth=50), [(3, 8, 256, 256), (3, 32, 256, 256)],
-                lambda sd, x: OF.slowfast_forward(sd, x[0], x[1]))
+        return create_slowfast(model_depth=50), [(3, 8, 256, 256), (3, 32, 256, 256)]
     if name == "mvit_b_32x3":
         from pytorchvideo_amd.models import create_multiscale_vision_transformers
         from pytorchvideo_amd.models.hub import mvit_video_base_32x3_config as cfg
-        return (create_multiscale_vision_transformers(**cfg), (3, 32, 224, 224),
-                lambda sd, x: OF.mvit_forward(sd, x, cfg))
+        return create_multiscale_vision_transformers(**cfg), (3, 32, 224, 224)
     raise SystemExit("unknown workload %s" % name)
+
+
+def oracle_forward(name):
+    """CPU oracle of a workload: ONLY the cpu_baseline leg calls this (oracle/ is test infrastructure)."""
+    from oracle import functional as OF
+    if name in ("x3d_m", "x3d_l"):
+        return lambda sd, x: OF.x3d_forward(sd, x, 16, 224)
+    if name == "slowfast_r50":
+        return lambda sd, x: OF.slowfast_forward(sd, x[0], x[1])
+    from pytorchvideo_amd.models.hub import mvit_video_base_32x3_config as cfg
+    return lambda sd, x: OF.mvit_forward(sd, x, cfg)
 
 
 def synth_input(shape, batch, seed):
     """Synthetic clips; SlowFast's slow pathway is the temporally subsampled fast pathway
     (PackPathway: uniform_temporal_subsample, transforms/functional.py:134-160)."""
+    import torch
     g = torch.Generator(device="cpu").manual_seed(seed)
     if isinstance(shape, list):
         fast = torch.randn((batch,) + tuple(shape[1]), generator=g)
@@ -73,140 +91,83 @@ def synth_input(shape, batch, seed):
 
 
 def build_model(name, batch, device, dtype):
+    import torch
     from pytorchvideo_amd.accelerator import convert_to_deployable_form, transmute_model
     from pytorchvideo_amd.utils import randomize_norm_stats
     torch.manual_seed(0)
-    model, shape, _ = make_model(name)
+    model, shape = make_model(name)
     randomize_norm_stats(model, 0)
     model.eval()
     x = synth_input(shape, batch, 1234 + int(os.environ.get("RANK", "0")))
     x = [t.to(dtype).to(device) for t in x] if isinstance(x, list) else x.to(dtype).to(device)
     transmute_model(model, "mi355x")
     deployed = convert_to_deployable_form(model, x, dtype=dtype)
-    return model, deployed, x
+    return deployed, x
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(name):
-    """The oracle (a CPU port of the reference forward) timed on this box's host cores, on a
-    bounded sample of the same workload.  Baseline, not target."""
+    """The oracle (oracle/functional.py: the reference forward restated op for op on torch-CPU, pinned bit-exact
+    to the reference by tests/golden) timed on this box's host cores, on a bounded sample of the same workload:
+    1 warm-up + 3 timed iterations, best of 3.  Baseline, not target."""
+    import torch
     from oracle.weights import reference_style_fill
+    nproc = os.cpu_count() or 1
     # big hosts (256 hw threads) run torch-CPU slower when oversubscribed: cap the thread count
-    cores = min(os.cpu_count() or 1, 32)
+    cores = min(nproc, 32)
     torch.set_num_threads(cores)
-    m, shape, oracle_fn = make_model(name)
+    m, shape = make_model(name)
+    oracle_fn = oracle_forward(name)
     reference_style_fill(m, 0).eval()
     sd = m.state_dict()
     b = {"x3d_m": 2, "x3d_l": 2, "slowfast_r50": 1, "mvit_b_32x3": 1}[name]
     x = synth_input(shape, b, 7)
+    times = []
     with torch.no_grad():
-        best = 1e30
-        for _ in range(2):
+        oracle_fn(sd, x)   # warm-up (oneDNN primitive creation, allocator)
+        for _ in range(3):
             t0 = time.perf_counter()
             oracle_fn(sd, x)
-            best = min(best, time.perf_counter() - t0)
+            times.append(time.perf_counter() - t0)
+    best = min(times)
     return {"value": round(b / best, 3), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "%d clips, fp32, torch-CPU oracle (oracle/functional.py), %d threads, best of 2" % (b, cores)}
+            "cpu": cpu_model_name(), "nproc": nproc, "iters_s": [round(t, 3) for t in times],
+            "sample": "%d clips, fp32, torch-CPU oracle (oracle/functional.py, op-for-op restatement of the reference, "
+                      "bit-exact vs the reference fixtures), %d threads, 1 warm-up + 3 timed, best of 3" % (b, cores)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="x3d_m")
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--with-h2d", action="store_true",
-                    help="also time steps that upload the (pinned) host input first; reported as pcie_inclusive, never as value")
-    args = ap.parse_args()
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-    from pytorchvideo_amd.parallel import gather_logits
 
-    wl = WORKLOADS[args.workload]
-    batch = args.batch or wl["batch"]
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    _, model, x = build_model(args.workload, batch, device, dtype)
-    if args.no_graph:
-        model.__dict__["_pv_use_graph"] = False
+def self_spawn(args):
+    """`python bench.py --gpus N` outside a torchrun environment: become the launcher."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    return subprocess.call(cmd, env=env)
 
-    def step():
-        return gather_logits(model(list(x) if isinstance(x, list) else x), global_batch=batch * world)
 
-    for _ in range(args.warmup):
-        out = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # one event per step on the launch stream (a few microseconds each): the spread of the step time, SURVEY 8d
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        out = step()
-        marks[i + 1].record()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    pct = lambda q: round(step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))], 4)
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    assert out.shape == (batch * world, 400) and torch.isfinite(out).all()
-
-    pcie = None
-    if args.with_h2d:   # the same steps with the host -> device upload of the batch inside the timed region
-        xs = x if isinstance(x, list) else [x]
-        hs = [t.cpu().pin_memory() for t in xs]
-        for _ in range(2):
-            for t, h in zip(xs, hs):
-                t.copy_(h, non_blocking=True)
-            out = step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            for t, h in zip(xs, hs):
-                t.copy_(h, non_blocking=True)
-            out = step()
-        torch.cuda.synchronize()
-        e1 = time.perf_counter() - t1
-        pcie = {"value": round(batch * args.steps / e1, 2), "unit": "clips/s (this rank)", "ms_per_step": round(e1 / args.steps * 1e3, 4),
-                "upload_bytes_per_step": int(sum(h.numel() * h.element_size() for h in hs))}
-        # ... and with the pre-path transforms fused into the ingest (pytorchvideo_amd.transforms.DevicePacker):
-        # one uint8 clip at the fast frame rate is uploaded, every pathway is subsampled / scaled / normalised
-        # on the device
-        from pytorchvideo_amd.transforms import DevicePacker
-        ratios = (xs[-1].shape[2] // xs[0].shape[2], 1) if len(xs) == 2 else None
-        packer = DevicePacker(model, (0.45,) * 3, (0.225,) * 3, div255=True, frame_ratios=ratios)
-        u8 = torch.randint(0, 256, tuple(xs[-1].shape), dtype=torch.uint8).pin_memory()
-        d8 = torch.empty_like(u8, device=device)
-        for _ in range(2):
-            d8.copy_(u8, non_blocking=True)
-            packer(d8)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            d8.copy_(u8, non_blocking=True)
-            packer(d8)
-        torch.cuda.synchronize()
-        e2 = time.perf_counter() - t2
-        pcie["u8_packed"] = {"value": round(batch * args.steps / e2, 2), "ms_per_step": round(e2 / args.steps * 1e3, 4),
-                             "upload_bytes_per_step": int(u8.numel())}
-
-    # per-kernel device time (HIP events on the launch stream, inside this process)
-    sess = model._pv_session
+def roofline_of(sess, workload, clips_s_per_gpu, ms_per_step):
+    """Per-kernel device time measured live (pv_plan_profile: in-situ HIP events on the launch stream, host
+    kept out of the measurement), folded per op family; the dominant family's algorithmic rate against its
+    roofline."""
+    wl = WORKLOADS[workload]
     prof = sess.profile(iters=3)
     agg = {}
     for label, kind, ms, alg_bytes, flops in prof:
@@ -223,39 +184,240 @@ def main():
     dom_gbs = dom[2] / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
     dom_tfs = dom[3] / (dom[1] * 1e-3) / 1e12 if dom[1] > 0 else 0.0
     mfma_bound = dom[2] > 0 and dom[3] / dom[2] > MFMA_PEAK_TFS * 1e12 / (HBM_PEAK_GBS * 1e9)
-
-    # HBM traffic of the dominant kernel family from the committed rocprofv3 PMC passes
-    # (tools/gpu_profile.sh + tools/summarize_pmc.py -> profiles/traffic.json), bytes per launch
-    traffic = None
+    # HBM traffic of that family from the rocprofv3 PMC passes of the SAME code (tools/gpu_profile.sh +
+    # tools/summarize_pmc.py -> profiles/traffic.json, stamped with the commit it was measured on)
+    traffic = traffic_commit = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        traffic = tj.get(args.workload, {}).get(dom_label, {}).get("hbm_bytes_per_launch")
+        traffic = tj.get(workload, {}).get(dom_label, {}).get("hbm_bytes_per_launch")
+        traffic_commit = tj.get("_measured_on", {}).get(workload)
     except (OSError, ValueError):
         pass
+    r = {
+        "bound": "mfma" if mfma_bound else "hbm", "kernel": dom_label, "launches_per_step": dom[0],
+        "achieved": round(dom_tfs if mfma_bound else dom_gbs, 1),
+        "peak": MFMA_PEAK_TFS if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
+        "frac": round(dom_tfs / MFMA_PEAK_TFS if mfma_bound else dom_gbs / HBM_PEAK_GBS, 4),
+        "traffic": traffic, "traffic_measured_on": traffic_commit,
+        "alg_bytes_per_launch": int(dom[2] / max(dom[0], 1)), "avg_launch_ms": round(dom[1] / max(dom[0], 1), 5),
+        "kernel_ms_per_step": round(dom[1], 4), "all_kernels_ms_per_step": round(total_kernel_ms, 4),
+        "launches_total": len(prof),
+        "timing": "pv_plan_profile: each op timed in situ between its own HIP event pair behind a queued replay, "
+                  "min of 3, null event interval subtracted",
+        "model_hbm_frac": round(clips_s_per_gpu * wl["mb"] * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
+        "model_mfma_frac": round(clips_s_per_gpu * wl["gflop"] * 1e9 / (MFMA_PEAK_TFS * 1e12), 4),
+    }
+    return r, prof, agg
+
+
+def timed_steps(step, steps, world, device):
+    """EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    out = None
+    for i in range(steps):
+        out = step()
+        marks[i + 1].record()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    return elapsed, step_ms, out
+
+
+def run_workload(name, args, world, rank, device, steps, warmup, sustained_s=0.0):
+    """Build, warm up, time; returns (result dict, deployed model, input)."""
+    import torch
+    from pytorchvideo_amd.parallel import gather_logits
+    wl = WORKLOADS[name]
+    batch = args.batch or wl["batch"]
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model, x = build_model(name, batch, device, dtype)
+    if args.no_graph:
+        model.__dict__["_pv_use_graph"] = False
+
+    def step():
+        return gather_logits(model(list(x) if isinstance(x, list) else x), global_batch=batch * world)
+
+    for _ in range(warmup):
+        out = step()
+    elapsed, step_ms, out = timed_steps(step, steps, world, device)
+    assert out.shape == (batch * world, 400) and torch.isfinite(out).all()
+    pct = lambda q: round(step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))], 4)
+    res = {"value": round(batch * world * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "step_ms": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9)}, "steps": steps, "per_gpu_batch": batch}
+    if sustained_s > 0:   # a run long enough for clocks / power to settle: same step, >= sustained_s seconds
+        n = max(steps, int(sustained_s / max(elapsed / steps, 1e-6)) + 1)
+        e2, _, _ = timed_steps(step, n, world, device)
+        res["sustained"] = {"seconds": round(e2, 3), "steps": n, "value": round(batch * world * n / e2, 2),
+                            "ms_per_step": round(e2 / n * 1e3, 4)}
+    return res, model, x, step
+
+
+def pcie_leg(model, x, step, batch, steps, device):
+    """The same steps with the host -> device upload of the batch inside the timed region (never `value`)."""
+    import torch
+    xs = x if isinstance(x, list) else [x]
+    hs = [t.cpu().pin_memory() for t in xs]
+    for _ in range(2):
+        for t, h in zip(xs, hs):
+            t.copy_(h, non_blocking=True)
+        step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        for t, h in zip(xs, hs):
+            t.copy_(h, non_blocking=True)
+        step()
+    torch.cuda.synchronize()
+    e1 = time.perf_counter() - t1
+    pcie = {"value": round(batch * steps / e1, 2), "unit": "clips/s (this rank)", "ms_per_step": round(e1 / steps * 1e3, 4),
+            "upload_bytes_per_step": int(sum(h.numel() * h.element_size() for h in hs))}
+    # ... and with the pre-path transforms fused into the ingest (pytorchvideo_amd.transforms.DevicePacker): one uint8
+    # clip at the fast frame rate is uploaded, every pathway is subsampled / scaled / normalised on the device
+    from pytorchvideo_amd.transforms import DevicePacker
+    ratios = (xs[-1].shape[2] // xs[0].shape[2], 1) if len(xs) == 2 else None
+    packer = DevicePacker(model, (0.45,) * 3, (0.225,) * 3, div255=True, frame_ratios=ratios)
+    u8 = torch.randint(0, 256, tuple(xs[-1].shape), dtype=torch.uint8).pin_memory()
+    d8 = torch.empty_like(u8, device=device)
+    for _ in range(2):
+        d8.copy_(u8, non_blocking=True)
+        packer(d8)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(steps):
+        d8.copy_(u8, non_blocking=True)
+        packer(d8)
+    torch.cuda.synchronize()
+    e2 = time.perf_counter() - t2
+    pcie["u8_packed"] = {"value": round(batch * steps / e2, 2), "ms_per_step": round(e2 / steps * 1e3, 4),
+                         "upload_bytes_per_step": int(u8.numel())}
+    return pcie
+
+
+def dry_host(args, world, rank):
+    """Launcher check without a GPU (tests/test_bench_launcher.py): the ORIGINAL-form model on the host, gloo.
+    Exercises exactly the spawn / rank binding / barrier / max-over-ranks / n_gpus reporting of the real run;
+    its number is not a measurement of the product path and the line says so."""
+    import torch
+    import torch.distributed as dist
+    from pytorchvideo_amd.parallel import gather_logits
+    torch.set_num_threads(2)
+    if world > 1:
+        dist.init_process_group("gloo")
+    torch.manual_seed(0)
+    model, shape = make_model("x3d_xs_dry")
+    model.eval()
+    batch = args.batch or 2
+    x = synth_input(shape, batch, 1234 + rank)
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = gather_logits(model(x), global_batch=batch * world)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = gather_logits(model(x), global_batch=batch * world)
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert out.shape == (batch * world, 400)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-host launcher check (NOT a measurement of the HIP path)",
+                          "value": round(batch * world * args.steps / elapsed, 3), "unit": "clips/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32",
+                          "data": "synthetic", "config": {"workload": "x3d_xs_dry: original-form model on the host, gloo",
+                                                           "per_gpu_batch": batch, "global_batch": batch * world,
+                                                           "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="x3d_m")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the MViT-B 32x3 leg of the N=1 line")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained run")
+    ap.add_argument("--with-h2d", action="store_true",
+                    help="also time steps that upload the (pinned) host input first; reported as pcie_inclusive, never as value")
+    ap.add_argument("--dry-host", action="store_true", help="launcher check on the host (gloo, original-form model); no GPU")
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_spawn(args))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.dry_host:
+        return dry_host(args, world, rank)
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    wl = WORKLOADS[args.workload]
+    res, model, x, step = run_workload(args.workload, args, world, rank, device, args.steps, args.warmup,
+                                       sustained_s=0.0 if args.no_sustained else 2.0)
+    batch = res["per_gpu_batch"]
+    pcie = pcie_leg(model, x, step, batch, args.steps, device) if args.with_h2d else None
+    roof, prof, agg = roofline_of(model._pv_session, args.workload, res["value"] / world, res["ms_per_step"])
+
+    secondary = None
+    if world == 1 and not args.no_secondary and args.workload == "x3d_m" and not args.batch:
+        del model, x, step
+        torch.cuda.empty_cache()
+        r2, m2, x2, _ = run_workload("mvit_b_32x3", args, 1, 0, device, max(10, args.steps // 2), 3, sustained_s=0.0)
+        roof2, _, _ = roofline_of(m2._pv_session, "mvit_b_32x3", r2["value"], r2["ms_per_step"])
+        secondary = {"mvit_b_32x3": {"value": r2["value"], "unit": "clips/s", "ms_per_step": r2["ms_per_step"],
+                                     "step_ms": r2["step_ms"], "steps": r2["steps"], "dtype": args.dtype,
+                                     "config": {"workload": "mvit_b_32x3: " + WORKLOADS["mvit_b_32x3"]["desc"],
+                                                "per_gpu_batch": r2["per_gpu_batch"]}, "roofline": roof2}}
+        del m2, x2
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        clips_s = batch * world * args.steps / elapsed
         line = {
-            "metric": "clips/sec forward", "value": round(clips_s, 2), "unit": "clips/s",
+            "metric": "clips/sec forward", "value": res["value"], "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "step_ms": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9)},
+            "ms_per_step": res["ms_per_step"], "step_ms": res["step_ms"],
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "per_gpu_batch": batch,
                        "global_batch": batch * world, "parallelism": "dp%d (batch-sharded, logits all_gather)" % world,
                        "weights": "random-init, randomised BN stats", "hip_graph": not args.no_graph},
-            "roofline": {
-                "bound": "mfma" if mfma_bound else "hbm", "kernel": dom_label, "launches_per_step": dom[0],
-                "achieved": round(dom_tfs if mfma_bound else dom_gbs, 1),
-                "peak": MFMA_PEAK_TFS if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                "frac": round(dom_tfs / MFMA_PEAK_TFS if mfma_bound else dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "alg_bytes_per_launch": int(dom[2] / max(dom[0], 1)), "avg_launch_ms": round(dom[1] / max(dom[0], 1), 5),
-                "kernel_ms_per_step": round(dom[1], 4), "all_kernels_ms_per_step": round(total_kernel_ms, 4),
-                "model_hbm_frac": round(clips_s / world * wl["mb"] * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
-                "model_mfma_frac": round(clips_s / world * wl["gflop"] * 1e9 / (MFMA_PEAK_TFS * 1e12), 4),
-            },
+            "roofline": roof,
         }
+        if "sustained" in res:
+            line["sustained"] = res["sustained"]
+        if secondary is not None:
+            line["secondary"] = secondary
         if pcie is not None:
             line["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:

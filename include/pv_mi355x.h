@@ -384,7 +384,9 @@ int pv_plan_launch(pv_plan* p, pv_stream_t stream);                 /* eager rep
 int pv_plan_launch_range(pv_plan* p, int first, int last, pv_stream_t stream);
 int pv_plan_graph_build(pv_plan* p, pv_stream_t stream);           /* capture+instantiate */
 int pv_plan_graph_launch(pv_plan* p, pv_stream_t stream);
-/* per-op device time in ms (HIP events on `stream`), averaged over `iters` replays */
+/* per-op device time in ms: every op timed in situ between its own pair of HIP events on `stream`, behind a
+ * queued un-instrumented replay (the host never paces the measurement); minimum over `iters` passes, minus the
+ * null interval of an empty event pair */
 int pv_plan_profile(pv_plan* p, pv_stream_t stream, int iters, float* ms_per_op);
 
 #ifdef __cplusplus

@@ -92,7 +92,9 @@ class Mi355xBlock(EfficientBlockBase):
         sess.launch(*self._op_range)
         out = self._out_ref
         if out.T == out.H == out.W == 1 and out.f32:
-            return sess.view_rows(out)[:, 0, :]
+            return sess.view_rows(out)[:, 0, :].clone()   # logits: a fresh tensor, like the reference's deploy form
+        # a block-level activation is handed on as a zero-copy view of the session arena (the next block of the
+        # same session recognises it and skips its ingest); it is valid until the next forward of this session
         return sess.view(out)
 
     def forward(self, *args, **kwargs):
@@ -181,7 +183,7 @@ class Mi355xRoIHeadBlock(Mi355xBlock):
             sess.ingest(x, self._in_ref)
         sess.load_boxes(bboxes, self._boxes, self._num_boxes)
         sess.launch(*self._op_range)
-        return self._result()
+        return self._result().clone()
 
 
 # ------------------------------------------------------------------------- transmuters

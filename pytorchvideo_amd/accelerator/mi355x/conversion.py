@@ -26,6 +26,14 @@ def _record_input_sizes(model, sample):
     lut, handles = {}, []
 
     def add(module, name):
+        def pre_hook(_m, _in):
+            # list-of-tensors input (SlowFast's MultiPathWayWithFuse / PoolConcatPathway, net.py:107-122): the
+            # reference's hook skips these (model_conversion.py:26-28); the MI355X multi-pathway blocks need them.
+            # Recorded BEFORE the forward: MultiPathWayWithFuse overwrites the caller's list in place (net.py:111-118)
+            if len(_in) > 0 and isinstance(_in[0], (list, tuple)) and len(_in[0]) > 0 and \
+                    all(isinstance(t, torch.Tensor) for t in _in[0]):
+                lut[name] = [tuple(t.size()) for t in _in[0]]
+
         def hook(_m, _in, _out):
             if len(_in) > 0 and isinstance(_in[0], torch.Tensor):
                 lut[name] = tuple(_in[0].size())
@@ -33,6 +41,7 @@ def _record_input_sizes(model, sample):
                     lut[name + "#thw"] = tuple(int(v) for v in _in[1])  # MultiScaleBlock(x, thw)
                 if len(_in) > 1 and isinstance(_in[1], torch.Tensor) and _in[1].dim() == 2:
                     lut[name + "#boxes"] = int(_in[1].shape[0])        # ResNetRoIHead(x, bboxes)
+        handles.append(module.register_forward_pre_hook(pre_hook))
         handles.append(module.register_forward_hook(hook))
         for child_name, child in module.named_children():
             add(child, f"{name}.{child_name}")
@@ -59,8 +68,12 @@ def _batch_of(x):
 def _convert_children(module, lut, batch, name, sess, dtype, kwargs):
     if isinstance(module, EfficientBlockBase):
         size = lut.get(name)
-        if size is not None:
-            size = (batch,) + tuple(size[1:])
+        # the probing forward ran on ONE clip: scale the leading dimension (it is B for the blocks of a Net and
+        # B*heads for a pool inside a declined attention module) instead of assuming it is the batch
+        if isinstance(size, list):
+            size = [(s[0] * batch,) + tuple(s[1:]) for s in size]
+        elif size is not None:
+            size = (size[0] * batch,) + tuple(size[1:])
         extra = dict(kwargs)
         if (name + "#thw") in lut:
             extra["thw"] = lut[name + "#thw"]
@@ -185,7 +198,7 @@ def _try_fuse_net(model, lut, batch, sess, dtype, input_tensor=None):
         return fused_result(self)
 
     model.forward = types.MethodType(fused_forward, model)
-    model.__dict__["_pv_result"] = lambda: fused_result(model)
+    model.__dict__["_pv_result"] = lambda: fused_result(model, zero_copy=True)
     return True
 
 
@@ -234,7 +247,7 @@ def _convert_detection(model, inputs, dtype, use_graph, kwargs):
             s.load_boxes(bboxes, head._boxes, head._num_boxes)
             s.launch(use_graph=self._pv_use_graph)
             out = head._result()
-            return out.reshape(out.shape[0], -1)    # net.py:74
+            return out.reshape(out.shape[0], -1).clone()    # net.py:74; fresh tensor, not a view of the arena
 
         converted.model.forward = types.MethodType(backbone_forward, converted.model)
         converted.model.__dict__["_pv_session"] = sess
@@ -252,10 +265,14 @@ def _convert_detection(model, inputs, dtype, use_graph, kwargs):
     return converted
 
 
-def fused_result(model):
+def fused_result(model, zero_copy=False):
+    """Result of the last replay.  The logits row is returned as a FRESH tensor (the reference's deploy form
+    returns fresh tensors; a view of the arena would be overwritten by the next forward).  `zero_copy=True`
+    (what `model._pv_result()` hands out) is the explicit opt-in for the arena view, valid until the next forward."""
     s, out = model._pv_session, model._pv_output
     if out.T == out.H == out.W == 1 and out.f32:
-        return s.view_rows(out)[:, 0, :]
+        v = s.view_rows(out)[:, 0, :]
+        return v if zero_copy else v.clone()
     return s.view(out)
 
 
@@ -306,7 +323,7 @@ def _try_fuse_mvit(model, sess, dtype, input_tensor):
         if not s.matches(x, first_in):
             s.ingest(x, first_in)
         s.launch(use_graph=self._pv_use_graph)
-        return s.view_rows(out)[:, 0, :]
+        return s.view_rows(out)[:, 0, :].clone()   # fresh tensor; `_pv_result()` is the zero-copy view
 
     model.forward = types.MethodType(fused_forward, model)
     model.__dict__["_pv_inputs"] = first_in

@@ -238,17 +238,19 @@ class Session:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def launch(self, first=0, last=None, use_graph=False):
-        """Replay ops [first, last) on the current torch stream."""
+        """Replay ops [first, last) on the session device's current torch stream (the session stays pinned to
+        the device it was finalized on, whatever device is current in the caller)."""
         lib = L.lib()
         n = len(self.ops)
         last = n if last is None else last
-        if use_graph and first == 0 and last == n:
-            if not self._graph_ready:
-                L.check(lib.pv_plan_graph_build(self.plan, self._stream()), "graph build")
-                self._graph_ready = True
-            L.check(lib.pv_plan_graph_launch(self.plan, self._stream()), "graph launch")
-        else:
-            L.check(lib.pv_plan_launch_range(self.plan, first, last, self._stream()), "plan launch")
+        with torch.cuda.device(self.device):
+            if use_graph and first == 0 and last == n:
+                if not self._graph_ready:
+                    L.check(lib.pv_plan_graph_build(self.plan, self._stream()), "graph build")
+                    self._graph_ready = True
+                L.check(lib.pv_plan_graph_launch(self.plan, self._stream()), "graph launch")
+            else:
+                L.check(lib.pv_plan_launch_range(self.plan, first, last, self._stream()), "plan launch")
 
     def profile(self, iters=5):
         """Per-op device milliseconds measured with HIP events on the launch stream."""
@@ -311,7 +313,8 @@ class Session:
         if ch_scale is not None:
             d.ch_scale = ch_scale.data_ptr()
             d.ch_shift = ch_shift.data_ptr() if ch_shift is not None else None
-        L.check(lib.pv_ingest_ncdhw(C.byref(d), self._stream()), "ingest")
+        with torch.cuda.device(self.device):
+            L.check(lib.pv_ingest_ncdhw(C.byref(d), self._stream()), "ingest")
 
     def alloc_boxes(self, count):
         """Persistent [count, 5] fp32 buffer for the box list of a detection head.  It lives beside the

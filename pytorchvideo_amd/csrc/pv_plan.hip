@@ -157,29 +157,56 @@ extern "C" int pv_plan_graph_launch(pv_plan* p, pv_stream_t stream) {
   return PV_OK;
 }
 
+// Per-op device time.  Every op is timed IN SITU (the ops before it have just run, so its operands sit in the
+// caches exactly as in a replay) between two events of its own, and the host is kept out of the measurement:
+// each measured pass is queued behind one un-instrumented replay of the whole plan, so the device still has
+// milliseconds of queued work when the host records the events (an event per op, as a first version did, makes
+// the "kernel time" of a 20 us kernel the host's launch + record time on a slow host).  One pass instruments
+// every kStride-th op; the minimum over `iters` passes is reported, minus the null interval of an event pair
+// with nothing between (the marker packets' own cost), clamped at 0.
 extern "C" int pv_plan_profile(pv_plan* p, pv_stream_t stream, int iters, float* ms_per_op) {
   if (!p || !ms_per_op || iters <= 0) return PV_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int n = (int)p->ops.size();
-  std::vector<hipEvent_t> ev(n + 1);
-  for (auto& e : ev) PV_HIP_CHECK(hipEventCreate(&e));
-  for (int i = 0; i < n; ++i) ms_per_op[i] = 0.f;
+  constexpr int kStride = 8;
+  const int slots = (n + kStride - 1) / kStride + 1;   // +1: the null pair
+  std::vector<hipEvent_t> e0(slots), e1(slots);
+  for (auto& e : e0) PV_HIP_CHECK(hipEventCreate(&e));
+  for (auto& e : e1) PV_HIP_CHECK(hipEventCreate(&e));
+  for (int i = 0; i < n; ++i) ms_per_op[i] = 1e30f;
+  float null_ms = 1e30f;
   int rc = PV_OK;
   for (int it = 0; it < iters && rc == PV_OK; ++it) {
-    PV_HIP_CHECK(hipEventRecord(ev[0], s));
-    for (int i = 0; i < n; ++i) {
-      rc = run_op(p->ops[i], stream);
+    for (int phase = 0; phase < kStride && phase < n && rc == PV_OK; ++phase) {
+      rc = pv_plan_launch(p, stream);                  // queue filler: the host runs ahead of the device
       if (rc != PV_OK) break;
-      PV_HIP_CHECK(hipEventRecord(ev[i + 1], s));
-    }
-    if (rc != PV_OK) break;
-    PV_HIP_CHECK(hipStreamSynchronize(s));
-    for (int i = 0; i < n; ++i) {
+      int slot = 0;
+      for (int i = 0; i < n; ++i) {
+        const bool timed = (i % kStride) == phase;
+        if (timed) PV_HIP_CHECK(hipEventRecord(e0[slot], s));
+        rc = run_op(p->ops[i], stream);
+        if (rc != PV_OK) break;
+        if (timed) PV_HIP_CHECK(hipEventRecord(e1[slot++], s));
+      }
+      if (rc != PV_OK) break;
+      PV_HIP_CHECK(hipEventRecord(e0[slot], s));       // null pair
+      PV_HIP_CHECK(hipEventRecord(e1[slot], s));
+      PV_HIP_CHECK(hipStreamSynchronize(s));
       float ms = 0.f;
-      PV_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-      ms_per_op[i] += ms / iters;
+      PV_HIP_CHECK(hipEventElapsedTime(&ms, e0[slot], e1[slot]));
+      if (ms < null_ms) null_ms = ms;
+      slot = 0;
+      for (int i = phase; i < n; i += kStride, ++slot) {
+        PV_HIP_CHECK(hipEventElapsedTime(&ms, e0[slot], e1[slot]));
+        if (ms < ms_per_op[i]) ms_per_op[i] = ms;
+      }
     }
   }
-  for (auto& e : ev) (void)hipEventDestroy(e);
+  for (auto& e : e0) (void)hipEventDestroy(e);
+  for (auto& e : e1) (void)hipEventDestroy(e);
+  if (rc == PV_OK) {
+    if (null_ms > 1e29f) null_ms = 0.f;
+    for (int i = 0; i < n; ++i) ms_per_op[i] = ms_per_op[i] > null_ms ? ms_per_op[i] - null_ms : 0.f;
+  }
   return rc;
 }

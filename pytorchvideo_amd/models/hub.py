@@ -29,11 +29,18 @@ r2plus1d_r50_config = dict(model_depth=50, dropout_rate=0.5)  # hub/r2plus1d.py
 # mirrored in pytorchvideo_amd/layers/attention.py).  There is no network here: `checkpoint` is a local
 # file (torch.save format) or the already loaded dict.  The MI355X deploy form reads its weights from the
 # module tree at convert time, so a loaded checkpoint needs nothing else.
-def load_checkpoint(model, checkpoint, strict=True):
-    """Load a model-zoo style checkpoint into a host-mirror (or reference) model; returns the model."""
+def load_checkpoint(model, checkpoint, strict=True, trusted=False):
+    """Load a model-zoo style checkpoint into a host-mirror (or reference) model; returns the model.
+    Files are read with the tensors-only unpickler (the zoo files are plain tensor dicts); `trusted=True`
+    allows full unpickling for a file that carries other Python objects and comes from a source you trust."""
     import torch
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
-        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+        try:
+            checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=True)
+        except Exception:
+            if not trusted:
+                raise
+            checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
     state = checkpoint["model_state"] if isinstance(checkpoint, dict) and "model_state" in checkpoint else checkpoint
     model.load_state_dict(state, strict=strict)     # RuntimeError on missing / unexpected keys, like the reference
     return model

@@ -1,0 +1,37 @@
+"""bench.py's own launcher path without a GPU: `python bench.py --gpus N` with no torchrun environment must
+become N ranks (the driver's documented invocation), bind one rank per LOCAL_RANK, and report n_gpus = N.
+`--dry-host` runs the original-form model on the host over gloo -- a launcher check, not a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-host", "--steps", "2", "--warmup", "1"] + extra,
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_spawns_that_many_ranks():
+    line = _run(["--gpus", "2"])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2 * line["config"]["per_gpu_batch"]
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+
+
+def test_single_process_default():
+    line = _run([])
+    assert line["n_gpus"] == 1
+
+
+def test_inside_a_torchrun_environment_the_world_size_wins():
+    # the driver's N>1 invocation passes --gpus N AND sets WORLD_SIZE: no second spawn
+    line = _run(["--gpus", "1"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert line["n_gpus"] == 1

@@ -71,6 +71,28 @@ def test_attention_matches_reference(dtype, B, heads, hd, Nq, Nk, res):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,heads,Nq,Nk", [
+    (1, 1, 50177, 785),     # MViT-B 32x3 block 0 (hub/vision_transformers.py:31-39): 16*56*56+1 queries x 16*7*7+1 keys
+    (2, 2, 12545, 3137),    # block 1: 16*28*28+1 queries x 16*14*14+1 keys
+    (1, 4, 3137, 3137),     # block 3
+    (1, 8, 785, 3137),      # block 14
+])
+def test_attention_at_the_mvit_b_32x3_geometries(dtype, B, heads, Nq, Nk):
+    """The (Nq, Nk, heads) of MViT-B 32x3 at 224^2, head_dim 96, reference in chunks of queries."""
+    hd = 96
+    Cw = heads * hd
+    q, k, v = _rand((B, Nq, Cw), 31, dtype), _rand((B, Nk, Cw), 32, dtype), _rand((B, Nk, Cw), 33, dtype)
+    scale = hd ** -0.5
+    got = _run_attention(q, k, v, heads, scale, False)
+    worst, amax = 0.0, 0.0
+    for lo in range(0, Nq, 4096):
+        want = _attention_ref(q[:, lo:lo + 4096], k, v, heads, scale, False)
+        worst = max(worst, (got[:, lo:lo + 4096].float() - want).abs().max().item())
+        amax = max(amax, want.abs().max().item())
+    assert worst / amax <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention_on_channel_slices_of_a_fused_qkv_buffer(dtype):
     B, heads, hd, N = 2, 2, 96, 300
     Cw = heads * hd

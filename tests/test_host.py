@@ -206,3 +206,23 @@ def test_an_op_that_touches_a_released_buffer_is_rejected_at_emission():
         sess.add_op(L.OP_ADD_ACT, f, label="stale")
     f2 = dict(f, a=b.channel_slice(8, 8).ptr)       # a channel slice of a live buffer is fine
     sess.add_op(L.OP_ADD_ACT, f2, label="slice")
+
+
+def test_slowfast_with_a_declined_head_converts_block_by_block():
+    """A multi-pathway model with one block the transmuter declines (unknown head activation) is converted block by
+    block: the size hook has to record the LIST input of MultiPathWayWithFuse / PoolConcatPathway (the reference's
+    hook records tensors only, model_conversion.py:26-28) and the batch is patched per pathway."""
+    from pytorchvideo_amd.accelerator.mi355x import conversion as CV
+    from pytorchvideo_amd.accelerator.mi355x.blocks import Mi355xMultiPathBlock
+    from pytorchvideo_amd.models import create_slowfast
+    m = create_slowfast(model_depth=18, model_num_class=7, head_pool_kernel_sizes=((2, 2, 2), (8, 2, 2)),
+                        head_activation=nn.Tanh).eval()
+    transmute_model(m, "mi355x")
+    assert isinstance(m.blocks[0], Mi355xMultiPathBlock) and not isinstance(m.blocks[-1], Mi355xBlock)   # head declined
+    x = [torch.randn(3, 3, 2, 64, 64), torch.randn(3, 3, 8, 64, 64)]
+    lut = CV._record_input_sizes(m, CV._one_clip(x))
+    assert lut[".blocks.0"] == [(1, 3, 2, 64, 64), (1, 3, 8, 64, 64)]
+    sess = Session(dtype=torch.bfloat16)
+    CV._convert_children(m, lut, 3, "", sess, torch.bfloat16, {})
+    assert all(b.convert_flag for b in m.blocks[:-1])
+    assert [r.B for r in m.blocks[0]._in_ref] == [3, 3] and len(sess.ops) > 30
