@@ -122,3 +122,29 @@ def quantize_like_kernels(sd, x=None):
             dense = False  # SE FCs / positional tables stay fp32
         out[k] = v.bfloat16().float() if dense else v
     return (out, x.bfloat16().float()) if x is not None else out
+
+
+@torch.no_grad()
+def calibrated_fill(model, calib_input, seed=0):
+    """reference_style_fill, then the running statistics of every BatchNorm are set to the ACTUAL batch
+    statistics of its input on `calib_input` -- what training leaves in a checkpoint (running_mean /
+    running_var track the data, torch BatchNorm with momentum=None = cumulative average, one batch).
+    With `rand_init_bn`'s arbitrary running statistics a deep stack is not normalised at all: X3D-L
+    (55 blocks) grows its logits to ~1e9 and amplifies a 2^-9 perturbation of the weights to 27 % of the
+    output (measured, tools/parity_full.py) -- a property of that random instance, not of the arithmetic
+    under test.  Calibrated statistics give the activation scales a trained network has (unit variance
+    after every BatchNorm, residual stream growing like sqrt(depth))."""
+    import torch.nn as nn
+    reference_style_fill(model, seed)
+    bns = [m for m in model.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+    saved = [m.momentum for m in bns]
+    model.eval()
+    for m in bns:
+        m.reset_running_stats()
+        m.momentum = None
+        m.train()
+    model(list(calib_input) if isinstance(calib_input, (list, tuple)) else calib_input)
+    for m, mom in zip(bns, saved):
+        m.momentum = mom
+    model.eval()
+    return model

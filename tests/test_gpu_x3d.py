@@ -117,6 +117,11 @@ def test_x3d_variants_match_the_host_mirror(cfg, shape, dtype, tol):
     """Factory sweep (reference tests sweep create_x3d the same way, tests/test_models_x3d.py:20-95): the
     deploy form against the original-form forward of the same module tree (itself pinned to the reference
     by test_oracle_golden.py), evaluated on the kernels' quantisation of weights and input."""
+    if dtype == torch.bfloat16 and cfg.get("depth_factor", 2.2) > 2.2:
+        # the bf16 check of the 55-block depth is tests/test_gpu_full_geometry.py::test_full_geometry_parity[x3d_l]
+        # (X3D-L at 16x224^2, 1e-2, no allowance): at this toy geometry res5 is 4x2x2 voxels per clip and the
+        # head averages over 16 values, so per-element bf16 storage noise is not averaged at all
+        pytest.skip("bf16 at X3D-L depth is checked at the full geometry")
     from pytorchvideo_amd.models import create_x3d
     torch.manual_seed(0)
     m = create_x3d(**cfg)
@@ -134,8 +139,4 @@ def test_x3d_variants_match_the_host_mirror(cfg, shape, dtype, tol):
     dm = _deploy(m, x, dtype)
     got = dm(x.cuda().to(dtype))
     assert got.shape == want.shape
-    # bf16 activation storage adds ~2^-9 of rounding noise per layer, a random walk over depth: the 26-block
-    # nets sit at 3-5e-3, the 55-block X3D-L depth (with these deliberately un-normalised random BN statistics,
-    # logits ~1e4) at ~3e-2; fp32 storage of the same plan is exact to 1e-3, so this is storage noise, not a kernel error
-    deep_bf16 = dtype == torch.bfloat16 and cfg.get("depth_factor", 2.2) > 2.2
-    assert _rel(got, want) <= (4e-2 if deep_bf16 else tol)
+    assert _rel(got, want) <= tol
