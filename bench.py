@@ -33,13 +33,13 @@ MFMA_PEAK_TFS = 2500.0    # dense bf16
 
 # algorithmic FLOPs / bytes per clip (probe of the reference op graph)
 WORKLOADS = {
-    "x3d_m": dict(batch=32, gflop=9.465, mb=365.0, bound="hbm",
+    "x3d_m": dict(batch=32, gflop=9.465, mb=365.0, bound="hbm", streams=2,
                   desc="create_x3d(input_clip_length=16,input_crop_size=224) [B,3,16,224,224]"),
-    "x3d_l": dict(batch=32, gflop=18.325, mb=604.0, bound="hbm",
+    "x3d_l": dict(batch=32, gflop=18.325, mb=604.0, bound="hbm", streams=2,
                   desc="create_x3d(16,224,depth_factor=5.0) [B,3,16,224,224]"),
     "slowfast_r50": dict(batch=16, gflop=131.42, mb=740.0, bound="mfma",
                          desc="create_slowfast(model_depth=50) slow [B,3,8,256,256] + fast [B,3,32,256,256]"),
-    "mvit_b_32x3": dict(batch=8, gflop=339.92, mb=1465.0, bound="mfma",
+    "mvit_b_32x3": dict(batch=8, gflop=339.92, mb=1465.0, bound="mfma", streams=2,
                         desc="create_multiscale_vision_transformers(**mvit_video_base_32x3_config) [B,3,32,224,224]"),
     # launcher check only (tests/test_bench_launcher.py): tiny clip, original-form model on the host, gloo
     "x3d_xs_dry": dict(batch=2, gflop=1.211, mb=0.0, bound="hbm",
@@ -90,7 +90,7 @@ def synth_input(shape, batch, seed):
     return torch.randn((batch,) + tuple(shape), generator=g)
 
 
-def build_model(name, batch, device, dtype):
+def build_model(name, batch, device, dtype, streams=1):
     import torch
     from pytorchvideo_amd.accelerator import convert_to_deployable_form, transmute_model
     from pytorchvideo_amd.utils import randomize_norm_stats
@@ -101,7 +101,7 @@ def build_model(name, batch, device, dtype):
     x = synth_input(shape, batch, 1234 + int(os.environ.get("RANK", "0")))
     x = [t.to(dtype).to(device) for t in x] if isinstance(x, list) else x.to(dtype).to(device)
     transmute_model(model, "mi355x")
-    deployed = convert_to_deployable_form(model, x, dtype=dtype)
+    deployed = convert_to_deployable_form(model, x, dtype=dtype, streams=streams)
     return deployed, x
 
 
@@ -163,6 +163,23 @@ def self_spawn(args):
     return subprocess.call(cmd, env=env)
 
 
+def roofline_session(model, name, batch, device, args):
+    """The plan whose kernels the `roofline` object describes: the full per-GPU batch as ONE plan, every kernel
+    alone on the chip (what `rocprofv3 --kernel-trace -- python bench.py --streams 1` sees).  With streams > 1 the
+    timed steps overlap kernels of different sub-batches, where a per-kernel duration is not defined; the
+    per-kernel evidence is therefore taken from the single-plan form of the same batch."""
+    if not hasattr(model, "parts"):
+        return model._pv_session
+    import torch
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    single, x = build_model(name, batch, device, dtype, streams=1)
+    for _ in range(2):
+        single(list(x) if isinstance(x, list) else x)
+    torch.cuda.synchronize()
+    roofline_session.keep = (single, x)      # alive while its session is profiled
+    return single._pv_session
+
+
 def roofline_of(sess, workload, clips_s_per_gpu, ms_per_step):
     """Per-kernel device time measured live (pv_plan_profile: in-situ HIP events on the launch stream, host
     kept out of the measurement), folded per op family; the dominant family's algorithmic rate against its
@@ -202,7 +219,8 @@ def roofline_of(sess, workload, clips_s_per_gpu, ms_per_step):
         "alg_bytes_per_launch": int(dom[2] / max(dom[0], 1)), "avg_launch_ms": round(dom[1] / max(dom[0], 1), 5),
         "kernel_ms_per_step": round(dom[1], 4), "all_kernels_ms_per_step": round(total_kernel_ms, 4),
         "launches_total": len(prof),
-        "timing": "pv_plan_profile: each op timed in situ between its own HIP event pair behind a queued replay, "
+        "timing": "pv_plan_profile on the single-plan form of the per-GPU batch (every kernel alone on the chip, = "
+                  "bench.py --streams 1): each op timed in situ between its own HIP event pair behind a queued replay, "
                   "min of 3, null event interval subtracted",
         "model_hbm_frac": round(clips_s_per_gpu * wl["mb"] * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
         "model_mfma_frac": round(clips_s_per_gpu * wl["gflop"] * 1e9 / (MFMA_PEAK_TFS * 1e12), 4),
@@ -243,9 +261,11 @@ def run_workload(name, args, world, rank, device, steps, warmup, sustained_s=0.0
     wl = WORKLOADS[name]
     batch = args.batch or wl["batch"]
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model, x = build_model(name, batch, device, dtype)
+    streams = args.streams if args.streams > 0 else wl.get("streams", 1)
+    model, x = build_model(name, batch, device, dtype, streams=streams)
     if args.no_graph:
-        model.__dict__["_pv_use_graph"] = False
+        for part in getattr(model, "parts", [model]):
+            part.__dict__["_pv_use_graph"] = False
 
     def step():
         return gather_logits(model(list(x) if isinstance(x, list) else x), global_batch=batch * world)
@@ -256,7 +276,8 @@ def run_workload(name, args, world, rank, device, steps, warmup, sustained_s=0.0
     assert out.shape == (batch * world, 400) and torch.isfinite(out).all()
     pct = lambda q: round(step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))], 4)
     res = {"value": round(batch * world * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 4),
-           "step_ms": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9)}, "steps": steps, "per_gpu_batch": batch}
+           "step_ms": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9)}, "steps": steps, "per_gpu_batch": batch,
+           "streams": len(getattr(model, "parts", [0]))}
     if sustained_s > 0:   # a run long enough for clocks / power to settle: same step, >= sustained_s seconds
         n = max(steps, int(sustained_s / max(elapsed / steps, 1e-6)) + 1)
         e2, _, _ = timed_steps(step, n, world, device)
@@ -358,6 +379,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="sub-batches replayed concurrently on their own HIP streams (0: the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the MViT-B 32x3 leg of the N=1 line")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained run")
@@ -387,19 +410,22 @@ def main():
     res, model, x, step = run_workload(args.workload, args, world, rank, device, args.steps, args.warmup,
                                        sustained_s=0.0 if args.no_sustained else 2.0)
     batch = res["per_gpu_batch"]
-    pcie = pcie_leg(model, x, step, batch, args.steps, device) if args.with_h2d else None
-    roof, prof, agg = roofline_of(model._pv_session, args.workload, res["value"] / world, res["ms_per_step"])
+    pcie = pcie_leg(model, x, step, batch, args.steps, device) if (args.with_h2d and not hasattr(model, "parts")) else None
+    roof, prof, agg = roofline_of(roofline_session(model, args.workload, batch, device, args), args.workload,
+                                  res["value"] / world, res["ms_per_step"])
 
     secondary = None
     if world == 1 and not args.no_secondary and args.workload == "x3d_m" and not args.batch:
         del model, x, step
         torch.cuda.empty_cache()
         r2, m2, x2, _ = run_workload("mvit_b_32x3", args, 1, 0, device, max(10, args.steps // 2), 3, sustained_s=0.0)
-        roof2, _, _ = roofline_of(m2._pv_session, "mvit_b_32x3", r2["value"], r2["ms_per_step"])
+        roof2, _, _ = roofline_of(roofline_session(m2, "mvit_b_32x3", r2["per_gpu_batch"], device, args), "mvit_b_32x3",
+                                  r2["value"], r2["ms_per_step"])
         secondary = {"mvit_b_32x3": {"value": r2["value"], "unit": "clips/s", "ms_per_step": r2["ms_per_step"],
                                      "step_ms": r2["step_ms"], "steps": r2["steps"], "dtype": args.dtype,
                                      "config": {"workload": "mvit_b_32x3: " + WORKLOADS["mvit_b_32x3"]["desc"],
-                                                "per_gpu_batch": r2["per_gpu_batch"]}, "roofline": roof2}}
+                                                "per_gpu_batch": r2["per_gpu_batch"], "streams": r2["streams"]},
+                                     "roofline": roof2}}
         del m2, x2
 
     if rank == 0:
@@ -411,7 +437,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "per_gpu_batch": batch,
                        "global_batch": batch * world, "parallelism": "dp%d (batch-sharded, logits all_gather)" % world,
-                       "weights": "random-init, randomised BN stats", "hip_graph": not args.no_graph},
+                       "weights": "random-init, randomised BN stats", "hip_graph": not args.no_graph,
+                       "streams": res["streams"]},
             "roofline": roof,
         }
         if "sustained" in res:

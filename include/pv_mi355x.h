@@ -384,6 +384,10 @@ int pv_plan_launch(pv_plan* p, pv_stream_t stream);                 /* eager rep
 int pv_plan_launch_range(pv_plan* p, int first, int last, pv_stream_t stream);
 int pv_plan_graph_build(pv_plan* p, pv_stream_t stream);           /* capture+instantiate */
 int pv_plan_graph_launch(pv_plan* p, pv_stream_t stream);
+/* `n` independent plans (sub-batches of one forward: pytorchvideo_amd.accelerator.mi355x.conversion.SplitBatchDeployed)
+ * captured as `n` PARALLEL branches of ONE graph, owned by plans[0] and replayed with pv_plan_graph_launch(plans[0]):
+ * the runtime runs the branches side by side, so the tail of one sub-batch's kernel overlaps the other's work */
+int pv_plan_graph_build_joint(pv_plan* const* plans, int n, pv_stream_t stream);
 /* per-op device time in ms: every op timed in situ between its own pair of HIP events on `stream`, behind a
  * queued un-instrumented replay (the host never paces the measurement); minimum over `iters` passes, minus the
  * null interval of an empty event pair */

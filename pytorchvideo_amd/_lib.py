@@ -131,10 +131,11 @@ _SYMBOLS = [
     ("pv_plan_launch_range", C.c_int, [_p, C.c_int, C.c_int, _p]),
     ("pv_plan_graph_build", C.c_int, [_p, _p]),
     ("pv_plan_graph_launch", C.c_int, [_p, _p]),
+    ("pv_plan_graph_build_joint", C.c_int, [C.POINTER(_p), C.c_int, _p]),
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lib = None
 

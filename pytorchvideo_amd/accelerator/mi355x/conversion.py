@@ -85,11 +85,96 @@ def _convert_children(module, lut, batch, name, sess, dtype, kwargs):
         _convert_children(child, lut, batch, f"{name}.{child_name}", sess, dtype, kwargs)
 
 
+class SplitBatchDeployed(nn.Module):
+    """`streams` > 1: the batch runs as `streams` independent sub-batches, each through its own deploy form
+    (own arena, own hipGraph) on its own HIP stream.  Clips do not interact in an eval forward, so the result is
+    the one-plan result row for row; what changes is the schedule: kernels of different sub-batches overlap, so
+    the tail of one launch (its last, partial round of workgroups) and the ~2-4 us gap before its successor are
+    filled with the other sub-batch's work.  Measured (tools/gpu_stream_sweep.sh, same box, 1 -> 2 sub-batches):
+    X3D-M b=32 +10 %, X3D-L b=32 +10 %, MViT-B b=8 +7 %, SlowFast-R50 b=16 -2 % (its kernels already fill the
+    chip); 3 and 4 sub-batches give nothing more.  By default the sub-plans are captured as parallel branches of
+    ONE hipGraph (pv_plan_graph_build_joint): a forward is the ingests, one graph launch and one concatenation."""
+
+    def __init__(self, parts, splits, device, joint=True):
+        super().__init__()
+        self.parts = nn.ModuleList(parts)
+        self._splits = splits
+        # the last sub-batch runs on the caller's stream: k sub-batches occupy k hardware queues, not k + 1
+        # (ROCm maps streams onto 4 hardware queues by default; a fifth stream shares one and serialises)
+        self._streams = [torch.cuda.Stream(device=device) for _ in parts[:-1]]
+        self._device = device
+        self.__dict__["_pv_session"] = parts[0]._pv_session      # per-op profiling: the first sub-plan
+        self.__dict__["_pv_sessions"] = [p._pv_session for p in parts]
+        # one graph with the sub-plans as parallel branches (one launch per forward) when every part is a
+        # whole-model plan with a known input buffer; else one graph per part on its own stream
+        self._joint = joint and all(getattr(p, "_pv_inputs", None) is not None and hasattr(p, "_pv_result")
+                                    and getattr(p, "_pv_use_graph", False) for p in parts)
+        self._joint_ready = False
+
+    def _forward_joint(self, x, multi):
+        import ctypes as C
+        lib = L.lib()
+        lo = 0
+        for part, b in zip(self.parts, self._splits):
+            xc = [t[lo:lo + b] for t in x] if multi else x[lo:lo + b]
+            lo += b
+            if not multi and xc.dim() == 4:
+                xc = xc.unsqueeze(2)                    # image model: a clip of one frame
+            _ingest_inputs(part._pv_session, xc, part._pv_inputs, multi)
+        s0 = self.parts[0]._pv_session
+        with torch.cuda.device(self._device):
+            if not self._joint_ready:
+                arr = (C.c_void_p * len(self.parts))(*[p._pv_session.plan for p in self.parts])
+                L.check(lib.pv_plan_graph_build_joint(arr, len(self.parts), s0._stream()), "joint graph build")
+                self._joint_ready = True
+            L.check(lib.pv_plan_graph_launch(s0.plan, s0._stream()), "graph launch")
+        return torch.cat([p._pv_result() for p in self.parts], dim=0)     # cat copies: a fresh tensor
+
+    def forward(self, x):
+        multi = isinstance(x, (list, tuple))
+        n = (x[0] if multi else x).shape[0]
+        if n != sum(self._splits):
+            raise L.PvError("deploy form was converted for a batch of %d, got %d" % (sum(self._splits), n))
+        if self._joint:
+            return self._forward_joint(x, multi)
+        cs = torch.cuda.current_stream(self._device)
+        outs, lo = [], 0
+        for i, (part, b) in enumerate(zip(self.parts, self._splits)):
+            xc = [t[lo:lo + b] for t in x] if multi else x[lo:lo + b]
+            lo += b
+            if i < len(self._streams):
+                st = self._streams[i]
+                st.wait_stream(cs)                 # the caller's input is ready
+                with torch.cuda.stream(st):
+                    o = part(xc)
+                o.record_stream(cs)
+            else:
+                o = part(xc)
+            outs.append(o)
+        for st in self._streams:
+            cs.wait_stream(st)
+        return torch.cat(outs, dim=0)
+
+
 def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quantize: bool = False,
-                               native_conv3d_op_qnnpack: bool = False, dtype=None, use_graph: bool = True):
+                               native_conv3d_op_qnnpack: bool = False, dtype=None, use_graph: bool = True,
+                               streams: int = 1):
     """Return a deploy-form copy of a transmuted `model`, specialised to `input_tensor`'s
     shape.  `dtype` (torch.bfloat16 | torch.float32) selects the kernels' storage type and
-    defaults to the input tensor's dtype (fp32 input -> fp32 kernels)."""
+    defaults to the input tensor's dtype (fp32 input -> fp32 kernels).  `streams` > 1: see SplitBatchDeployed."""
+    if streams > 1 and type(model).__name__ != "DetectionBBoxNetwork":
+        n = _batch_of(input_tensor)
+        k = min(int(streams), n)
+        splits = [n // k + (1 if i < n % k else 0) for i in range(k)]
+        parts, lo = [], 0
+        for b in splits:
+            xc = [t[lo:lo + b] for t in input_tensor] if isinstance(input_tensor, (list, tuple)) else input_tensor[lo:lo + b]
+            lo += b
+            parts.append(convert_to_deployable_form(model, xc, convert_for_quantize, native_conv3d_op_qnnpack,
+                                                    dtype=dtype, use_graph=use_graph))
+        import os
+        return SplitBatchDeployed(parts, splits, parts[0]._pv_session.device,
+                                  joint=os.environ.get("PV_SPLIT_JOINT", "1") != "0")
     if type(model).__name__ == "DetectionBBoxNetwork":
         return _convert_detection(model, input_tensor, dtype, use_graph,
                                   dict(convert_for_quantize=convert_for_quantize,

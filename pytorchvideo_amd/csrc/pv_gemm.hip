@@ -58,7 +58,7 @@ struct GemmGeom {   // per-thread staging geometry of one output tile
 // as long as the K loop itself.
 // VT = voxel tiles (32 rows) per wave: 2 -> 128 x 128 output tiles; 1 -> 64 x 128, for layers whose tile count
 // sits just above a multiple of the resident workgroups (the second, nearly empty round costs a full tile time).
-template <bool PW, int VT>
+template <bool PW, int VT, int ABL = 0>   // ABL: ablation builds for tools/bench_gemm.py (1 no loads, 2 no MFMA, 3 no epilogue)
 __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles,
                                                                 float inv_cin) {
   constexpr int BK = 64;
@@ -221,8 +221,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
         __builtin_amdgcn_s_waitcnt(vm(0));
       }
       __builtin_amdgcn_s_barrier();
+      if constexpr (ABL != 1) {
       if (ks + 1 < nk) stage((gs + 1) & 1, cur, ks + 1);
       else if (has_next) stage((gs + 1) & 1, nxt, 0);   // first step of the next tile: in flight during the epilogue
+      }
       const bf16_t* wb = smem + (gs & 1) * 2 * TILE_ELEMS;
       const bf16_t* xb = wb + TILE_ELEMS;
       // fragment reads are software-pipelined one 16-deep sub-step ahead of the MFMAs that use them
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
         for (int t = 0; t < VT; ++t)
           bfr[slot][t] = *reinterpret_cast<const bf16x8*>(xb + b_row[t] * BK + ((c ^ swz(b_row[t])) << 3));
       };
+      if constexpr (ABL == 2) continue;
       read_frags(0, 0);
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
@@ -256,6 +259,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
     // tile's first wait can then be a counted vmcnt that leaves them in flight.
     // every load of the epilogue (residual rows, scale / shift) is consumed before the first store is
     // issued -- a load consumed after a store would make the compiler drain the store queue
+    if constexpr (ABL == 3) {
+      float keep = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int v = 0; v < VT; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) keep += acc[a][v][r];
+      if (keep == 1.2345e-30f) static_cast<float*>(d.y)[0] = keep;   // keeps the accumulators live
+      first_wait_stores = false;
+      cur = nxt;
+      continue;
+    }
     long e_b[VT], e_sp[VT];
     bool e_ok[VT];
 #pragma unroll
@@ -410,6 +426,17 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return PV_ERR_UNSUPPORTED;   // 31-bit buffer offsets
   const float inv_cin = 1.0f / (float)d.cin;
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads);
+  static const int abl = getenv("PV_GEMM_ABL") ? atoi(getenv("PV_GEMM_ABL")) : 0;
+  if (abl && vt == 2) {
+    if (abl == 1) { if (pw) hipLaunchKernelGGL((gemm_glds_kernel<true, 2, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+                    else hipLaunchKernelGGL((gemm_glds_kernel<false, 2, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin); }
+    if (abl == 2) { if (pw) hipLaunchKernelGGL((gemm_glds_kernel<true, 2, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+                    else hipLaunchKernelGGL((gemm_glds_kernel<false, 2, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin); }
+    if (abl == 3) { if (pw) hipLaunchKernelGGL((gemm_glds_kernel<true, 2, 3>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+                    else hipLaunchKernelGGL((gemm_glds_kernel<false, 2, 3>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin); }
+    PV_LAUNCH_CHECK();
+    return PV_OK;
+  }
   if (vt == 1) {
     if (pw) hipLaunchKernelGGL((gemm_glds_kernel<true, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
     else hipLaunchKernelGGL((gemm_glds_kernel<false, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);

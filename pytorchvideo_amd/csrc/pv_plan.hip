@@ -9,7 +9,7 @@
 
 namespace {
 thread_local std::string g_last_error;
-constexpr int kAbiVersion = 14;
+constexpr int kAbiVersion = 15;
 }  // namespace
 
 int pv_set_hip_error(hipError_t e, const char* what) {
@@ -144,6 +144,52 @@ extern "C" int pv_plan_graph_build(pv_plan* p, pv_stream_t stream) {
   if (r != PV_OK) {
     if (g) (void)hipGraphDestroy(g);
     return r;
+  }
+  if (e != hipSuccess) return pv_set_hip_error(e, "hipStreamEndCapture");
+  p->graph = g;
+  PV_HIP_CHECK(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+  return PV_OK;
+}
+
+extern "C" int pv_plan_graph_build_joint(pv_plan* const* plans, int n, pv_stream_t stream) {
+  if (!plans || n <= 0 || n > 16) return PV_ERR_INVALID;
+  for (int i = 0; i < n; ++i)
+    if (!plans[i]) return PV_ERR_INVALID;
+  if (n == 1) return pv_plan_graph_build(plans[0], stream);
+  pv_plan* p = plans[0];
+  drop_graph(p);
+  (void)stream;
+  // fork / join by events inside the capture: branch i > 0 is recorded on its own stream behind a fork event of the
+  // origin stream, and the origin stream waits for every branch's last event before the capture ends
+  std::vector<hipStream_t> ss(n, nullptr);
+  std::vector<hipEvent_t> ev(n, nullptr);
+  auto cleanup = [&]() {
+    for (auto& s : ss) if (s) (void)hipStreamDestroy(s);
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+  };
+  for (int i = 0; i < n; ++i) {
+    hipError_t e = hipStreamCreateWithFlags(&ss[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    if (e != hipSuccess) { cleanup(); return pv_set_hip_error(e, "joint graph: stream / event"); }
+  }
+  hipError_t e = hipStreamBeginCapture(ss[0], hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) { cleanup(); return pv_set_hip_error(e, "hipStreamBeginCapture"); }
+  int r = PV_OK;
+  hipError_t he = hipEventRecord(ev[0], ss[0]);
+  for (int i = 1; i < n && he == hipSuccess; ++i) he = hipStreamWaitEvent(ss[i], ev[0], 0);
+  for (int i = n - 1; i >= 0 && he == hipSuccess && r == PV_OK; --i) {
+    r = pv_plan_launch(plans[i], ss[i]);
+    if (i > 0 && r == PV_OK) he = hipEventRecord(ev[i], ss[i]);
+  }
+  // join only after the origin stream's own branch is recorded (a wait placed earlier would order that branch
+  // behind the others)
+  for (int i = 1; i < n && he == hipSuccess && r == PV_OK; ++i) he = hipStreamWaitEvent(ss[0], ev[i], 0);
+  hipGraph_t g = nullptr;
+  e = hipStreamEndCapture(ss[0], &g);
+  cleanup();
+  if (r != PV_OK || he != hipSuccess) {
+    if (g) (void)hipGraphDestroy(g);
+    return r != PV_OK ? r : pv_set_hip_error(he, "joint graph: fork / join");
   }
   if (e != hipSuccess) return pv_set_hip_error(e, "hipStreamEndCapture");
   p->graph = g;

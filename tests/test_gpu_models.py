@@ -288,3 +288,34 @@ def test_resnet_family_variants_match_the_host_mirror(factory, cfg, shape, dtype
     got, want, dm = _mirror_case(getattr(M, factory), cfg, seeded_input(shape, 6), dtype)
     assert got.shape == want.shape and rel_err(got.float(), want) <= tol
     assert getattr(dm, "_pv_inputs", None) is not None     # nothing declined: one launch plan
+
+
+@pytest.mark.parametrize("family", ["x3d", "slowfast", "mvit"])
+def test_split_batch_streams_give_the_one_plan_result(family):
+    """convert_to_deployable_form(..., streams=k): k sub-batches on k HIP streams, each with its own plan; clips do
+    not interact in an eval forward, so the rows must be the one-plan rows (same kernels, same reduction order)."""
+    import pytorchvideo_amd.models as M
+    from pytorchvideo_amd.accelerator import convert_to_deployable_form, transmute_model
+    torch.manual_seed(0)
+    if family == "x3d":
+        m = M.create_x3d(input_clip_length=4, input_crop_size=96, model_num_class=11)
+        x = seeded_input((5, 3, 4, 96, 96), 3)
+    elif family == "slowfast":
+        m = M.create_slowfast(model_depth=18, model_num_class=9, head_pool_kernel_sizes=((2, 2, 2), (8, 2, 2)))
+        fast = seeded_input((4, 3, 8, 64, 64), 3)
+        x = [fast[:, :, torch.linspace(0, 7, 2).long()].clone(), fast]
+    else:
+        m = M.create_multiscale_vision_transformers(**_MV)
+        x = seeded_input((4, 3, _MV["temporal_size"], 64, 64), 3)
+    deterministic_fill(m, 4).eval()
+    transmute_model(m, "mi355x")
+    xd = [t.cuda().bfloat16() for t in x] if isinstance(x, list) else x.cuda().bfloat16()
+    one = convert_to_deployable_form(m, xd, dtype=torch.bfloat16)
+    want = one(list(xd) if isinstance(xd, list) else xd).clone()
+    for k in (2, 3):
+        dm = convert_to_deployable_form(m, xd, dtype=torch.bfloat16, streams=k)
+        assert len(dm.parts) == k
+        got = dm(list(xd) if isinstance(xd, list) else xd)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape and torch.equal(got, want)
+        assert torch.equal(dm(list(xd) if isinstance(xd, list) else xd), want)     # replays are idempotent
