@@ -132,6 +132,29 @@ int pv_conv3d_dwt_supported(const pv_conv3d_desc* d);
 /* 1 if this geometry (pointers are ignored; x2_cin > 0) can run with the second K operand, else 0 */
 int pv_conv3d_x2_supported(const pv_conv3d_desc* d);
 
+/* ---- SlowFast lateral connection (fast -> slow fusion) -----------------------------------
+ * Replaces FuseFastToSlow.forward (models/slowfast.py:720-729) as built by
+ * FastToSlowFusionBuilder.create_module (models/slowfast.py:661-694), called from
+ * MultiPathWayWithFuse.forward (models/net.py:107-122):
+ *   fuse = act(BatchNorm3d(Conv3d(cin -> cout, kernel (kt,1,1), stride (st,1,1), padding (pt,0,0), bias=False)(x_fast)))
+ *   x_slow_fuse = torch.cat([x_slow, fuse], dim=1)
+ * x is the fast pathway (B, Ti, H, W, cin) channels-last; y points at channel C_slow of the slow pathway's
+ * (wider) buffer -- voxel stride ldy = that buffer's row width -- so the concatenation is the store itself.
+ * Weights packed [cout][kt][cin] (cin padded to 8) in `dtype`; scale / shift = the folded BatchNorm.
+ * bf16: the dedicated streaming kernel (csrc/pv_lateral.hip); fp32 parity mode: the same arithmetic through
+ * pv_conv3d's (kt,1,1) path. */
+typedef struct pv_lateral_desc {
+  const void* x; const void* w; void* y;
+  const float* scale; const float* shift;   /* [cout] or NULL */
+  int64_t x_bs, y_bs;                       /* batch strides, elements */
+  int32_t ldx, ldy;                         /* voxel strides, elements */
+  int32_t B, Ti, H, W, cin;                 /* cin: channels read per fast voxel (multiple of 8) */
+  int32_t To, cout;                         /* slow frames, true output channels */
+  int32_t kt, st, pt;                       /* temporal kernel / stride (alpha) / padding */
+  int32_t act, dtype;
+} pv_lateral_desc;
+int pv_lateral_fuse(const pv_lateral_desc* d, pv_stream_t stream);
+
 /* ---- depthwise convolution ---------------------------------------------------------
  * Replaces nn.Conv3d(groups=C) [+ BatchNorm3d eval][+ activation]:
  *   models/x3d.py:66-88 (stem 5x1x1), models/x3d.py:180-189 (3x3x3), models/csn.py:169,
@@ -373,7 +396,7 @@ enum pv_op_kind {
   PV_OP_CONV3D = 1, PV_OP_DWCONV3D = 2, PV_OP_SE_GATE = 3, PV_OP_POOL3D = 4,
   PV_OP_LAYERNORM = 5, PV_OP_SOFTMAX_ROWS = 6, PV_OP_MEAN_ROWS = 7, PV_OP_POSENC = 8,
   PV_OP_ATTENTION = 9, PV_OP_ADD_ACT = 10, PV_OP_INGEST = 11, PV_OP_EGRESS = 12, PV_OP_TOKEN_POOL = 13,
-  PV_OP_ROI_ALIGN = 14
+  PV_OP_ROI_ALIGN = 14, PV_OP_LATERAL = 15
 };
 typedef struct pv_plan pv_plan;
 pv_plan* pv_plan_create(void);

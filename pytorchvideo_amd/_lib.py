@@ -16,7 +16,7 @@ PV_F32, PV_BF16, PV_U8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 POOL_MAX, POOL_AVG = 0, 1
 (OP_CONV3D, OP_DWCONV3D, OP_SE_GATE, OP_POOL3D, OP_LAYERNORM, OP_SOFTMAX_ROWS, OP_MEAN_ROWS,
- OP_POSENC, OP_ATTENTION, OP_ADD_ACT, OP_INGEST, OP_EGRESS, OP_TOKEN_POOL, OP_ROI_ALIGN) = range(1, 15)
+ OP_POSENC, OP_ATTENTION, OP_ADD_ACT, OP_INGEST, OP_EGRESS, OP_TOKEN_POOL, OP_ROI_ALIGN, OP_LATERAL) = range(1, 16)
 
 _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -44,6 +44,10 @@ DwConv3dDesc = _struct("DwConv3dDesc", [
     + _ints("ldx", "ldy", "B", "Ti", "Hi", "Wi", "C", "To", "Ho", "Wo",
             "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "w_mod", "act", "dtype", "n_prefix")
     + [("pw_w", _p), ("pw_scale", _p), ("pw_shift", _p)] + _ints("pw_cin", "pw_act"))
+
+LateralDesc = _struct("LateralDesc", [
+    ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("x_bs", _i64), ("y_bs", _i64)]
+    + _ints("ldx", "ldy", "B", "Ti", "H", "W", "cin", "To", "cout", "kt", "st", "pt", "act", "dtype"))
 
 EnsembleDesc = _struct("EnsembleDesc", [
     ("logits", _p), ("video_index", _p), ("accum", _p), ("counts", _p)] + _ints("N", "C", "ld", "V", "mode"))
@@ -96,7 +100,7 @@ DESC_FOR_OP = {
     OP_CONV3D: Conv3dDesc, OP_DWCONV3D: DwConv3dDesc, OP_SE_GATE: SeGateDesc, OP_POOL3D: Pool3dDesc,
     OP_LAYERNORM: RowsDesc, OP_SOFTMAX_ROWS: RowsDesc, OP_MEAN_ROWS: RowsDesc, OP_POSENC: PosencDesc,
     OP_ATTENTION: AttentionDesc, OP_ADD_ACT: AddDesc, OP_INGEST: LayoutDesc, OP_EGRESS: LayoutDesc,
-    OP_TOKEN_POOL: TokenPoolDesc, OP_ROI_ALIGN: RoiAlignDesc,
+    OP_TOKEN_POOL: TokenPoolDesc, OP_ROI_ALIGN: RoiAlignDesc, OP_LATERAL: LateralDesc,
 }
 
 # every symbol the header declares: (name, restype, argtypes)
@@ -123,6 +127,7 @@ _SYMBOLS = [
     ("pv_add_act", C.c_int, [C.POINTER(AddDesc), _p]),
     ("pv_token_pool", C.c_int, [C.POINTER(TokenPoolDesc), _p]),
     ("pv_roi_align", C.c_int, [C.POINTER(RoiAlignDesc), _p]),
+    ("pv_lateral_fuse", C.c_int, [C.POINTER(LateralDesc), _p]),
     ("pv_plan_create", _p, []),
     ("pv_plan_destroy", None, [_p]),
     ("pv_plan_add", C.c_int, [_p, C.c_int, _p, C.c_size_t]),
@@ -135,7 +140,7 @@ _SYMBOLS = [
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _lib = None
 

@@ -857,9 +857,44 @@ def emit_multipathway(sess, mp, xs):
     wide = sess.alloc_act(xs[0].B, t_s, h_s, w_s, c_s + c_f)
     slow_slice = wide.channel_slice(0, c_s)
     emit_module_out(sess, blocks[0], xs[0], slow_slice)
-    emit_conv(sess, conv, fast, fusion.norm, act_code(fusion.activation), out=wide.channel_slice(c_s, c_f),
-              label="lateral_fuse")
+    emit_lateral(sess, conv, fast, fusion.norm, act_code(fusion.activation), wide.channel_slice(c_s, c_f))
     return [wide, fast], [slow_slice, fast]
+
+
+def emit_lateral(sess, conv, fast, norm, act, out):
+    """FuseFastToSlow's conv + norm + activation (models/slowfast.py:661-694, :720-729) -> pv_lateral_fuse, the
+    dedicated time-strided kernel (csrc/pv_lateral.hip) that stores into the slow buffer's channel slice `out`.
+    Anything that is not the builder's (kt,1,1) / (alpha,1,1) / (kt//2,0,0) bias-free conv goes through the
+    general conv emitter (same result, generic kernel)."""
+    kt, kh, kw = conv.kernel_size
+    st, sh, sw = conv.stride
+    pt, ph, pw = _triple(conv.padding)
+    plain = (kh, kw, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0) and tuple(conv.dilation) == (1, 1, 1) and conv.groups == 1 \
+        and conv.bias is None and fast.ld != 4 and not fast.f32
+    if not plain:
+        return emit_conv(sess, conv, fast, norm, act, out=out, label="lateral_fuse")
+    if conv.in_channels != fast.C:
+        raise RuntimeError("conv expects %d input channels, got %d" % (conv.in_channels, fast.C))
+    To = _conv_out(fast.T, kt, st, pt)
+    cout, cin_p = conv.out_channels, pad8(fast.C)
+    if To <= 0:
+        raise RuntimeError("conv output would be empty")
+    if (out.B, out.T, out.H, out.W) != (fast.B, To, fast.H, fast.W) or out.C != cout:
+        raise RuntimeError("lateral fusion output geometry mismatch: %s vs %s" % (
+            (out.B, out.T, out.H, out.W, out.C), (fast.B, To, fast.H, fast.W, cout)))
+    wp = torch.zeros(cout, kt, cin_p, dtype=torch.float32)
+    wp[:, :, : fast.C] = conv.weight.detach().float().cpu().reshape(cout, fast.C, kt).permute(0, 2, 1)
+    scale, shift = fold_norm(norm, cout, None)
+    has_affine = norm is not None and not isinstance(norm, nn.Identity)
+    f = dict(x=fast.ptr, w=sess.add_weight(wp.to(sess.dtype)), y=out.ptr,
+             scale=sess.add_weight(scale) if has_affine else None, shift=sess.add_weight(shift) if has_affine else None,
+             x_bs=fast.bs, y_bs=out.bs, ldx=fast.ld, ldy=out.ld, B=fast.B, Ti=fast.T, H=fast.H, W=fast.W, cin=cin_p,
+             To=To, cout=cout, kt=kt, st=st, pt=pt, act=act, dtype=sess.pv_dtype)
+    vox_out = fast.B * To * fast.H * fast.W
+    alg = sess.itemsize * (fast.B * fast.voxels * cin_p + cout * kt * cin_p + vox_out * pad8(cout))
+    detail = "|%dx%dx%dx%d c%d->%d k%dx1x1 s%d11" % (fast.B, To, fast.H, fast.W, fast.C, cout, kt, st)
+    sess.add_op(L.OP_LATERAL, f, label="lateral_fuse" + detail, alg_bytes=alg, flops=2 * vox_out * cout * kt * fast.C)
+    return out
 
 
 def emit_module_out(sess, m, x, out):

@@ -1,0 +1,243 @@
+// SlowFast's lateral connection as its own kernel: FuseFastToSlow.forward (models/slowfast.py:720-729) as
+// built by FastToSlowFusionBuilder.create_module (models/slowfast.py:661-694):
+//
+//   fuse        = act(BN(Conv3d(C_f -> 2 C_f, kernel (kt,1,1), stride (alpha,1,1), padding (kt/2,0,0), bias=False)(x_fast)))
+//   x_slow_fuse = cat([x_slow, fuse], dim=1)
+//
+// The conv is a time-strided gather of kt fast frames per slow frame at ONE spatial position: no spatial
+// halo, K = kt * C_f, and (8 -> 16 ... 128 -> 256 channels) an arithmetic intensity of 40-300 FLOP/B -- an
+// HBM-bound stream, not a tiled GEMM.  So the kernel is a streaming pass with an MFMA in the middle:
+//   * the filter slab of a workgroup (<= 128 output channels x kt*C_f, at most ~116 KB) is staged into LDS
+//     once; the workgroup then walks 16-voxel tiles of the SLOW grid in a grid-stride loop, no barriers;
+//   * the activation operand goes global -> MFMA B registers directly: for K step s lane (n = lane & 15,
+//     q = lane >> 4) loads the 16 bytes x_fast[b][alpha*t_s - kt/2 + tap][h][w][c .. c+7] with (tap, c) the
+//     position of k = 32 s + 8 q in the tap-major K order -- a per-lane frame offset from a tiny LDS table,
+//     frames outside the clip are the conv's zero padding (buffer addressing: out-of-range offset reads 0);
+//   * filter rows are permuted in LDS so that a lane's accumulators are 8 CONSECUTIVE output channels of its
+//     voxel: BN scale/shift + ReLU in registers, one 16-byte store per lane STRAIGHT INTO THE CHANNEL SLICE
+//     [C_slow, C_slow + 2 C_f) of the slow pathway's buffer -- the reference's torch.cat (a full copy of the
+//     slow tensor) does not exist;
+//   * each fast frame is needed by up to two slow frames (kt = 7, alpha = 4: 7 reads per 4 frames); tiles
+//     are ordered frame-major inside a clip, so the second use hits in L2 / Infinity Cache.
+#include "pv_common.h"
+
+namespace {
+
+constexpr int kLatThreads = 512;   // 8 waves share one filter slab
+
+struct LatTile {
+  unsigned xoff;   // byte offset of x[b][alpha*to - pt][h][w][0] (may be "negative": wraps, fixed by the frame offset)
+  int t0;          // alpha*to - pt
+  unsigned yoff;   // byte offset of y[b][to][h][w][n0]
+  bool ok;
+};
+
+// NT: 16-channel MFMA row tiles per workgroup (slab = NT * 16 output channels); TM: voxel tiles per wave tile
+template <int NT, int TM>
+__global__ __launch_bounds__(kLatThreads) void lateral_fuse_kernel(const pv_lateral_desc d, int ksteps, int ngroups,
+                                                                   int nchunks, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int Kp = ksteps * 32;
+  const int WLD = Kp + 8;   // row stride in elements: 16 B x odd -> conflict-free ds_read_b128
+  bf16_t* w_s = reinterpret_cast<bf16_t*>(smem_raw);
+  float* sc_s = reinterpret_cast<float*>(smem_raw + (size_t)NT * 16 * WLD * 2);
+  float* sh_s = sc_s + NT * 16;
+  int2* tap_s = reinterpret_cast<int2*>(sh_s + NT * 16);   // [ksteps][4]: (frame delta, byte offset of the frame + channel)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, q = lane >> 4;
+  const int cin_p = d.cin;                 // multiple of 8
+  const int cout_p8 = pv_round_up(d.cout, 8);
+  const int HW = d.H * d.W;
+  const long M = (long)d.B * d.To * HW;
+  // the N splits of one voxel chunk are consecutive workgroups of one XCD: the activations are fetched from
+  // HBM once and re-read from that XCD's L2 by the other splits
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int chunk = (slot / nsplit) * 8 + xcd;
+  const int n0 = (slot % nsplit) * (NT * 16);
+
+  // ---- stage the filter slab (LDS row r = channel n0 + perm(r)), BN scale / shift, the tap table ----
+  {
+    const bf16_t* __restrict__ Wt = static_cast<const bf16_t*>(d.w);
+    const int K = d.kt * cin_p;
+    const int cpr = Kp / 8;
+    for (int id = tid; id < NT * 16 * cpr; id += kLatThreads) {
+      const int r = id / cpr, kc = id - r * cpr;
+      const int tn = r >> 4, ii = r & 15;
+      const int c = n0 + (tn >> 1) * 32 + (ii >> 2) * 8 + (tn & 1) * 4 + (ii & 3);
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (c < d.cout && kc * 8 < K) v = *reinterpret_cast<const bf16x8*>(Wt + (long)c * K + kc * 8);
+      *reinterpret_cast<bf16x8*>(w_s + r * WLD + kc * 8) = v;
+    }
+    for (int i = tid; i < NT * 16; i += kLatThreads) {
+      const int c = n0 + i;
+      const bool ok = c < d.cout;
+      sc_s[i] = ok ? (d.scale ? d.scale[c] : 1.f) : 0.f;
+      sh_s[i] = ok ? (d.shift ? d.shift[c] : 0.f) : 0.f;
+    }
+    for (int i = tid; i < ksteps * 4; i += kLatThreads) {
+      const int k = (i >> 2) * 32 + (i & 3) * 8;
+      const int tap = k / cin_p, c = k - tap * cin_p;
+      // taps past kt (the zero-padded tail of the last K step) get a frame delta that is always outside the clip
+      tap_s[i] = tap < d.kt ? int2{tap, (int)(((unsigned)tap * (unsigned)HW * (unsigned)d.ldx + (unsigned)c) * 2u)}
+                            : int2{1 << 28, 0};
+    }
+  }
+  __syncthreads();
+
+  constexpr unsigned kOOB = 0x80000000u;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(d.x), 0, (int)((unsigned)d.B * (unsigned)d.x_bs * 2u), 0x00020000);
+  __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      d.y, 0, (int)((unsigned)d.B * (unsigned)d.y_bs * 2u), 0x00020000);
+  const int live_pairs = min(NT / 2, (cout_p8 - n0 + 31) / 32);   // wave-uniform
+  constexpr int NP = NT / 2;
+  constexpr int NWV = kLatThreads / 64;
+
+  auto tile_of = [&](int g, LatTile (&t)[TM]) {
+    const long m_base = ((long)g * NWV + wave) * (TM * 16);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long m = m_base + i * 16 + n16;
+      const bool ok = g < ngroups && m < M;
+      const unsigned mm = ok ? (unsigned)m : 0u;
+      const unsigned bt = mm / (unsigned)HW, hw = mm - bt * (unsigned)HW;   // bt = b * To + to
+      const unsigned b = bt / (unsigned)d.To, to = bt - b * (unsigned)d.To;
+      t[i].ok = ok;
+      t[i].t0 = (int)to * d.st - d.pt;
+      t[i].xoff = (unsigned)((long)b * d.x_bs + ((long)t[i].t0 * HW + hw) * d.ldx) * 2u;
+      t[i].yoff = (unsigned)((long)b * d.y_bs + ((long)to * HW + hw) * d.ldy + n0) * 2u;
+    }
+  };
+  auto load_x = [&](u32x4 (&dst)[TM], const LatTile (&t)[TM], int ks) {
+    const int2 tp = tap_s[ks * 4 + q];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const bool ok = t[i].ok && (unsigned)(t[i].t0 + tp.x) < (unsigned)d.Ti;
+      dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? t[i].xoff + (unsigned)tp.y : kOOB), 0, 0);
+    }
+  };
+
+  LatTile cur[TM], nxt[TM];
+  u32x4 xf[TM], xn[TM];
+  int g = chunk < nchunks ? chunk : ngroups;   // padded workgroups (grid is a multiple of 8 chunks) do nothing
+  tile_of(g, cur);
+  load_x(xf, cur, 0);
+  for (; g < ngroups; g += nchunks) {
+    f32x4 acc[NT][TM];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[a][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    tile_of(g + nchunks, nxt);
+    for (int ks = 0; ks < ksteps; ++ks) {
+      // the next K step's operand (or the next tile's first one) is requested before this step's MFMAs
+      if (ks + 1 < ksteps) load_x(xn, cur, ks + 1);
+      else load_x(xn, nxt, 0);
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        if ((a >> 1) < live_pairs) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w_s + (a * 16 + n16) * WLD + ks * 32 + q * 8);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, xf[i]), acc[a][i], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xf[i] = xn[i];
+    }
+    // ---- epilogue: lane (n16, q) owns channels n0 + 32 p + 8 q .. + 7 of its voxel ----
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (p >= live_pairs) break;
+      const int cl = p * 32 + q * 8;
+      const int c0 = n0 + cl;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc_s + cl), s1 = *reinterpret_cast<const f32x4*>(sc_s + cl + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh_s + cl), h1 = *reinterpret_cast<const f32x4*>(sh_s + cl + 4);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[2 * p][i][j] * s0[j] + h0[j];
+          v[4 + j] = acc[2 * p + 1][i][j] * s1[j] + h1[j];
+        }
+        pv_apply_act_n<true>(v, d.act);
+        if (c0 + 8 > d.cout) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (c0 + j >= d.cout) v[j] = 0.f;   // the padding up to the 8-multiple is written as zeros
+        }
+        bf16x8 ob;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ob[j] = (bf16_t)v[j];
+        const bool ok = cur[i].ok && c0 < cout_p8;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), ry,
+                                               (int)(ok ? cur[i].yoff + (unsigned)cl * 2u : kOOB), 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) cur[i] = nxt[i];
+  }
+}
+
+template <int NT, int TM>
+int launch_lateral(const pv_lateral_desc& d, int ksteps, size_t lds, hipStream_t s) {
+  const long M = (long)d.B * d.To * d.H * d.W;
+  const long ngroups = pv_ceil_div(M, (kLatThreads / 64) * TM * 16);
+  const int nsplit = (int)pv_ceil_div(pv_round_up(d.cout, 8), NT * 16);
+  auto kern = lateral_fuse_kernel<NT, TM>;
+  if (lds > 64 * 1024)
+    PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // one resident generation of workgroups; the rest is the grid-stride loop (the slab is staged once per workgroup)
+  long per_cu = (160 * 1024) / (long)(lds + 1024);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+  long nchunks = pv_ceil_div(256 * per_cu, nsplit);
+  if (nchunks > ngroups) nchunks = ngroups;
+  const long blocks = pv_ceil_div(nchunks, 8) * 8 * nsplit;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kLatThreads), lds, s, d, ksteps, (int)ngroups, (int)nchunks, nsplit);
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
+}  // namespace
+
+extern "C" int pv_lateral_fuse(const pv_lateral_desc* dp, pv_stream_t stream) {
+  if (!dp) return PV_ERR_INVALID;
+  const pv_lateral_desc& d = *dp;
+  if (!d.x || !d.w || !d.y) return PV_ERR_INVALID;
+  if (d.B <= 0 || d.Ti <= 0 || d.H <= 0 || d.W <= 0 || d.cin <= 0 || d.cout <= 0 || d.To <= 0) return PV_ERR_INVALID;
+  if (d.kt < 1 || d.st < 1 || d.pt < 0 || d.cin % 8 || d.ldx % 8 || d.ldy % 8 || d.x_bs % 8 || d.y_bs % 8) return PV_ERR_INVALID;
+  if ((d.Ti + 2 * d.pt - d.kt) / d.st + 1 != d.To || d.ldx < d.cin || d.ldy < pv_round_up(d.cout, 8)) return PV_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int cout_p8 = pv_round_up(d.cout, 8);
+  const int ksteps = (d.kt * d.cin + 31) / 32;
+  const bool small_offsets = (long)d.B * d.x_bs * 2 <= 0x7fffffffL && (long)d.B * d.y_bs * 2 <= 0x7fffffffL &&
+                             (long)d.B * d.To * d.H * d.W <= 0x7fffffffL;
+  int nt = cout_p8 <= 32 ? 2 : (cout_p8 <= 64 ? 4 : 8);
+  auto lds_of = [&](int t) { return (size_t)t * 16 * (ksteps * 32 + 8) * 2 + (size_t)2 * t * 16 * 4 + (size_t)ksteps * 4 * 8; };
+  while (nt > 2 && lds_of(nt) > 120 * 1024) nt >>= 1;
+  // Where the op stops being a stream: K = kt * cin >= 448 (SlowFast-R50's 64 -> 128 and 128 -> 256 sites, 150-300
+  // FLOP/B) is MFMA work whose operands want full 128-byte lines staged through LDS; measured on the R50 sites
+  // (16 clips, same box): streaming kernel 26 / 61 / 60 / 59 us, LDS-DMA implicit GEMM 38 / 87 / 53 / 41 us.
+  const bool stream_shaped = d.kt * d.cin <= 256;
+  if (d.dtype != PV_BF16 || !small_offsets || !stream_shaped || lds_of(nt) > 120 * 1024) {
+    // fp32 parity mode, MFMA-bound widths and geometries outside the streaming kernel's range: the same arithmetic
+    // as a (kt,1,1) convolution through the dense-conv entry point -- still the HIP library, never a host path
+    pv_conv3d_desc c = {};
+    c.x = d.x; c.w = d.w; c.y = d.y; c.scale = d.scale; c.shift = d.shift;
+    c.x_bs = d.x_bs; c.y_bs = d.y_bs; c.ldx = d.ldx; c.ldy = d.ldy;
+    c.B = d.B; c.Ti = d.Ti; c.Hi = d.H; c.Wi = d.W; c.cin = d.cin;
+    c.To = d.To; c.Ho = d.H; c.Wo = d.W; c.cout = d.cout;
+    c.kt = d.kt; c.kh = 1; c.kw = 1; c.st = d.st; c.sh = 1; c.sw = 1; c.pt = d.pt;
+    c.act = d.act; c.dtype = d.dtype;
+    return pv_conv3d(&c, stream);
+  }
+  const size_t lds = lds_of(nt);
+  if (nt == 2) return launch_lateral<2, 2>(d, ksteps, lds, s);
+  if (nt == 4) return launch_lateral<4, 2>(d, ksteps, lds, s);
+  return launch_lateral<8, 1>(d, ksteps, lds, s);
+}

@@ -9,7 +9,7 @@
 
 namespace {
 thread_local std::string g_last_error;
-constexpr int kAbiVersion = 15;
+constexpr int kAbiVersion = 16;
 }  // namespace
 
 int pv_set_hip_error(hipError_t e, const char* what) {
@@ -55,6 +55,7 @@ size_t desc_size(int kind) {
     case PV_OP_EGRESS: return sizeof(pv_layout_desc);
     case PV_OP_TOKEN_POOL: return sizeof(pv_token_pool_desc);
     case PV_OP_ROI_ALIGN: return sizeof(pv_roi_align_desc);
+    case PV_OP_LATERAL: return sizeof(pv_lateral_desc);
     default: return 0;
   }
 }
@@ -76,6 +77,7 @@ int run_op(const pv_plan::Op& op, pv_stream_t s) {
     case PV_OP_EGRESS: return pv_egress_ncdhw(static_cast<const pv_layout_desc*>(p), s);
     case PV_OP_TOKEN_POOL: return pv_token_pool(static_cast<const pv_token_pool_desc*>(p), s);
     case PV_OP_ROI_ALIGN: return pv_roi_align(static_cast<const pv_roi_align_desc*>(p), s);
+    case PV_OP_LATERAL: return pv_lateral_fuse(static_cast<const pv_lateral_desc*>(p), s);
     default: return PV_ERR_INVALID;
   }
 }

@@ -651,3 +651,46 @@ def test_fused_token_pooling_conv_layernorm(dtype, heads, hd, thw, strides, cls)
     call("pv_token_pool", d)
     for y, want in zip(outs, wants):
         assert rel_err(y, want) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Ti,H,W,cin,cout,c_slow,kt,st", [
+    (2, 32, 16, 16, 8, 16, 64, 7, 4),      # SlowFast-R50 site 1 (stem -> res2): 4 taps per K step
+    (2, 32, 8, 8, 32, 64, 256, 7, 4),      # site 2
+    (1, 32, 8, 8, 64, 128, 512, 7, 4),     # site 3
+    (1, 32, 4, 4, 128, 256, 1024, 7, 4),   # site 4: the slab is split over channels
+    (2, 16, 7, 9, 24, 40, 16, 5, 2),       # slowfast_r101's 5x1x1 kernel, alpha = 2, ragged spatial size and widths
+    (1, 9, 5, 3, 16, 8, 8, 7, 4),          # fewer voxels than one wave tile, T not a multiple of alpha
+])
+def test_lateral_fusion_writes_the_slow_buffers_channel_slice(dtype, B, Ti, H, W, cin, cout, c_slow, kt, st):
+    """pv_lateral_fuse vs F.conv3d + BatchNorm + ReLU + torch.cat (FuseFastToSlow.forward, models/slowfast.py:720-729)."""
+    pt = kt // 2
+    To = (Ti + 2 * pt - kt) // st + 1
+    cin_p, cw = (cin + 7) // 8 * 8, c_slow + (cout + 7) // 8 * 8
+    g = torch.Generator().manual_seed(11)
+    xf = torch.zeros(B, Ti, H, W, cin_p)
+    xf[..., :cin] = torch.randn(B, Ti, H, W, cin, generator=g)
+    xf = xf.to(dtype).cuda()
+    w = (torch.randn(cout, cin, kt, 1, 1, generator=g) * (1.5 / (cin * kt)) ** 0.5).to(dtype)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.rand(cout, generator=g) - 0.5
+    slow = torch.randn(B, To, H, W, c_slow, generator=g).to(dtype)
+    wide = torch.full((B, To, H, W, cw), 3.0, dtype=dtype)
+    wide[..., :c_slow] = slow
+    wide = wide.cuda()
+    wp = torch.zeros(cout, kt, cin_p, dtype=dtype)
+    wp[:, :, :cin] = w.reshape(cout, cin, kt).permute(0, 2, 1)
+    wp, sc, sh = wp.cuda(), scale.cuda(), shift.cuda()
+    d = L.LateralDesc()
+    d.x, d.w, d.y = xf.data_ptr(), wp.data_ptr(), wide.data_ptr() + c_slow * wide.element_size()
+    d.scale, d.shift = sc.data_ptr(), sh.data_ptr()
+    d.x_bs, d.y_bs, d.ldx, d.ldy = xf.stride(0), wide.stride(0), cin_p, cw
+    d.B, d.Ti, d.H, d.W, d.cin, d.To, d.cout = B, Ti, H, W, cin_p, To, cout
+    d.kt, d.st, d.pt, d.act, d.dtype = kt, st, pt, L.ACT_RELU, pv_dtype(xf)
+    call("pv_lateral_fuse", d)
+    ref = F.conv3d(xf[..., :cin].float().cpu().permute(0, 4, 1, 2, 3), w.float(), stride=(st, 1, 1), padding=(pt, 0, 0))
+    ref = F.relu(ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)).permute(0, 2, 3, 4, 1)
+    got = wide.float().cpu()
+    assert torch.equal(got[..., :c_slow], slow.float())                       # the slow pathway's slice is untouched
+    assert rel_err(got[..., c_slow:c_slow + cout], ref) <= TOL[dtype]
+    assert torch.all(got[..., c_slow + cout:] == 0)                           # padding channels of the slice are zeros
