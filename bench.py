@@ -387,6 +387,7 @@ def main():
     ap.add_argument("--with-h2d", action="store_true",
                     help="also time steps that upload the (pinned) host input first; reported as pcie_inclusive, never as value")
     ap.add_argument("--dry-host", action="store_true", help="launcher check on the host (gloo, original-form model); no GPU")
+    ap.add_argument("--tune", default="", help="development knobs k=v,... (pytorchvideo_amd.accelerator.mi355x.tuning / pv_tune_set)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -401,6 +402,9 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.tune:
+        from pytorchvideo_amd.accelerator.mi355x import tuning
+        tuning.apply(args.tune)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:

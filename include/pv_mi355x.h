@@ -132,6 +132,13 @@ int pv_conv3d_dwt_supported(const pv_conv3d_desc* d);
 /* 1 if this geometry (pointers are ignored; x2_cin > 0) can run with the second K operand, else 0 */
 int pv_conv3d_x2_supported(const pv_conv3d_desc* d);
 
+/* ---- development knobs ---------------------------------------------------------------------
+ * Kernel-routing choices that were settled by A/B measurements on the MI355X stay overridable for the tools
+ * that re-measure them (tools/bench_gemm.py, tools/gpu_*.sh): pv_tune_set("gemm8", 0) etc.  Process-wide, read
+ * when an op is launched eagerly or recorded into a graph; nothing is ever read from the environment. */
+int pv_tune_set(const char* key, int value);
+int pv_tune_clear(void);
+
 /* ---- SlowFast lateral connection (fast -> slow fusion) -----------------------------------
  * Replaces FuseFastToSlow.forward (models/slowfast.py:720-729) as built by
  * FastToSlowFusionBuilder.create_module (models/slowfast.py:661-694), called from

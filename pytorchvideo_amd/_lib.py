@@ -128,6 +128,8 @@ _SYMBOLS = [
     ("pv_token_pool", C.c_int, [C.POINTER(TokenPoolDesc), _p]),
     ("pv_roi_align", C.c_int, [C.POINTER(RoiAlignDesc), _p]),
     ("pv_lateral_fuse", C.c_int, [C.POINTER(LateralDesc), _p]),
+    ("pv_tune_set", C.c_int, [C.c_char_p, C.c_int]),
+    ("pv_tune_clear", C.c_int, []),
     ("pv_plan_create", _p, []),
     ("pv_plan_destroy", None, [_p]),
     ("pv_plan_add", C.c_int, [_p, C.c_int, _p, C.c_size_t]),
@@ -140,7 +142,7 @@ _SYMBOLS = [
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _lib = None
 
@@ -171,6 +173,12 @@ def lib():
             raise PvError("ABI mismatch: library %d, binding %d" % (h.pv_version(), ABI_VERSION))
         _lib = h
     return _lib
+
+
+def tune(**knobs):
+    """Development knobs of the library (kernel-routing A/Bs; see include/pv_mi355x.h): tune(gemm8=0)."""
+    for k, v in knobs.items():
+        check(lib().pv_tune_set(k.encode(), int(v)), "pv_tune_set(%s)" % k)
 
 
 def check(status, what=""):

@@ -172,9 +172,8 @@ def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quant
             lo += b
             parts.append(convert_to_deployable_form(model, xc, convert_for_quantize, native_conv3d_op_qnnpack,
                                                     dtype=dtype, use_graph=use_graph))
-        import os
-        return SplitBatchDeployed(parts, splits, parts[0]._pv_session.device,
-                                  joint=os.environ.get("PV_SPLIT_JOINT", "1") != "0")
+        from . import tuning
+        return SplitBatchDeployed(parts, splits, parts[0]._pv_session.device, joint=tuning.get("split_joint_graph"))
     if type(model).__name__ == "DetectionBBoxNetwork":
         return _convert_detection(model, input_tensor, dtype, use_graph,
                                   dict(convert_for_quantize=convert_for_quantize,

@@ -11,12 +11,12 @@ scaling and Swish are fused into conv epilogues / prologues as described in DESI
 in place (reference convention: transmuter_mobile_cpu.py:21-22).
 """
 import ctypes as C
-import os
 
 import torch
 import torch.nn as nn
 
 from ... import _lib as L
+from . import tuning
 from .session import pad8
 
 
@@ -126,7 +126,7 @@ def _shortcut_geometry(conv_s, x2, out_thw):
 def can_fold_shortcut(sess, conv_c, conv_s, x2, cin_c):
     """True when the projection shortcut `conv_s(x2)` can ride in the pointwise conv_c as a second K operand
     (csrc/pv_pwconv.hip); decided by the library from the geometry.  `cin_c`: conv_c's input channels."""
-    if os.environ.get("PV_FUSE_SHORTCUT", "1") == "0" or sess.itemsize != 2 or x2.f32:
+    if not tuning.get("fuse_shortcut") or sess.itemsize != 2 or x2.f32:
         return False
     if not isinstance(conv_c, nn.Conv3d) or not isinstance(conv_s, nn.Conv3d):
         return False
@@ -179,7 +179,7 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
     # pack [cout][taps][cin_p]
     w = conv.weight.detach().float().cpu()  # [cout, cin, kt, kh, kw]
     wpair = 0
-    if c4 and pad8(cout) <= 8 and dwt is None and not y_f32 and os.environ.get("PV_STEM_WPAIR", "1") != "0":
+    if c4 and pad8(cout) <= 8 and dwt is None and not y_f32 and tuning.get("stem_wpair"):
         # <= 8 output channels (SlowFast's fast stem): two W-adjacent outputs per MFMA column; row (j, co) of the
         # 16-row filter tile is co's filter shifted right by j*sw voxels
         wpair, cp8 = 2, pad8(cout)
@@ -291,12 +291,12 @@ def _pointwise_producer_fields(sess, producer, x, Cc):
 def can_fuse_pointwise_into_dw(sess, conv_a, conv_b, x):
     """True when conv_a (1x1x1) -> conv_b (depthwise 3x3x3) can run as one pv_dwconv3d launch with
     the fused pointwise producer (csrc/pv_pwdw.hip); decided by the library from the geometry."""
-    if os.environ.get("PV_FUSE_AB", "1") == "0" or sess.itemsize != 2 or x.f32:
+    if not tuning.get("fuse_ab") or sess.itemsize != 2 or x.f32:
         return False
     # Every 32-channel slab of the expanded tensor is a workgroup that reads the whole block input, so
     # the fusion pays while the input is narrow (X3D res2/res3: measured 1.3-1.8x over the pair of
     # launches); with >= 96 input channels the slabs' re-reads cost more than the round trip saved.
-    if x.C > int(os.environ.get("PV_FUSE_AB_MAX_CIN", "64")):
+    if x.C > tuning.get("fuse_ab_max_cin"):
         return False
     if not isinstance(conv_a, nn.Conv3d) or not isinstance(conv_b, nn.Conv3d):
         return False
@@ -601,7 +601,7 @@ def can_fuse_temporal_dw(sess, first, second, mid_norm, mid_act, x, act):
     """True when `first` (dense 1 x kh x kw conv on the 4-channel first-layer layout) and `second`
     (depthwise k x 1 x 1 temporal conv) with nothing in between can run as one pv_conv3d launch
     (csrc/pv_stem.hip, X3D stem); decided by the library from the geometry."""
-    if os.environ.get("PV_FUSE_STEM", "1") == "0" or x.ld != 4 or sess.itemsize != 2:
+    if not tuning.get("fuse_stem") or x.ld != 4 or sess.itemsize != 2:
         return False
     if mid_norm is not None and not isinstance(mid_norm, nn.Identity):
         return False

@@ -19,7 +19,7 @@ epilogues add an fp32 residual and write fp32 -- so that 16 blocks of bf16 round
 pile up on the stream; every MFMA operand (x_norm, q/k/v, P, attention output, MLP hidden)
 is bf16.
 """
-import os
+from . import tuning
 
 import torch
 import torch.nn as nn
@@ -332,7 +332,7 @@ def emit_multiscale_attention(sess, attn, xn, residual, label="attn"):
         outs = list(parts)
         big = [i for i in range(3) if _streams_well(pools[i], parts[i])]
         kv = None
-        if 1 in big and 2 in big and os.environ.get("PV_FUSE_KV_POOL", "1") != "0":
+        if 1 in big and 2 in big and tuning.get("fuse_kv_pool"):
             xkv = qkv.channel_slice(attn.dim_out, 2 * attn.dim_out)
             xkv.thw, xkv.has_cls = xn.thw, xn.has_cls
             kv = emit_attention_pool_kv(sess, pools[1], pools[2], xkv, heads, label + ".pool_kv")
@@ -438,7 +438,7 @@ def emit_patch_embed_and_pos(sess, patch_embed, cls_pos, x):
 
     # In the bf16 plan the conv runs on the first-layer kernel, whose fp32 epilogue adds the position tables
     # (the full table minus its cls row when they are not separable); only the cls row is left to pos_encoding.
-    in_conv = x.ld == 4 and os.environ.get("PV_FUSE_POSENC", "1") != "0"
+    in_conv = x.ld == 4 and tuning.get("fuse_posenc")
     pos = None
     if in_conv:
         full = cls_pos.pos_embed_spatial if sep else cls_pos.pos_embed

@@ -1,0 +1,30 @@
+"""Fusion / routing decisions of the emitters that were settled by A/B measurements on the MI355X, kept
+overridable for the tools that re-measure them (tools/*.py set OPTIONS[...] before converting a model).
+Nothing here -- and nothing in the library (pv_tune_set) -- is read from the environment; none of the
+options selects a non-HIP path."""
+
+OPTIONS = {
+    "fuse_shortcut": True,       # projection shortcut as a second K operand of conv_c            (emit.can_fold_shortcut)
+    "stem_wpair": True,          # two W-adjacent outputs per MFMA column in the <= 8-channel stem (emit.emit_conv)
+    "fuse_ab": True,             # conv_a evaluated inside the depthwise conv_b kernel             (emit.can_fuse_pointwise_into_dw)
+    "fuse_ab_max_cin": 64,       # ... while the block input has at most this many channels
+    "fuse_stem": True,           # X3D stem (conv_xy + temporal depthwise + BN + ReLU) in one launch
+    "fuse_kv_pool": True,        # MViT pool_k + pool_v as one depthwise launch                   (emit_mvit)
+    "fuse_posenc": True,         # position tables added in the patch-embedding conv's epilogue   (emit_mvit)
+    "split_joint_graph": True,   # sub-batches of SplitBatchDeployed as branches of ONE hipGraph  (conversion)
+}
+
+
+def get(name):
+    return OPTIONS[name]
+
+
+def apply(spec):
+    """"k=v,k=v" (tools' --tune option): emitter options by name, everything else goes to the library (pv_tune_set)."""
+    from ... import _lib as L
+    for item in [t for t in (spec or "").split(",") if t]:
+        k, v = item.split("=")
+        if k in OPTIONS:
+            OPTIONS[k] = type(OPTIONS[k])(int(v))
+        else:
+            L.tune(**{k: int(v)})

@@ -12,7 +12,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define PV_WAVE 64
 
-int pv_set_hip_error(hipError_t e, const char* what);  // pv_plan.cpp
+int pv_set_hip_error(hipError_t e, const char* what);  // pv_plan.hip
+// development knobs (kernel routing A/Bs): set through the C ABI (pv_tune_set), never read from the environment
+int pv_tune(const char* key, int dflt);                // pv_plan.hip
 #define PV_HIP_CHECK(expr)                                   \
   do {                                                       \
     hipError_t _e = (expr);                                  \

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s);      // pv_pwconv.hip
 int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);  // pv_gemm.hip
+int pv_gemm8_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);      // pv_gemm8.hip
 int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s);                 // pv_stem.hip
 int pv_stem_dwt_supported(const pv_conv3d_desc& d);                     // pv_stem.hip
 int pv_pwconv_x2_supported(const pv_conv3d_desc& d);                    // pv_pwconv.hip
@@ -370,14 +371,14 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
     return pv_pwconv_stream_try(d, s);
   }
   if (d.dtype == PV_BF16) {
-    // PV_CONV_ROUTE (experiments): 1 = prefer the streaming kernel, 2 = prefer the LDS-DMA GEMM, 3 = generic only
-    static const int route = getenv("PV_CONV_ROUTE") ? atoi(getenv("PV_CONV_ROUTE")) : 0;
+    // pv_tune "conv_route" (experiments): 1 = prefer the streaming kernel, 2 = prefer the LDS-DMA GEMM, 3 = generic only
+    const int route = pv_tune("conv_route", 0);
     const int cout_p8 = pv_round_up(d.cout, 8);
     // Pointwise layers with a short reduction (X3D widths, SlowFast's fast pathway, MViT's first block)
     // are streaming problems: weights resident in LDS, activations straight into MFMA operands.
     // From ~192 input channels on the LDS-DMA GEMM wins on every measured shape, narrow outputs included
-    // (profiles/r1: route sweeps on MViT-B and SlowFast-R50).  PV_CONV_SMALL_CIN overrides the threshold.
-    static const int small_cin = getenv("PV_CONV_SMALL_CIN") ? atoi(getenv("PV_CONV_SMALL_CIN")) : 128;
+    // (profiles/r1: route sweeps on MViT-B and SlowFast-R50).  pv_tune "conv_small_cin" overrides the threshold.
+    const int small_cin = pv_tune("conv_small_cin", 128);
     const bool small = d.cin <= small_cin;
     if (route != 3) {
       if (pw && (route == 1 || (route == 0 && small))) {
@@ -388,7 +389,9 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
       // decoding dominates when a tap is only 8 channels wide (RGB stems): those stay on the
       // generic register-staged kernel
       const bool gemm_ok = route == 2 || pw || (cout_p8 >= 64 && d.cin >= 64);
-      int r = gemm_ok ? pv_gemm_glds_try(d, pw, s) : PV_ERR_UNSUPPORTED;
+      int r = gemm_ok ? pv_gemm8_try(d, pw, s) : PV_ERR_UNSUPPORTED;     // large tiles, 4-stage ring: big layers
+      if (r != PV_ERR_UNSUPPORTED) return r;
+      r = gemm_ok ? pv_gemm_glds_try(d, pw, s) : PV_ERR_UNSUPPORTED;
       if (r != PV_ERR_UNSUPPORTED) return r;
       if (pw) {
         r = pv_pwconv_stream_try(d, s);

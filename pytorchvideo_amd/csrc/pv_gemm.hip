@@ -418,7 +418,7 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   // them whenever they pack the rounds better costs MViT-B 4 % (a 64-row tile re-stages the same 128-row filter
   // tile for half the MFMA work); this rule gains SlowFast-R50 1.4 % and MViT-B 0.7 %.
   const long t128 = pv_ceil_div(M, 128) * tiles_n;
-  static const int force_vt = getenv("PV_GEMM_VT") ? atoi(getenv("PV_GEMM_VT")) : 0;
+  const int force_vt = pv_tune("gemm_vt", 0);
   const int vt = force_vt ? force_vt : (2 * t128 <= resident ? 1 : 2);
   const long tiles_m = pv_ceil_div(M, 64 * vt);
   const long total = tiles_m * tiles_n;
@@ -426,7 +426,7 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return PV_ERR_UNSUPPORTED;   // 31-bit buffer offsets
   const float inv_cin = 1.0f / (float)d.cin;
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads);
-  static const int abl = getenv("PV_GEMM_ABL") ? atoi(getenv("PV_GEMM_ABL")) : 0;
+  const int abl = pv_tune("gemm_abl", 0);
   if (abl && vt == 2) {
     if (abl == 1) { if (pw) hipLaunchKernelGGL((gemm_glds_kernel<true, 2, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
                     else hipLaunchKernelGGL((gemm_glds_kernel<false, 2, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin); }

@@ -9,7 +9,7 @@
 
 namespace {
 thread_local std::string g_last_error;
-constexpr int kAbiVersion = 16;
+constexpr int kAbiVersion = 17;
 }  // namespace
 
 int pv_set_hip_error(hipError_t e, const char* what) {
@@ -17,6 +17,30 @@ int pv_set_hip_error(hipError_t e, const char* what) {
   snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
   g_last_error = buf;
   return PV_ERR_HIP;
+}
+
+namespace {
+struct TuneEntry { std::string key; int value; };
+std::vector<TuneEntry>& tune_table() { static std::vector<TuneEntry> t; return t; }
+}  // namespace
+
+int pv_tune(const char* key, int dflt) {
+  for (const auto& e : tune_table())
+    if (e.key == key) return e.value;
+  return dflt;
+}
+
+extern "C" int pv_tune_set(const char* key, int value) {
+  if (!key || !*key || strlen(key) > 48) return PV_ERR_INVALID;
+  for (auto& e : tune_table())
+    if (e.key == key) { e.value = value; return PV_OK; }
+  tune_table().push_back({key, value});
+  return PV_OK;
+}
+
+extern "C" int pv_tune_clear(void) {
+  tune_table().clear();
+  return PV_OK;
 }
 
 extern "C" int pv_version(void) { return kAbiVersion; }

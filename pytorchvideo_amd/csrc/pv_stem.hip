@@ -456,11 +456,11 @@ int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s) {
   if (jp == 2) return launch_stem<1, 4, 2>(d, ksteps, s);
   if (cout_p8 <= 16) return launch_stem<1, 4>(d, ksteps, s);
   if (cout_p8 <= 32) return launch_stem<2, 4>(d, ksteps, s);
-  static const int mid = getenv("PV_STEM_MID") ? atoi(getenv("PV_STEM_MID")) : 4;
+  const int mid = pv_tune("stem_mid", 4);
   if (cout_p8 <= 64) return mid == 2 ? launch_stem<2, 4>(d, ksteps, s) : launch_stem<4, 2>(d, ksteps, s);
   // wider outputs (MViT's 96 patch-embedding channels) split over blockIdx.y: 48 filter rows per workgroup keep
   // the LDS-resident filter slab (K up to 672) small enough for two workgroups per CU
-  static const int wide = getenv("PV_STEM_WIDE") ? atoi(getenv("PV_STEM_WIDE")) : 2;
+  const int wide = pv_tune("stem_wide", 2);
   if (wide == 6) return launch_stem<6, 1>(d, ksteps, s);
   if (wide == 2) return launch_stem<2, 2>(d, ksteps, s);
   return launch_stem<3, 2>(d, ksteps, s);

@@ -694,3 +694,62 @@ def test_lateral_fusion_writes_the_slow_buffers_channel_slice(dtype, B, Ti, H, W
     assert torch.equal(got[..., :c_slow], slow.float())                       # the slow pathway's slice is untouched
     assert rel_err(got[..., c_slow:c_slow + cout], ref) <= TOL[dtype]
     assert torch.all(got[..., c_slow + cout:] == 0)                           # padding channels of the slice are zeros
+
+
+# ------------------------------------------------------------------ large-tile GEMM (256-voxel tiles, 4-stage LDS ring)
+def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine):
+    """pv_conv3d forced onto the large-tile kernel (pv_tune gemm8 = 2 | 4) vs torch on the same bf16-rounded data."""
+    dtype = torch.bfloat16
+    pad = tuple(kk // 2 for kk in k)
+    g = torch.Generator().manual_seed(7 * cin + cout)
+    x = torch.randn(B, T, H, W, cin, generator=g).to(dtype).cuda()
+    w = (torch.randn((cout, cin) + k, generator=g) * (cin * k[0] * k[1] * k[2]) ** -0.5).to(dtype).cuda()
+    shift = torch.randn(cout, generator=g).cuda()
+    scale = (torch.rand(cout, generator=g) + 0.5).cuda() if affine else None
+    want = F.conv3d(x.float().permute(0, 4, 1, 2, 3), w.float(), stride=stride, padding=pad)
+    if affine:
+        want = want * scale.view(1, -1, 1, 1, 1)
+    want = want + shift.view(1, -1, 1, 1, 1)
+    To, Ho, Wo = want.shape[2:]
+    cp = (cout + 7) // 8 * 8
+    r = None
+    if res:
+        r = torch.randn(B, To, Ho, Wo, cp, generator=g).to(torch.float32 if y_f32 else dtype).cuda()
+        want = want + r[..., :cout].float().permute(0, 4, 1, 2, 3)
+    want = {L.ACT_NONE: lambda t: t, L.ACT_RELU: F.relu, L.ACT_GELU: F.gelu}[act](want)
+    y = torch.full((B, To, Ho, Wo, cp), 5.0, dtype=torch.float32 if y_f32 else dtype, device="cuda")
+    wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous()
+    d = L.Conv3dDesc()
+    d.x, d.w, d.y, d.shift = x.data_ptr(), wp.data_ptr(), y.data_ptr(), shift.data_ptr()
+    d.scale = scale.data_ptr() if affine else None
+    d.residual = r.data_ptr() if res else None
+    d.x_bs, d.y_bs, d.r_bs, d.ldx, d.ldy, d.ldr = T * H * W * cin, To * Ho * Wo * cp, To * Ho * Wo * cp, cin, cp, cp
+    d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, cin, To, Ho, Wo, cout
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *stride, *pad)
+    d.act, d.a_act, d.dtype, d.y_f32, d.r_f32 = act, L.ACT_NONE, L.PV_BF16, int(y_f32), int(y_f32 and res)
+    L.tune(gemm8=ct)
+    try:
+        call("pv_conv3d", d)
+        got1 = y.clone()
+        call("pv_conv3d", d)                       # a second launch gives the same bits
+    finally:
+        L.tune(gemm8=1)
+    assert torch.equal(got1, y)
+    assert rel_err(y[..., :cout].permute(0, 4, 1, 2, 3), want) <= 1e-2
+    if cp > cout:
+        assert torch.all(y[..., cout:] == 0)       # padding channels are written as zeros
+
+
+@pytest.mark.parametrize("ct", [2, 4])
+@pytest.mark.parametrize("B,T,H,W,cin,cout,k,stride,act,res,y_f32,affine", [
+    (1, 1, 1, 1000, 136, 200, (1, 1, 1), (1, 1, 1), L.ACT_RELU, True, False, True),     # ragged M, N and K tails
+    (8, 1, 1, 785, 768, 768, (1, 1, 1), (1, 1, 1), L.ACT_NONE, True, True, False),      # MViT proj: fp32 stream in / out
+    (2, 1, 1, 3137, 384, 1536, (1, 1, 1), (1, 1, 1), L.ACT_GELU, False, False, False),  # MViT fc1
+    (1, 1, 1, 70000, 96, 120, (1, 1, 1), (1, 1, 1), L.ACT_NONE, False, False, False),   # > 256 tiles: several tiles per
+                                                                                         # workgroup, shortest K (3 stages)
+    (2, 8, 10, 10, 64, 96, (3, 1, 1), (1, 1, 1), L.ACT_RELU, False, False, True),       # SlowFast conv_a (3,1,1)
+    (2, 4, 17, 13, 32, 136, (1, 3, 3), (1, 2, 2), L.ACT_RELU, True, False, True),       # conv_b (1,3,3), stride 2, odd grid
+    (1, 32, 6, 6, 128, 256, (7, 1, 1), (4, 1, 1), L.ACT_RELU, False, False, True),      # lateral-shaped (7,1,1) / stride 4
+])
+def test_large_tile_gemm_kernel(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine):
+    _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine)

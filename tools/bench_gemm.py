@@ -75,8 +75,12 @@ def run(label, B, T, H, W, cin, cout, k, s, p, iters=20):
 
 
 if __name__ == "__main__":
-    sel = sys.argv[1:] 
-    print("route", os.environ.get("PV_CONV_ROUTE", "0"))
+    sel = [a for a in sys.argv[1:] if not a.startswith("--tune=")]
+    for a in sys.argv[1:]:
+        if a.startswith("--tune="):      # e.g. --tune=gemm8=0,conv_route=2
+            from pytorchvideo_amd.accelerator.mi355x import tuning
+            tuning.apply(a[len("--tune="):])
+            print("tune", a[len("--tune="):])
     for sh in SHAPES:
         if not sel or any(t in sh[0] for t in sel):
             run(*sh)
