@@ -384,6 +384,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the MViT-B 32x3 leg of the N=1 line")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained run")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the per-op profiling passes (rocprofv3 --pmc runs: only the replays are wanted)")
     ap.add_argument("--with-h2d", action="store_true",
                     help="also time steps that upload the (pinned) host input first; reported as pcie_inclusive, never as value")
     ap.add_argument("--dry-host", action="store_true", help="launcher check on the host (gloo, original-form model); no GPU")
@@ -415,11 +417,14 @@ def main():
                                        sustained_s=0.0 if args.no_sustained else 2.0)
     batch = res["per_gpu_batch"]
     pcie = pcie_leg(model, x, step, batch, args.steps, device) if (args.with_h2d and not hasattr(model, "parts")) else None
-    roof, prof, agg = roofline_of(roofline_session(model, args.workload, batch, device, args), args.workload,
-                                  res["value"] / world, res["ms_per_step"])
+    if args.no_roofline:
+        roof, prof, agg = None, [], {}
+    else:
+        roof, prof, agg = roofline_of(roofline_session(model, args.workload, batch, device, args), args.workload,
+                                      res["value"] / world, res["ms_per_step"])
 
     secondary = None
-    if world == 1 and not args.no_secondary and args.workload == "x3d_m" and not args.batch:
+    if world == 1 and not args.no_secondary and not args.no_roofline and args.workload == "x3d_m" and not args.batch:
         del model, x, step
         torch.cuda.empty_cache()
         r2, m2, x2, _ = run_workload("mvit_b_32x3", args, 1, 0, device, max(10, args.steps // 2), 3, sustained_s=0.0)

@@ -1,0 +1,91 @@
+"""Fold the PMC passes of tools/gpu_evidence.sh into one markdown table per workload (runs on the GPU box).
+
+    python tools/summarize_evidence.py <workload> <scratch dir with fetch/write/sq passes> <per_op.txt>
+
+Per kernel symbol (top by time): dispatches per replay, average duration (kernel trace of the SQ pass), HBM bytes
+per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (separate passes; gfx950 reports half of the bytes of wide
+coalesced reads, /opt/skills/guides/MI355X_MICROARCH.md, HBM section), and from the SQ pass:
+  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)   (busy cycles are summed over SIMDs),
+  VALU issue share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES,
+  issue-stalled = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES  (quad-cycle counters of the same unit: ratios are exact).
+Also prints a JSON line `TRAFFIC {...}` with the per-family HBM bytes for profiles/traffic.json.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def short(name):
+    k = re.sub(r"\(anonymous namespace\)::", "", name)
+    k = re.sub(r"^void ", "", k)
+    k = re.sub(r"_ZN12_GLOBAL__N_1\d+", "", k)
+    return re.sub(r"\(pv_.*", "", k)[:52]
+
+
+def counters(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(set)
+    for row in csv.DictReader(open(path)):
+        k = short(row["Kernel_Name"])
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        n[k].add(row["Dispatch_Id"])
+    return agg, {k: len(v) for k, v in n.items()}
+
+
+def find(d, pat):
+    f = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return f[0] if f else None
+
+
+FAMILIES = {   # op family of bench.py's roofline object -> kernel symbols behind it
+    "x3d_m": {"conv_c": r"pw_stream_kernel<\d, \d, (true|false), \d+, false, (true|false)>|conv_igemm", "conv_ab": r"pwdw_plane_kernel",
+              "conv_b": r"dw3_plane_kernel", "stem.conv01": r"stem_c4_dwt_kernel"},
+    "mvit_b_32x3": {"attn.core": r"attn_kernel", "gemm": r"gemm_glds_kernel", "layernorm": r"layernorm", "stream": r"pw_stream_kernel"},
+    "slowfast_r50": {"conv_a": r"gemm_glds_kernel<false|pw_stream_kernel|conv_igemm", "gemm": r"gemm_glds_kernel", "stem.conv": r"stem_c4_kernel",
+                     "lateral_fuse": r"lateral_fuse_kernel"},
+}
+
+
+def main():
+    wl, d = sys.argv[1], sys.argv[2]
+    fetch, nf = counters(find(d, "fetch_counter_collection.csv"))
+    write, nw = counters(find(d, "write_counter_collection.csv"))
+    sq, ns = counters(find(d, "sq_counter_collection.csv"))
+    dur = collections.defaultdict(list)
+    for row in csv.DictReader(open(find(d, "sq_kernel_trace.csv"))):
+        dur[short(row["Kernel_Name"])].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)
+    tot = {k: sum(v) for k, v in dur.items()}
+    print("### %s  (bench.py --streams 1, replays only; %d kernel symbols)\n" % (wl, len(tot)))
+    print("| kernel | dispatches | avg us (PMC pass) | HBM MB / launch (2F+W) | MFMA util | VALU issue | parked (WAIT_ANY) | issue-stalled |")
+    print("|---|---|---|---|---|---|---|---|")
+    for k in sorted(tot, key=lambda k: -tot[k])[:14]:
+        c = sq.get(k, {})
+        wc = c.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+        mf = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024.0) if gui else 0.0
+        hb = (2.0 * fetch.get(k, {}).get("FETCH_SIZE", 0.0) / max(nf.get(k, 1), 1)
+              + write.get(k, {}).get("WRITE_SIZE", 0.0) / max(nw.get(k, 1), 1)) * 1024 / 1e6
+        print("| `%s` | %d | %.1f | %.1f | %.1f %% | %.0f %% | %.0f %% | %.0f %% |" % (
+            k, len(dur[k]), tot[k] / len(dur[k]), hb, 100 * mf, 100 * c.get("SQ_ACTIVE_INST_VALU", 0) / wc,
+            100 * c.get("SQ_WAIT_ANY", 0) / wc, 100 * c.get("SQ_WAIT_INST_ANY", 0) / wc))
+    traffic = {}
+    for label, rx in FAMILIES.get(wl, {}).items():
+        pat = re.compile(rx)
+        ks = [k for k in nf if pat.search(k)]
+        n1, n2 = sum(nf[k] for k in ks), sum(nw.get(k, 0) for k in ks)
+        if not n1 or not n2:
+            continue
+        fb = 2.0 * sum(fetch[k]["FETCH_SIZE"] for k in ks) * 1024 / n1
+        wb = sum(write[k]["WRITE_SIZE"] for k in ks if k in write) * 1024 / n2
+        traffic[label] = {"kernel_regex": rx, "dispatches_profiled": n1, "fetch_bytes_per_launch": round(fb),
+                          "write_bytes_per_launch": round(wb), "hbm_bytes_per_launch": round(fb + wb),
+                          "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, gfx950 FETCH_SIZE x2 correction"}
+    print("\nTRAFFIC " + json.dumps({wl: traffic}))
+
+
+if __name__ == "__main__":
+    main()
