@@ -257,7 +257,8 @@ class Session:
         lib = L.lib()
         n = len(self.ops)
         out = (C.c_float * n)()
-        L.check(lib.pv_plan_profile(self.plan, self._stream(), iters, out), "profile")
+        with torch.cuda.device(self.device):    # the session stays pinned to the device it was finalized on
+            L.check(lib.pv_plan_profile(self.plan, self._stream(), iters, out), "profile")
         return [(self.ops[i][3], self.ops[i][0], float(out[i]), self.ops[i][4], self.ops[i][5]) for i in range(n)]
 
     # ------------------------------------------------------------------ tensor views

@@ -247,6 +247,61 @@ __global__ __launch_bounds__(kThreads) void ingest_c4_kernel(const pv_layout_des
   *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(d.dst) + b * d.bs + sp * 4) = o;
 }
 
+// The same with EIGHT W-adjacent voxels per thread (the frame size is a multiple of 8 voxels and the source planes are
+// 16-byte aligned: every BASELINE geometry): per channel plane one 16-byte (bf16) / 8-byte (uint8) / 2 x 16-byte
+// (fp32) load instead of eight scalar ones, and 64 contiguous bytes stored -- the scalar kernel moves 2 bytes per
+// load instruction and reaches 2.6 TB/s (138 us for X3D-M's 32 clips, 3.8 % of its forward).
+template <typename S>
+__global__ __launch_bounds__(kThreads) void ingest_c4_vec8_kernel(const pv_layout_desc d, long ngroups) {
+  const long grp = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (grp >= ngroups) return;
+  const long HW = (long)d.H * d.W;
+  const long S3 = (long)d.T * HW;
+  const long vox = grp * 8;
+  const long b = vox / S3;
+  const long sp = vox - b * S3;          // multiple of 8, and so is HW: the eight voxels share frame t
+  const int t = (int)(sp / HW);
+  const long S3s = (long)(d.t_index ? d.src_T : d.T) * HW;
+  const long sps = (long)(d.t_index ? d.t_index[t] : t) * HW + (sp - (long)t * HW);
+  const S* src = static_cast<const S*>(d.src) + b * d.C * S3s + sps;
+  float f[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < d.C) {
+      const S* p = src + (long)j * S3s;
+      if constexpr (sizeof(S) == 2) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[j][i] = (float)v[i];
+      } else if constexpr (sizeof(S) == 4) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[j][i] = lo[i]; f[j][4 + i] = hi[i]; }
+      } else {
+        typedef unsigned char u8x8 __attribute__((ext_vector_type(8)));
+        const u8x8 v = *reinterpret_cast<const u8x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[j][i] = (float)v[i];
+      }
+      if (d.ch_scale) {
+        const float a = d.ch_scale[j], c = d.ch_shift ? d.ch_shift[j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[j][i] = f[j][i] * a + c;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[j][i] = 0.f;
+    }
+  }
+  bf16_t* dst = static_cast<bf16_t*>(d.dst) + b * d.bs + sp * 4;
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {     // two voxels = one 16-byte chunk of the first-layer layout
+    const bf16x8 o = {(bf16_t)f[0][i], (bf16_t)f[1][i], (bf16_t)f[2][i], (bf16_t)f[3][i],
+                      (bf16_t)f[0][i + 1], (bf16_t)f[1][i + 1], (bf16_t)f[2][i + 1], (bf16_t)f[3][i + 1]};
+    *reinterpret_cast<bf16x8*>(dst + i * 4) = o;
+  }
+}
+
 template <typename T, typename S>
 __global__ __launch_bounds__(kThreads) void egress_kernel(const pv_layout_desc d, long nvox) {
   const int CG = d.c_p / 8;
@@ -779,6 +834,18 @@ extern "C" int pv_ingest_ncdhw(const pv_layout_desc* d, pv_stream_t stream) {
     dim3 grid(blocks_for(nvox)), block(kThreads);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (d->t_index && d->src_T <= 0) return PV_ERR_INVALID;
+    const int esz = d->src_dtype == PV_F32 ? 4 : (d->src_dtype == PV_BF16 ? 2 : 1);
+    const long HW = (long)d->H * d->W;
+    if (HW % 8 == 0 && (HW * esz) % 16 == 0 && ((uintptr_t)d->src % 16) == 0 && ((uintptr_t)d->dst % 16) == 0 && d->bs % 8 == 0) {
+      const long ngroups = nvox / 8;
+      dim3 g8(blocks_for(ngroups));
+      if (d->src_dtype == PV_F32) hipLaunchKernelGGL(ingest_c4_vec8_kernel<float>, g8, block, 0, s, *d, ngroups);
+      else if (d->src_dtype == PV_BF16) hipLaunchKernelGGL(ingest_c4_vec8_kernel<bf16_t>, g8, block, 0, s, *d, ngroups);
+      else if (d->src_dtype == PV_U8) hipLaunchKernelGGL(ingest_c4_vec8_kernel<unsigned char>, g8, block, 0, s, *d, ngroups);
+      else return PV_ERR_UNSUPPORTED;
+      PV_LAUNCH_CHECK();
+      return PV_OK;
+    }
     if (d->src_dtype == PV_F32) hipLaunchKernelGGL(ingest_c4_kernel<float>, grid, block, 0, s, *d, nvox);
     else if (d->src_dtype == PV_BF16) hipLaunchKernelGGL(ingest_c4_kernel<bf16_t>, grid, block, 0, s, *d, nvox);
     else if (d->src_dtype == PV_U8) hipLaunchKernelGGL(ingest_c4_kernel<unsigned char>, grid, block, 0, s, *d, nvox);

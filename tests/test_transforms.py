@@ -54,12 +54,13 @@ def test_device_packer_rejects_models_that_were_not_converted_whole():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(9, 11), (8, 12)], ids=["odd_frame", "frame_of_8n_voxels"])   # scalar / 8-voxel-per-thread kernel
 @pytest.mark.parametrize("c4", [True, False])
-def test_ingest_fuses_frame_selection_scaling_and_normalisation(c4):
+def test_ingest_fuses_frame_selection_scaling_and_normalisation(c4, hw):
     """pv_ingest_ncdhw with t_index / ch_scale / ch_shift on uint8 frames against the host transforms."""
     from pytorchvideo_amd import _lib as L
     from gpu_util import call
-    B, T, H, W, Tout = 2, 16, 9, 11, 4
+    B, T, (H, W), Tout = 2, 16, hw, 4
     g = torch.Generator().manual_seed(5)
     clip = torch.randint(0, 256, (B, 3, T, H, W), generator=g, dtype=torch.uint8).cuda()
     mean, std = (0.45, 0.40, 0.50), (0.225, 0.25, 0.2)
