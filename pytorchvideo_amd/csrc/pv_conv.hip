@@ -20,6 +20,7 @@
 int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s);      // pv_pwconv.hip
 int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);  // pv_gemm.hip
 int pv_gemm8_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);      // pv_gemm8.hip
+int pv_tapstream_try(const pv_conv3d_desc& d, hipStream_t s);           // pv_lateral.hip
 int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s);                 // pv_stem.hip
 int pv_stem_dwt_supported(const pv_conv3d_desc& d);                     // pv_stem.hip
 int pv_pwconv_x2_supported(const pv_conv3d_desc& d);                    // pv_pwconv.hip
@@ -398,6 +399,10 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
         if (r != PV_ERR_UNSUPPORTED) return r;
       }
     }
+  }
+  if (d.dtype == PV_BF16 && !pw) {   // narrow dense convs (SlowFast's fast pathway, ...): the tap-streaming kernel
+    const int r = pv_tapstream_try(d, s);
+    if (r != PV_ERR_UNSUPPORTED) return r;
   }
   if (d.dtype == PV_BF16) return launch_conv<bf16_t>(d, pw, s);
   if (d.dtype == PV_F32) return launch_conv<float>(d, pw, s);

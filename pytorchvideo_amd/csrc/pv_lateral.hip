@@ -19,22 +19,39 @@
 //     slow tensor) does not exist;
 //   * each fast frame is needed by up to two slow frames (kt = 7, alpha = 4: 7 reads per 4 frames); tiles
 //     are ordered frame-major inside a clip, so the second use hits in L2 / Infinity Cache.
+//
+// The same streaming structure serves every NARROW dense convolution of the path -- SlowFast's fast pathway
+// (conv_a (3,1,1) and conv_b (1,3,3) on 8-64 channels), the narrow ends of CSN / R(2+1)D: K = taps x cin of a
+// few hundred, <= 128 output channels, 16-64 bytes per voxel.  Those are HBM streams as well (a c8 -> c8 1x3x3 layer
+// moves 67 MB for 10 GFLOP), which a 128-wide LDS-tiled GEMM serves at 0.75-1.8 TB/s; here the tap is a per-lane
+// (dt, dh, dw) offset with bounds tests instead of a frame offset only (pv_tapstream_try, called by pv_conv3d).
 #include "pv_common.h"
 
 namespace {
 
 constexpr int kLatThreads = 512;   // 8 waves share one filter slab
 
+struct TapConv {       // the convolution the kernel evaluates (a lateral connection is kh = kw = sh = sw = 1)
+  const void* x; const void* w; void* y;
+  const float* scale; const float* shift;
+  long x_bs, y_bs;
+  int ldx, ldy;
+  int B, Ti, Hi, Wi, cin;
+  int To, Ho, Wo, cout;
+  int kt, kh, kw, st, sh, sw, pt, ph, pw;
+  int act;
+};
+
 struct LatTile {
-  unsigned xoff;   // byte offset of x[b][alpha*to - pt][h][w][0] (may be "negative": wraps, fixed by the frame offset)
-  int t0;          // alpha*to - pt
-  unsigned yoff;   // byte offset of y[b][to][h][w][n0]
+  unsigned xoff;   // byte offset of x[b][t0][h0][w0][0] (may be "negative": wraps, fixed by the tap offset)
+  int t0, h0, w0;  // input coordinates of tap (0,0,0): stride * output coordinate - padding
+  unsigned yoff;   // byte offset of y[b][to][ho][wo][n0]
   bool ok;
 };
 
 // NT: 16-channel MFMA row tiles per workgroup (slab = NT * 16 output channels); TM: voxel tiles per wave tile
 template <int NT, int TM>
-__global__ __launch_bounds__(kLatThreads) void lateral_fuse_kernel(const pv_lateral_desc d, int ksteps, int ngroups,
+__global__ __launch_bounds__(kLatThreads) void lateral_fuse_kernel(const TapConv d, int ksteps, int ngroups,
                                                                    int nchunks, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int Kp = ksteps * 32;
@@ -42,7 +59,7 @@ __global__ __launch_bounds__(kLatThreads) void lateral_fuse_kernel(const pv_late
   bf16_t* w_s = reinterpret_cast<bf16_t*>(smem_raw);
   float* sc_s = reinterpret_cast<float*>(smem_raw + (size_t)NT * 16 * WLD * 2);
   float* sh_s = sc_s + NT * 16;
-  int2* tap_s = reinterpret_cast<int2*>(sh_s + NT * 16);   // [ksteps][4]: (frame delta, byte offset of the frame + channel)
+  int2* tap_s = reinterpret_cast<int2*>(sh_s + NT * 16);   // [ksteps][4]: (dt | dh << 8 | dw << 16, byte offset of tap + channel)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -50,8 +67,9 @@ __global__ __launch_bounds__(kLatThreads) void lateral_fuse_kernel(const pv_late
   const int n16 = lane & 15, q = lane >> 4;
   const int cin_p = d.cin;                 // multiple of 8
   const int cout_p8 = pv_round_up(d.cout, 8);
-  const int HW = d.H * d.W;
-  const long M = (long)d.B * d.To * HW;
+  const int HWo = d.Ho * d.Wo;
+  const long M = (long)d.B * d.To * HWo;
+  const int taps = d.kt * d.kh * d.kw;
   // the N splits of one voxel chunk are consecutive workgroups of one XCD: the activations are fetched from
   // HBM once and re-read from that XCD's L2 by the other splits
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -61,7 +79,7 @@ __global__ __launch_bounds__(kLatThreads) void lateral_fuse_kernel(const pv_late
   // ---- stage the filter slab (LDS row r = channel n0 + perm(r)), BN scale / shift, the tap table ----
   {
     const bf16_t* __restrict__ Wt = static_cast<const bf16_t*>(d.w);
-    const int K = d.kt * cin_p;
+    const int K = taps * cin_p;
     const int cpr = Kp / 8;
     for (int id = tid; id < NT * 16 * cpr; id += kLatThreads) {
       const int r = id / cpr, kc = id - r * cpr;
@@ -80,9 +98,12 @@ __global__ __launch_bounds__(kLatThreads) void lateral_fuse_kernel(const pv_late
     for (int i = tid; i < ksteps * 4; i += kLatThreads) {
       const int k = (i >> 2) * 32 + (i & 3) * 8;
       const int tap = k / cin_p, c = k - tap * cin_p;
-      // taps past kt (the zero-padded tail of the last K step) get a frame delta that is always outside the clip
-      tap_s[i] = tap < d.kt ? int2{tap, (int)(((unsigned)tap * (unsigned)HW * (unsigned)d.ldx + (unsigned)c) * 2u)}
-                            : int2{1 << 28, 0};
+      const int dt = tap / (d.kh * d.kw), r2 = tap - dt * d.kh * d.kw, dh = r2 / d.kw, dw = r2 - dh * d.kw;
+      // taps past the last one (the zero-padded tail of the last K step) are marked invalid
+      tap_s[i] = tap < taps ? int2{dt | (dh << 8) | (dw << 16),
+                                   (int)((((unsigned)dt * (unsigned)d.Hi + (unsigned)dh) * (unsigned)d.Wi + (unsigned)dw) *
+                                             (unsigned)d.ldx * 2u + (unsigned)c * 2u)}
+                            : int2{-1, 0};
     }
   }
   __syncthreads();
@@ -104,19 +125,23 @@ __global__ __launch_bounds__(kLatThreads) void lateral_fuse_kernel(const pv_late
       const long m = m_base + i * 16 + n16;
       const bool ok = g < ngroups && m < M;
       const unsigned mm = ok ? (unsigned)m : 0u;
-      const unsigned bt = mm / (unsigned)HW, hw = mm - bt * (unsigned)HW;   // bt = b * To + to
+      const unsigned bt = mm / (unsigned)HWo, hw = mm - bt * (unsigned)HWo;   // bt = b * To + to
       const unsigned b = bt / (unsigned)d.To, to = bt - b * (unsigned)d.To;
+      const unsigned ho = hw / (unsigned)d.Wo, wo = hw - ho * (unsigned)d.Wo;
       t[i].ok = ok;
       t[i].t0 = (int)to * d.st - d.pt;
-      t[i].xoff = (unsigned)((long)b * d.x_bs + ((long)t[i].t0 * HW + hw) * d.ldx) * 2u;
-      t[i].yoff = (unsigned)((long)b * d.y_bs + ((long)to * HW + hw) * d.ldy + n0) * 2u;
+      t[i].h0 = (int)ho * d.sh - d.ph;
+      t[i].w0 = (int)wo * d.sw - d.pw;
+      t[i].xoff = (unsigned)((long)b * d.x_bs + (((long)t[i].t0 * d.Hi + t[i].h0) * d.Wi + t[i].w0) * d.ldx) * 2u;
+      t[i].yoff = (unsigned)((long)b * d.y_bs + ((long)to * HWo + hw) * d.ldy + n0) * 2u;
     }
   };
   auto load_x = [&](u32x4 (&dst)[TM], const LatTile (&t)[TM], int ks) {
     const int2 tp = tap_s[ks * 4 + q];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const bool ok = t[i].ok && (unsigned)(t[i].t0 + tp.x) < (unsigned)d.Ti;
+      const bool ok = t[i].ok && tp.x >= 0 && (unsigned)(t[i].t0 + (tp.x & 255)) < (unsigned)d.Ti &&
+                      (unsigned)(t[i].h0 + ((tp.x >> 8) & 255)) < (unsigned)d.Hi && (unsigned)(t[i].w0 + (tp.x >> 16)) < (unsigned)d.Wi;
       dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? t[i].xoff + (unsigned)tp.y : kOOB), 0, 0);
     }
   };
@@ -185,8 +210,8 @@ __global__ __launch_bounds__(kLatThreads) void lateral_fuse_kernel(const pv_late
 }
 
 template <int NT, int TM>
-int launch_lateral(const pv_lateral_desc& d, int ksteps, size_t lds, hipStream_t s) {
-  const long M = (long)d.B * d.To * d.H * d.W;
+int launch_lateral(const TapConv& d, int ksteps, size_t lds, hipStream_t s) {
+  const long M = (long)d.B * d.To * d.Ho * d.Wo;
   const long ngroups = pv_ceil_div(M, (kLatThreads / 64) * TM * 16);
   const int nsplit = (int)pv_ceil_div(pv_round_up(d.cout, 8), NT * 16);
   auto kern = lateral_fuse_kernel<NT, TM>;
@@ -203,41 +228,75 @@ int launch_lateral(const pv_lateral_desc& d, int ksteps, size_t lds, hipStream_t
   return PV_OK;
 }
 
-}  // namespace
-
-extern "C" int pv_lateral_fuse(const pv_lateral_desc* dp, pv_stream_t stream) {
-  if (!dp) return PV_ERR_INVALID;
-  const pv_lateral_desc& d = *dp;
-  if (!d.x || !d.w || !d.y) return PV_ERR_INVALID;
-  if (d.B <= 0 || d.Ti <= 0 || d.H <= 0 || d.W <= 0 || d.cin <= 0 || d.cout <= 0 || d.To <= 0) return PV_ERR_INVALID;
-  if (d.kt < 1 || d.st < 1 || d.pt < 0 || d.cin % 8 || d.ldx % 8 || d.ldy % 8 || d.x_bs % 8 || d.y_bs % 8) return PV_ERR_INVALID;
-  if ((d.Ti + 2 * d.pt - d.kt) / d.st + 1 != d.To || d.ldx < d.cin || d.ldy < pv_round_up(d.cout, 8)) return PV_ERR_INVALID;
-  hipStream_t s = static_cast<hipStream_t>(stream);
+// PV_OK: launched; PV_ERR_UNSUPPORTED: not a geometry of the streaming kernel (nothing launched)
+int tapstream_launch(const TapConv& d, int k_limit, hipStream_t s) {
+  const int taps = d.kt * d.kh * d.kw;
+  const long K = (long)taps * d.cin;
+  if (K > k_limit || d.kt > 255 || d.kh > 255 || d.kw > 255) return PV_ERR_UNSUPPORTED;
   const int cout_p8 = pv_round_up(d.cout, 8);
-  const int ksteps = (d.kt * d.cin + 31) / 32;
+  const int ksteps = (int)((K + 31) / 32);
   const bool small_offsets = (long)d.B * d.x_bs * 2 <= 0x7fffffffL && (long)d.B * d.y_bs * 2 <= 0x7fffffffL &&
-                             (long)d.B * d.To * d.H * d.W <= 0x7fffffffL;
+                             (long)d.B * d.To * d.Ho * d.Wo <= 0x7fffffffL;
+  if (!small_offsets) return PV_ERR_UNSUPPORTED;
   int nt = cout_p8 <= 32 ? 2 : (cout_p8 <= 64 ? 4 : 8);
   auto lds_of = [&](int t) { return (size_t)t * 16 * (ksteps * 32 + 8) * 2 + (size_t)2 * t * 16 * 4 + (size_t)ksteps * 4 * 8; };
   while (nt > 2 && lds_of(nt) > 120 * 1024) nt >>= 1;
-  // Where the op stops being a stream: K = kt * cin >= 448 (SlowFast-R50's 64 -> 128 and 128 -> 256 sites, 150-300
-  // FLOP/B) is MFMA work whose operands want full 128-byte lines staged through LDS; measured on the R50 sites
-  // (16 clips, same box): streaming kernel 26 / 61 / 60 / 59 us, LDS-DMA implicit GEMM 38 / 87 / 53 / 41 us.
-  const bool stream_shaped = d.kt * d.cin <= 256;
-  if (d.dtype != PV_BF16 || !small_offsets || !stream_shaped || lds_of(nt) > 120 * 1024) {
-    // fp32 parity mode, MFMA-bound widths and geometries outside the streaming kernel's range: the same arithmetic
-    // as a (kt,1,1) convolution through the dense-conv entry point -- still the HIP library, never a host path
-    pv_conv3d_desc c = {};
-    c.x = d.x; c.w = d.w; c.y = d.y; c.scale = d.scale; c.shift = d.shift;
-    c.x_bs = d.x_bs; c.y_bs = d.y_bs; c.ldx = d.ldx; c.ldy = d.ldy;
-    c.B = d.B; c.Ti = d.Ti; c.Hi = d.H; c.Wi = d.W; c.cin = d.cin;
-    c.To = d.To; c.Ho = d.H; c.Wo = d.W; c.cout = d.cout;
-    c.kt = d.kt; c.kh = 1; c.kw = 1; c.st = d.st; c.sh = 1; c.sw = 1; c.pt = d.pt;
-    c.act = d.act; c.dtype = d.dtype;
-    return pv_conv3d(&c, stream);
-  }
+  if (lds_of(nt) > 120 * 1024) return PV_ERR_UNSUPPORTED;
   const size_t lds = lds_of(nt);
   if (nt == 2) return launch_lateral<2, 2>(d, ksteps, lds, s);
   if (nt == 4) return launch_lateral<4, 2>(d, ksteps, lds, s);
   return launch_lateral<8, 1>(d, ksteps, lds, s);
+}
+
+}  // namespace
+
+// Narrow dense convolutions of pv_conv3d (called before its generic kernel): bf16, no residual / gate / second operand,
+// no dilation, <= 128 output channels, K = taps * cin <= 640.  Returns PV_ERR_UNSUPPORTED for everything else.
+int pv_tapstream_try(const pv_conv3d_desc& c, hipStream_t s) {
+  if (c.dtype != PV_BF16 || c.y_f32 || c.residual || c.a_gate || c.a_act != PV_ACT_NONE || c.x2 || c.dwt_w || c.pos_spatial)
+    return PV_ERR_UNSUPPORTED;
+  if (c.dil_t > 1 || c.dil_h > 1 || c.dil_w > 1 || c.cin % 8 || pv_round_up(c.cout, 8) > 128) return PV_ERR_UNSUPPORTED;
+  if (!pv_tune("tapstream", 1)) return PV_ERR_UNSUPPORTED;
+  TapConv d;
+  d.x = c.x; d.w = c.w; d.y = c.y; d.scale = c.scale; d.shift = c.shift;
+  d.x_bs = c.x_bs; d.y_bs = c.y_bs; d.ldx = c.ldx; d.ldy = c.ldy;
+  d.B = c.B; d.Ti = c.Ti; d.Hi = c.Hi; d.Wi = c.Wi; d.cin = c.cin;
+  d.To = c.To; d.Ho = c.Ho; d.Wo = c.Wo; d.cout = c.cout;
+  d.kt = c.kt; d.kh = c.kh; d.kw = c.kw; d.st = c.st; d.sh = c.sh; d.sw = c.sw; d.pt = c.pt; d.ph = c.ph; d.pw = c.pw;
+  d.act = c.act;
+  return tapstream_launch(d, 640, s);
+}
+
+extern "C" int pv_lateral_fuse(const pv_lateral_desc* dp, pv_stream_t stream) {
+  if (!dp) return PV_ERR_INVALID;
+  const pv_lateral_desc& l = *dp;
+  if (!l.x || !l.w || !l.y) return PV_ERR_INVALID;
+  if (l.B <= 0 || l.Ti <= 0 || l.H <= 0 || l.W <= 0 || l.cin <= 0 || l.cout <= 0 || l.To <= 0) return PV_ERR_INVALID;
+  if (l.kt < 1 || l.st < 1 || l.pt < 0 || l.cin % 8 || l.ldx % 8 || l.ldy % 8 || l.x_bs % 8 || l.y_bs % 8) return PV_ERR_INVALID;
+  if ((l.Ti + 2 * l.pt - l.kt) / l.st + 1 != l.To || l.ldx < l.cin || l.ldy < pv_round_up(l.cout, 8)) return PV_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // Where the op stops being a stream: K = kt * cin >= 448 (SlowFast-R50's 64 -> 128 and 128 -> 256 sites, 150-300
+  // FLOP/B) is MFMA work whose operands want full 128-byte lines staged through LDS; measured on the R50 sites
+  // (16 clips, same box): streaming kernel 26 / 61 / 60 / 59 us, LDS-DMA implicit GEMM 38 / 87 / 53 / 41 us.
+  if (l.dtype == PV_BF16) {
+    TapConv d;
+    d.x = l.x; d.w = l.w; d.y = l.y; d.scale = l.scale; d.shift = l.shift;
+    d.x_bs = l.x_bs; d.y_bs = l.y_bs; d.ldx = l.ldx; d.ldy = l.ldy;
+    d.B = l.B; d.Ti = l.Ti; d.Hi = l.H; d.Wi = l.W; d.cin = l.cin;
+    d.To = l.To; d.Ho = l.H; d.Wo = l.W; d.cout = l.cout;
+    d.kt = l.kt; d.kh = 1; d.kw = 1; d.st = l.st; d.sh = 1; d.sw = 1; d.pt = l.pt; d.ph = 0; d.pw = 0;
+    d.act = l.act;
+    const int r = tapstream_launch(d, 256, s);
+    if (r != PV_ERR_UNSUPPORTED) return r;
+  }
+  // fp32 parity mode, MFMA-bound widths and geometries outside the streaming kernel's range: the same arithmetic
+  // as a (kt,1,1) convolution through the dense-conv entry point -- still the HIP library, never a host path
+  pv_conv3d_desc c = {};
+  c.x = l.x; c.w = l.w; c.y = l.y; c.scale = l.scale; c.shift = l.shift;
+  c.x_bs = l.x_bs; c.y_bs = l.y_bs; c.ldx = l.ldx; c.ldy = l.ldy;
+  c.B = l.B; c.Ti = l.Ti; c.Hi = l.H; c.Wi = l.W; c.cin = l.cin;
+  c.To = l.To; c.Ho = l.H; c.Wo = l.W; c.cout = l.cout;
+  c.kt = l.kt; c.kh = 1; c.kw = 1; c.st = l.st; c.sh = 1; c.sw = 1; c.pt = l.pt;
+  c.act = l.act; c.dtype = l.dtype;
+  return pv_conv3d(&c, stream);
 }

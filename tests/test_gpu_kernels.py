@@ -753,3 +753,52 @@ def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine):
 ])
 def test_large_tile_gemm_kernel(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine):
     _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine)
+
+
+@pytest.mark.parametrize("B,T,H,W,cin,cout,k,stride", [
+    (2, 8, 16, 16, 8, 8, (1, 3, 3), (1, 1, 1)),      # SlowFast fast pathway res2 conv_b: 16 bytes per voxel
+    (2, 8, 16, 16, 32, 8, (3, 1, 1), (1, 1, 1)),     # ... conv_a (3,1,1)
+    (1, 6, 17, 13, 16, 16, (1, 3, 3), (1, 2, 2)),    # stride 2, odd grid
+    (2, 5, 9, 7, 64, 32, (3, 1, 1), (1, 1, 1)),      # res4 fast conv_a
+    (1, 4, 10, 12, 24, 40, (3, 3, 3), (2, 1, 2)),    # every tap direction at once, temporal stride, ragged widths
+    (1, 3, 6, 6, 128, 32, (3, 1, 1), (1, 1, 1)),     # wide input, narrow output
+])
+def test_narrow_dense_conv_on_the_tap_streaming_kernel(B, T, H, W, cin, cout, k, stride):
+    """pv_conv3d for narrow dense convolutions (csrc/pv_lateral.hip, pv_tapstream_try) vs torch, and the same op with
+    the kernel switched off (generic implicit GEMM) to the last bit of bf16."""
+    dtype = torch.bfloat16
+    pad = tuple(kk // 2 for kk in k)
+    g = torch.Generator().manual_seed(3 * cin + cout)
+    cin_p = (cin + 7) // 8 * 8
+    x = torch.zeros(B, T, H, W, cin_p)
+    x[..., :cin] = torch.randn(B, T, H, W, cin, generator=g)
+    x = x.to(dtype).cuda()
+    w = (torch.randn((cout, cin) + k, generator=g) * (cin * k[0] * k[1] * k[2]) ** -0.5).to(dtype)
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.rand(cout, generator=g) - 0.5).cuda()
+    want = F.conv3d(x[..., :cin].float().cpu().permute(0, 4, 1, 2, 3), w.float(), stride=stride, padding=pad)
+    want = F.relu(want * scale.cpu().view(1, -1, 1, 1, 1) + shift.cpu().view(1, -1, 1, 1, 1))
+    To, Ho, Wo = want.shape[2:]
+    cp = (cout + 7) // 8 * 8
+    wp = torch.zeros(cout, k[0] * k[1] * k[2], cin_p, dtype=dtype)
+    wp[:, :, :cin] = w.permute(0, 2, 3, 4, 1).reshape(cout, -1, cin)
+    wp = wp.cuda()
+
+    def run(tap):
+        y = torch.full((B, To, Ho, Wo, cp), 5.0, dtype=dtype, device="cuda")
+        d = L.Conv3dDesc()
+        d.x, d.w, d.y, d.scale, d.shift = x.data_ptr(), wp.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr()
+        d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * cin_p, To * Ho * Wo * cp, cin_p, cp
+        d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, cin_p, To, Ho, Wo, cout
+        d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *stride, *pad)
+        d.act, d.a_act, d.dtype = L.ACT_RELU, L.ACT_NONE, L.PV_BF16
+        L.tune(tapstream=tap)
+        try:
+            call("pv_conv3d", d)
+        finally:
+            L.tune(tapstream=1)
+        return y
+
+    y1, y0 = run(1), run(0)
+    assert rel_err(y1[..., :cout].permute(0, 4, 1, 2, 3), want) <= 1e-2
+    assert torch.all(y1[..., cout:] == 0)
+    assert rel_err(y1, y0) <= 4e-3      # the generic kernel: same products, other summation order
