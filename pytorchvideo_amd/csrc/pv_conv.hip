@@ -389,6 +389,12 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
       // the 128-channel LDS-DMA tile wastes the matrix core on narrow outputs, and per-chunk tap
       // decoding dominates when a tap is only 8 channels wide (RGB stems): those stay on the
       // generic register-staged kernel
+      // a 64-channel output fills half of the GEMM's 128-channel tile; with a short reduction (K <= 640) the
+      // tap-streaming kernel (whole filter in LDS, operands straight into MFMA registers) takes those first
+      if (!pw && cout_p8 <= 64 && (long)taps * d.cin <= 640 && pv_tune("tapstream_first", 1)) {
+        const int r = pv_tapstream_try(d, s);
+        if (r != PV_ERR_UNSUPPORTED) return r;
+      }
       const bool gemm_ok = route == 2 || pw || (cout_p8 >= 64 && d.cin >= 64);
       int r = gemm_ok ? pv_gemm8_try(d, pw, s) : PV_ERR_UNSUPPORTED;     // large tiles, 4-stage ring: big layers
       if (r != PV_ERR_UNSUPPORTED) return r;

@@ -762,6 +762,7 @@ def test_large_tile_gemm_kernel(ct, B, T, H, W, cin, cout, k, stride, act, res, 
     (2, 5, 9, 7, 64, 32, (3, 1, 1), (1, 1, 1)),      # res4 fast conv_a
     (1, 4, 10, 12, 24, 40, (3, 3, 3), (2, 1, 2)),    # every tap direction at once, temporal stride, ragged widths
     (1, 3, 6, 6, 128, 32, (3, 1, 1), (1, 1, 1)),     # wide input, narrow output
+    (2, 3, 12, 12, 64, 64, (1, 3, 3), (1, 1, 1)),    # SlowFast / ResNet res2 conv_b: taken BEFORE the 128-wide GEMM
 ])
 def test_narrow_dense_conv_on_the_tap_streaming_kernel(B, T, H, W, cin, cout, k, stride):
     """pv_conv3d for narrow dense convolutions (csrc/pv_lateral.hip, pv_tapstream_try) vs torch, and the same op with
@@ -791,11 +792,11 @@ def test_narrow_dense_conv_on_the_tap_streaming_kernel(B, T, H, W, cin, cout, k,
         d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, cin_p, To, Ho, Wo, cout
         d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *stride, *pad)
         d.act, d.a_act, d.dtype = L.ACT_RELU, L.ACT_NONE, L.PV_BF16
-        L.tune(tapstream=tap)
+        L.tune(tapstream=tap, tapstream_first=tap)
         try:
             call("pv_conv3d", d)
         finally:
-            L.tune(tapstream=1)
+            L.tune(tapstream=1, tapstream_first=1)
         return y
 
     y1, y0 = run(1), run(0)
