@@ -451,8 +451,9 @@ int pv_gemm8_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
     // tiles take only what fills >= 4 rounds of them; everything else stays on the 128 x 128 kernel.
     const long t256 = tiles_m * pv_ceil_div(cout_p8, 256), t128 = tiles_m * pv_ceil_div(cout_p8, 128);
     const double waste256 = (double)(pv_ceil_div(cout_p8, 256) * 256 - cout_p8) / (double)cout_p8;
+    const double waste128 = (double)(pv_ceil_div(cout_p8, 128) * 128 - cout_p8) / (double)cout_p8;
     if (K >= 1024 && waste256 <= 0.15 && t256 >= 1024) ct = 4;
-    else if (K >= 256 && t128 >= 2048) ct = 2;
+    else if (K >= 256 && waste128 <= 0.15 && t128 >= 2048) ct = 2;   // (SlowFast's 256 -> 64 conv_a: 117 vs 100 us here)
     else return PV_ERR_UNSUPPORTED;
   }
   const int tiles_n = (int)pv_ceil_div(cout_p8, 64 * ct);

@@ -51,7 +51,7 @@ struct LatTile {
 
 // NT: 16-channel MFMA row tiles per workgroup (slab = NT * 16 output channels); TM: voxel tiles per wave tile
 template <int NT, int TM>
-__global__ __launch_bounds__(kLatThreads) void lateral_fuse_kernel(const TapConv d, int ksteps, int ngroups,
+__global__ __launch_bounds__(kLatThreads) void tap_stream_kernel(const TapConv d, int ksteps, int ngroups,
                                                                    int nchunks, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int Kp = ksteps * 32;
@@ -214,7 +214,7 @@ int launch_lateral(const TapConv& d, int ksteps, size_t lds, hipStream_t s) {
   const long M = (long)d.B * d.To * d.Ho * d.Wo;
   const long ngroups = pv_ceil_div(M, (kLatThreads / 64) * TM * 16);
   const int nsplit = (int)pv_ceil_div(pv_round_up(d.cout, 8), NT * 16);
-  auto kern = lateral_fuse_kernel<NT, TM>;
+  auto kern = tap_stream_kernel<NT, TM>;
   if (lds > 64 * 1024)
     PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // one resident generation of workgroups; the rest is the grid-stride loop (the slab is staged once per workgroup)

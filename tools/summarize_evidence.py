@@ -5,7 +5,9 @@
 Per kernel symbol (top by time): dispatches per replay, average duration (kernel trace of the SQ pass), HBM bytes
 per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (separate passes; gfx950 reports half of the bytes of wide
 coalesced reads, /opt/skills/guides/MI355X_MICROARCH.md, HBM section), and from the SQ pass:
-  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)   (busy cycles are summed over SIMDs),
+  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs): busy cycles are summed over the
+  1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (calibrated on a 32768 x 4096 x 4096 GEMM: 33.5 M MFMAs x 32 cycles
+  against its measured 961 TFLOP/s = 38 % of 2.5 PFLOP/s),
   VALU issue share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES,
   issue-stalled = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES  (quad-cycle counters of the same unit: ratios are exact).
 Also prints a JSON line `TRAFFIC {...}` with the per-family HBM bytes for profiles/traffic.json.
@@ -46,7 +48,7 @@ FAMILIES = {   # op family of bench.py's roofline object -> kernel symbols behin
               "conv_b": r"dw3_plane_kernel", "stem.conv01": r"stem_c4_dwt_kernel"},
     "mvit_b_32x3": {"attn.core": r"attn_kernel", "gemm": r"gemm_glds_kernel", "layernorm": r"layernorm", "stream": r"pw_stream_kernel"},
     "slowfast_r50": {"conv_a": r"gemm_glds_kernel<false|pw_stream_kernel|conv_igemm", "gemm": r"gemm_glds_kernel", "stem.conv": r"stem_c4_kernel",
-                     "lateral_fuse": r"lateral_fuse_kernel"},
+                     "narrow+lateral": r"tap_stream_kernel"},
 }
 
 
@@ -66,7 +68,7 @@ def main():
         c = sq.get(k, {})
         wc = c.get("SQ_WAVE_CYCLES", 0.0) or 1.0
         gui = c.get("GRBM_GUI_ACTIVE", 0.0)
-        mf = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024.0) if gui else 0.0
+        mf = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8.0 * 1024.0) if gui else 0.0
         hb = (2.0 * fetch.get(k, {}).get("FETCH_SIZE", 0.0) / max(nf.get(k, 1), 1)
               + write.get(k, {}).get("WRITE_SIZE", 0.0) / max(nw.get(k, 1), 1)) * 1024 / 1e6
         print("| `%s` | %d | %.1f | %.1f | %.1f %% | %.0f %% | %.0f %% | %.0f %% |" % (
