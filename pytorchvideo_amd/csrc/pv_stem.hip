@@ -224,6 +224,248 @@ template <int NT, int TM, int JP = 1> int launch_stem(const pv_conv3d_desc& d, i
 
 
 // ---------------------------------------------------------------------------------------
+// 7 x 7 / stride-2 stems with the input tile in LDS: SlowFast's slow (1,7,7) and fast (5,7,7) stems
+// (models/slowfast.py:209-229 -> models/stem.py:80-107).
+//
+// The kernel above gathers every MFMA B operand straight from global memory: 2.2 KB of window per output voxel of
+// the (5,7,7) stem go through L1 / the texture addresser (PMC: 554 MB of HBM traffic against 369 MB algorithmic,
+// 18.6 k VALU instructions per wave, most of them address arithmetic) -- 0.79 ms for 99 GFLOP.  Here a workgroup
+// owns an 8 x 32 output tile of one clip and walks the T axis:
+//   * each input frame's halo tile (21 x 70 voxels x 8 bytes) is staged into LDS ONCE and stays in a ring of kt + 1
+//     frames: the 5 temporal taps re-read LDS, not memory; the next frame's loads are in flight during the MFMAs;
+//   * with kw = 7 padded to 8, one (dt, dh) row of the window is exactly one K step of 32: lane (n, q) reads ONE
+//     aligned 16-byte chunk (voxel pair q of output column n) with a compile-time LDS offset -- no tap table, no
+//     bounds tests (the halo is zero-filled at staging time);
+//   * the filter is held in LDS as ready-made A fragments (lane-linear 1 KB each: conflict-free ds_read_b128);
+//   * <= 8 output channels (fast stem): the 16 MFMA rows are 8 channels x TWO vertically adjacent outputs -- input
+//     row r of a row pair feeds output row h with dh = r and output row h+1 with dh = r - 2 -- so no half of the
+//     instruction is idle; 64 channels (slow stem): 4 channel tiles share every B fragment.
+template <int RP, int NT, int TM>
+__global__ __launch_bounds__(kThreads) void stem7_kernel(const pv_conv3d_desc d, int tiles_h, int tiles_w, int wpitch) {
+  constexpr int TH = 8, TW = TM * 16;
+  constexpr int IH = (TH - 1) * 2 + 7;       // 21 input rows
+  constexpr int IW = (TW - 1) * 2 + 8;       // 70 input columns (even: 16-byte chunks = voxel pairs)
+  constexpr int NVOX = IH * IW;
+  constexpr int FRAME = NVOX * 4;            // bf16 elements per staged frame
+  constexpr int NLD = (NVOX + kThreads - 1) / kThreads;
+  constexpr int JR = RP == 2 ? 9 : 7;        // A fragments per temporal tap (row offsets of a row pair / dh)
+  constexpr int NA = RP == 2 ? 1 : NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* wf_s = reinterpret_cast<bf16_t*>(smem_raw);               // [kt][JR][NA][64 lanes][8]
+  const int nfrag = d.kt * JR * NA;
+  bf16_t* ring = wf_s + (size_t)nfrag * 512;                         // [kt + 1][IH][IW][4]
+  const int nslot = d.kt + 1;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, q = lane >> 4;
+  const int tw = blockIdx.x % tiles_w;
+  const int th = (blockIdx.x / tiles_w) % tiles_h;
+  const int b = blockIdx.x / (tiles_w * tiles_h);
+  const int ho0 = th * TH, wo0 = tw * TW;
+  const int hi0 = ho0 * 2 - 3, wi0 = wo0 * 2 - 3;
+  const int cout_p8 = pv_round_up(d.cout, 8);
+
+  // ---- filter -> A fragments ----
+  {
+    const bf16_t* __restrict__ Wt = static_cast<const bf16_t*>(d.w);
+    const long Kh = (long)d.kt * 7 * wpitch;     // elements per filter row as the host packed it
+    for (int id = tid; id < nfrag * 64; id += kThreads) {
+      const int f = id >> 6, l = id & 63;
+      const int r = l & 15, qq = l >> 4;
+      const int a = f % NA, j = (f / NA) % JR, dt = f / (NA * JR);
+      int ch, dh;
+      if (RP == 2) { ch = r & 7; dh = j - 2 * (r >> 3); }
+      else { ch = a * 16 + r; dh = j; }
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ch < d.cout && dh >= 0 && dh < 7)
+        v = *reinterpret_cast<const bf16x8*>(Wt + (long)ch * Kh + (long)(dt * 7 + dh) * wpitch + qq * 8);
+      *reinterpret_cast<bf16x8*>(wf_s + (size_t)id * 8) = v;
+    }
+  }
+
+  // ---- staging geometry: thread -> voxels of the halo tile (fixed for the whole clip) ----
+  constexpr unsigned kOOB = 0x80000000u;
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const bf16_t* X = static_cast<const bf16_t*>(d.x) + (long)b * d.x_bs;
+  const unsigned frame_bytes = (unsigned)(d.Hi * d.Wi) * 8u;
+  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)(frame_bytes * (unsigned)d.Ti), 0x00020000);
+  unsigned g_off[NLD];
+#pragma unroll
+  for (int n = 0; n < NLD; ++n) {
+    const int i = tid + n * kThreads;
+    const int ir = i / IW, ic = i - ir * IW;
+    const int hi = hi0 + ir, wi = wi0 + ic;
+    const bool ok = i < NVOX && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
+    g_off[n] = ok ? (unsigned)(hi * d.Wi + wi) * 8u : kOOB;
+  }
+  u32x2 st[NLD];
+  auto load_frame = [&](int ti) {
+    const bool live = (unsigned)ti < (unsigned)d.Ti;   // frames outside the clip are the conv's temporal zero padding
+#pragma unroll
+    for (int n = 0; n < NLD; ++n)
+      st[n] = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)((live && g_off[n] != kOOB) ? g_off[n] + (unsigned)ti * frame_bytes : kOOB), 0, 0);
+  };
+  auto slot_of = [&](int ti) { return (ti + 8 * nslot) % nslot; };
+  auto store_frame = [&](int ti) {
+    bf16_t* dst = ring + (size_t)slot_of(ti) * FRAME;
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+      const int i = tid + n * kThreads;
+      if (i < NVOX) *reinterpret_cast<u32x2*>(dst + (size_t)i * 4) = st[n];
+    }
+  };
+
+  // ---- epilogue constants ----
+  float sc[RP == 2 ? 1 : NT][4], sh[RP == 2 ? 1 : NT][4];
+#pragma unroll
+  for (int a = 0; a < (RP == 2 ? 1 : NT); ++a)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int c = RP == 2 ? 4 * (q & 1) + jj : a * 16 + 4 * q + jj;
+      const bool ok = c < d.cout;
+      sc[a][jj] = ok ? (d.scale ? d.scale[c] : 1.f) : 0.f;
+      sh[a][jj] = ok ? (d.shift ? d.shift[c] : 0.f) : 0.f;
+    }
+  bf16_t* Y = static_cast<bf16_t*>(d.y) + (long)b * d.y_bs;
+  const unsigned y_frame_bytes = (unsigned)(d.Ho * d.Wo * d.ldy) * 2u;
+  __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)(y_frame_bytes * (unsigned)d.To), 0x00020000);
+
+  // prologue: the first kt frames
+  for (int dt = 0; dt < d.kt; ++dt) {
+    load_frame(dt - d.pt);
+    store_frame(dt - d.pt);
+  }
+  __syncthreads();
+
+  for (int to = 0; to < d.To; ++to) {
+    const int ti_new = to + 1 - d.pt + d.kt - 1;      // the frame output to+1 needs on top of this one's
+    load_frame(to + 1 < d.To ? ti_new : -1);
+    if constexpr (RP == 2) {
+      f32x4 acc[TM];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int dt = 0; dt < d.kt; ++dt) {
+        const bf16_t* fb = ring + (size_t)slot_of(to - d.pt + dt) * FRAME + ((4 * wave) * IW + 2 * n16 + 2 * q) * 4;
+        const bf16_t* wp = wf_s + (size_t)(dt * JR) * 512 + lane * 8;
+#pragma unroll
+        for (int j = 0; j < JR; ++j) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(wp + j * 512);
+#pragma unroll
+          for (int t = 0; t < TM; ++t) {
+            const bf16x8 bfv = *reinterpret_cast<const bf16x8*>(fb + (j * IW + 32 * t) * 4);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfv, acc[t], 0, 0, 0);
+          }
+        }
+      }
+      store_frame(ti_new);
+      // rows 4q..4q+3 of the tile = channels 4(q&1)..+3 of output row 2*wave + (q >> 1)
+      const int ho = ho0 + 2 * wave + (q >> 1), co0 = 4 * (q & 1);
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int wo = wo0 + t * 16 + n16;
+        float v[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) v[jj] = acc[t][jj] * sc[0][jj] + sh[0][jj];
+        pv_apply_act_n<true>(v, d.act);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          if (co0 + jj >= d.cout) v[jj] = 0.f;
+        const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        const bool ok = ho < d.Ho && wo < d.Wo && co0 < cout_p8;
+        const unsigned off = ok ? (unsigned)to * y_frame_bytes + (unsigned)((ho * d.Wo + wo) * d.ldy + co0) * 2u : kOOB;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, (int)off, 0, 0);
+      }
+    } else {
+      f32x4 acc[NT][2][TM];
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+          for (int t = 0; t < TM; ++t) acc[a][rr][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int dt = 0; dt < d.kt; ++dt) {
+        const bf16_t* fb = ring + (size_t)slot_of(to - d.pt + dt) * FRAME + (2 * n16 + 2 * q) * 4;
+        const bf16_t* wp = wf_s + (size_t)(dt * JR * NT) * 512 + lane * 8;
+#pragma unroll
+        for (int dh = 0; dh < 7; ++dh) {
+          bf16x8 bfv[2][TM];
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+              bfv[rr][t] = *reinterpret_cast<const bf16x8*>(fb + ((2 * (wave + 4 * rr) + dh) * IW + 32 * t) * 4);
+#pragma unroll
+          for (int a = 0; a < NT; ++a) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(wp + (dh * NT + a) * 512);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+              for (int t = 0; t < TM; ++t)
+                acc[a][rr][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfv[rr][t], acc[a][rr][t], 0, 0, 0);
+          }
+        }
+      }
+      store_frame(ti_new);
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const int c0 = a * 16 + 4 * q;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int ho = ho0 + wave + 4 * rr;
+#pragma unroll
+          for (int t = 0; t < TM; ++t) {
+            const int wo = wo0 + t * 16 + n16;
+            float v[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[jj] = acc[a][rr][t][jj] * sc[a][jj] + sh[a][jj];
+            pv_apply_act_n<true>(v, d.act);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              if (c0 + jj >= d.cout) v[jj] = 0.f;
+            const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            const bool ok = ho < d.Ho && wo < d.Wo && c0 < cout_p8;
+            const unsigned off = ok ? (unsigned)to * y_frame_bytes + (unsigned)((ho * d.Wo + wo) * d.ldy + c0) * 2u : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry, (int)off, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();   // frame ti_new is visible; nobody reads the slot it replaced any more
+  }
+}
+
+// geometry of the LDS-staged 7 x 7 stem kernel: 0 = not this kernel's
+int stem7_variant(const pv_conv3d_desc& d) {
+  if (d.dtype != PV_BF16 || d.cin != 4 || d.ldx != 4 || d.y_f32 || d.pos_spatial || d.pos_temporal || d.dwt_w) return 0;
+  if (d.kh != 7 || d.kw != 7 || d.sh != 2 || d.sw != 2 || d.ph != 3 || d.pw != 3 || d.st != 1) return 0;
+  if (d.kt < 1 || d.kt > 7 || d.pt != d.kt / 2 || d.To != d.Ti) return 0;
+  if (d.dil_t > 1 || d.dil_h > 1 || d.dil_w > 1) return 0;
+  if ((long)d.Ti * d.Hi * d.Wi * 8 > 0x7fffffffL || (long)d.To * d.Ho * d.Wo * d.ldy * 2 > 0x7fffffffL) return 0;
+  if (d.cout <= 8) return 2;                                   // row pairs
+  if (d.cout % 16 == 0 && d.cout <= 64) return 1;              // channel tiles
+  return 0;
+}
+
+template <int RP, int NT, int TM> int launch_stem7(const pv_conv3d_desc& d, int wpitch, hipStream_t s) {
+  constexpr int TH = 8, TW = TM * 16;
+  constexpr int FRAME_B = ((TH - 1) * 2 + 7) * ((TW - 1) * 2 + 8) * 8;
+  const int tiles_h = (d.Ho + TH - 1) / TH, tiles_w = (d.Wo + TW - 1) / TW;
+  const int nfrag = d.kt * (RP == 2 ? 9 : 7 * NT);
+  const size_t lds = (size_t)nfrag * 1024 + (size_t)(d.kt + 1) * FRAME_B;
+  if (lds > 160 * 1024) return PV_ERR_UNSUPPORTED;
+  auto kern = stem7_kernel<RP, NT, TM>;
+  if (lds > 64 * 1024)
+    PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long blocks = (long)d.B * tiles_h * tiles_w;
+  if (blocks > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), lds, s, d, tiles_h, tiles_w, wpitch);
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // X3D stem in one pass: conv_xy (1 x kh x kw from the 4-channel input, MFMA) followed, with nothing in
 // between (models/x3d.py:66-88: Conv2plus1d(norm=None, activation=None)), by the depthwise temporal
 // conv_t (DK x 1 x 1, stride 1, padding DK/2) + folded BN + activation.  A lane owns its voxels for
@@ -453,6 +695,15 @@ int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s) {
   }
   if (ksteps * 4 > kMaxPairs || d.kt > 255 || d.kh > 255 || d.kw > 255) return PV_ERR_UNSUPPORTED;
   const int cout_p8 = pv_round_up(d.cout, 8);
+  if (const int v7 = pv_tune("stem7", 1) ? stem7_variant(d) : 0) {   // 7 x 7 / stride 2: input tiles through LDS
+    int r;
+    if (v7 == 2) r = launch_stem7<2, 1, 2>(d, KWP * 4, s);
+    else if (d.cout == 64) r = launch_stem7<1, 4, 2>(d, KWP * 4, s);
+    else if (d.cout == 48) r = launch_stem7<1, 3, 2>(d, KWP * 4, s);
+    else if (d.cout == 32) r = launch_stem7<1, 2, 2>(d, KWP * 4, s);
+    else r = launch_stem7<1, 1, 2>(d, KWP * 4, s);
+    if (r != PV_ERR_UNSUPPORTED) return r;
+  }
   if (jp == 2) return launch_stem<1, 4, 2>(d, ksteps, s);
   if (cout_p8 <= 16) return launch_stem<1, 4>(d, ksteps, s);
   if (cout_p8 <= 32) return launch_stem<2, 4>(d, ksteps, s);

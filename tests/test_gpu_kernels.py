@@ -312,6 +312,12 @@ def test_pointwise_conv_with_se_gate_swish_and_residual(dtype, B, S, K, N, gate,
     (2, 4, 18, 22, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1), False),    # X3D stem conv (odd kw: padded pair)
     (1, 6, 28, 28, 96, (3, 7, 7), (2, 4, 4), (1, 3, 3), True),     # MViT patch embedding (+bias, fp32 out)
     (1, 3, 9, 11, 20, (3, 2, 4), (1, 1, 3), (1, 0, 2), False),     # odd everything
+    # 7x7 / stride 2 with the input tile staged in LDS (stem7_kernel): several ragged tiles, frame ring wrapping
+    (1, 9, 70, 150, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3), False),
+    (2, 9, 50, 134, 8, (5, 7, 7), (1, 2, 2), (2, 3, 3), False),
+    (1, 5, 40, 70, 32, (3, 7, 7), (1, 2, 2), (1, 3, 3), False),
+    (1, 3, 21, 37, 6, (7, 7, 7), (1, 2, 2), (3, 3, 3), False),
+    (1, 2, 33, 66, 16, (1, 7, 7), (1, 2, 2), (0, 3, 3), False),
 ])
 def test_first_layer_conv_on_c4_layout(B, T, H, W, cout, k, s, p, f32out):
     x = _rand((B, 3, T, H, W), 61, torch.bfloat16)
