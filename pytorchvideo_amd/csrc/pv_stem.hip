@@ -240,7 +240,7 @@ template <int NT, int TM, int JP = 1> int launch_stem(const pv_conv3d_desc& d, i
 //   * <= 8 output channels (fast stem): the 16 MFMA rows are 8 channels x TWO vertically adjacent outputs -- input
 //     row r of a row pair feeds output row h with dh = r and output row h+1 with dh = r - 2 -- so no half of the
 //     instruction is idle; 64 channels (slow stem): 4 channel tiles share every B fragment.
-template <int RP, int NT, int TM>
+template <int RP, int NT, int TM, int KT>
 __global__ __launch_bounds__(kThreads) void stem7_kernel(const pv_conv3d_desc d, int tiles_h, int tiles_w, int wpitch) {
   constexpr int TH = 8, TW = TM * 16;
   constexpr int IH = (TH - 1) * 2 + 7;       // 21 input rows
@@ -251,8 +251,12 @@ __global__ __launch_bounds__(kThreads) void stem7_kernel(const pv_conv3d_desc d,
   constexpr int JR = RP == 2 ? 9 : 7;        // A fragments per temporal tap (row offsets of a row pair / dh)
   constexpr int NA = RP == 2 ? 1 : NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // KT > 0 (row-pair form only): the temporal extent is a compile-time constant and every wave keeps all KT * 9 A
+  // fragments in registers (180 VGPRs for the (5,7,7) stem) -- the LDS then holds nothing but the frame ring
+  // (70 KB: two workgroups per CU, one's barrier waits hidden behind the other's MFMAs) and A costs no LDS bandwidth.
+  constexpr bool kAReg = RP == 2 && KT > 0;
   bf16_t* wf_s = reinterpret_cast<bf16_t*>(smem_raw);               // [kt][JR][NA][64 lanes][8]
-  const int nfrag = d.kt * JR * NA;
+  const int nfrag = kAReg ? 0 : d.kt * JR * NA;
   bf16_t* ring = wf_s + (size_t)nfrag * 512;                         // [kt + 1][IH][IW][4]
   const int nslot = d.kt + 1;
 
@@ -332,10 +336,41 @@ __global__ __launch_bounds__(kThreads) void stem7_kernel(const pv_conv3d_desc d,
   const unsigned y_frame_bytes = (unsigned)(d.Ho * d.Wo * d.ldy) * 2u;
   __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)(y_frame_bytes * (unsigned)d.To), 0x00020000);
 
-  // prologue: the first kt frames
-  for (int dt = 0; dt < d.kt; ++dt) {
-    load_frame(dt - d.pt);
-    store_frame(dt - d.pt);
+  // prologue: the first kt frames (all of them in flight at once when kt is a compile-time constant)
+  if constexpr (KT > 0) {
+    u32x2 pf[KT][NLD];
+#pragma unroll
+    for (int dt = 0; dt < KT; ++dt) {
+      load_frame(dt - d.pt);
+#pragma unroll
+      for (int n = 0; n < NLD; ++n) pf[dt][n] = st[n];
+    }
+#pragma unroll
+    for (int dt = 0; dt < KT; ++dt) {
+#pragma unroll
+      for (int n = 0; n < NLD; ++n) st[n] = pf[dt][n];
+      store_frame(dt - d.pt);
+    }
+  } else {
+    for (int dt = 0; dt < d.kt; ++dt) {
+      load_frame(dt - d.pt);
+      store_frame(dt - d.pt);
+    }
+  }
+  bf16x8 areg[kAReg ? KT * JR : 1];
+  if constexpr (kAReg) {
+    const bf16_t* __restrict__ Wt = static_cast<const bf16_t*>(d.w);
+    const long Kh = (long)KT * 7 * wpitch;
+    const int ch = n16 & 7;
+#pragma unroll
+    for (int f = 0; f < KT * JR; ++f) {
+      const int j = f % JR, dt = f / JR;
+      const int dh = j - 2 * (n16 >> 3);
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ch < d.cout && dh >= 0 && dh < 7)
+        v = *reinterpret_cast<const bf16x8*>(Wt + (long)ch * Kh + (long)(dt * 7 + dh) * wpitch + q * 8);
+      areg[f] = v;
+    }
   }
   __syncthreads();
 
@@ -346,12 +381,15 @@ __global__ __launch_bounds__(kThreads) void stem7_kernel(const pv_conv3d_desc d,
       f32x4 acc[TM];
 #pragma unroll
       for (int t = 0; t < TM; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int dt = 0; dt < d.kt; ++dt) {
+#pragma unroll
+      for (int dt = 0; dt < (KT > 0 ? KT : d.kt); ++dt) {
         const bf16_t* fb = ring + (size_t)slot_of(to - d.pt + dt) * FRAME + ((4 * wave) * IW + 2 * n16 + 2 * q) * 4;
         const bf16_t* wp = wf_s + (size_t)(dt * JR) * 512 + lane * 8;
 #pragma unroll
         for (int j = 0; j < JR; ++j) {
-          const bf16x8 af = *reinterpret_cast<const bf16x8*>(wp + j * 512);
+          bf16x8 af;
+          if constexpr (kAReg) af = areg[dt * JR + j];
+          else af = *reinterpret_cast<const bf16x8*>(wp + j * 512);
 #pragma unroll
           for (int t = 0; t < TM; ++t) {
             const bf16x8 bfv = *reinterpret_cast<const bf16x8*>(fb + (j * IW + 32 * t) * 4);
@@ -448,14 +486,14 @@ int stem7_variant(const pv_conv3d_desc& d) {
   return 0;
 }
 
-template <int RP, int NT, int TM> int launch_stem7(const pv_conv3d_desc& d, int wpitch, hipStream_t s) {
+template <int RP, int NT, int TM, int KT = 0> int launch_stem7(const pv_conv3d_desc& d, int wpitch, hipStream_t s) {
   constexpr int TH = 8, TW = TM * 16;
   constexpr int FRAME_B = ((TH - 1) * 2 + 7) * ((TW - 1) * 2 + 8) * 8;
   const int tiles_h = (d.Ho + TH - 1) / TH, tiles_w = (d.Wo + TW - 1) / TW;
-  const int nfrag = d.kt * (RP == 2 ? 9 : 7 * NT);
+  const int nfrag = (RP == 2 && KT > 0) ? 0 : d.kt * (RP == 2 ? 9 : 7 * NT);
   const size_t lds = (size_t)nfrag * 1024 + (size_t)(d.kt + 1) * FRAME_B;
   if (lds > 160 * 1024) return PV_ERR_UNSUPPORTED;
-  auto kern = stem7_kernel<RP, NT, TM>;
+  auto kern = stem7_kernel<RP, NT, TM, KT>;
   if (lds > 64 * 1024)
     PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long blocks = (long)d.B * tiles_h * tiles_w;
@@ -697,7 +735,8 @@ int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s) {
   const int cout_p8 = pv_round_up(d.cout, 8);
   if (const int v7 = pv_tune("stem7", 1) ? stem7_variant(d) : 0) {   // 7 x 7 / stride 2: input tiles through LDS
     int r;
-    if (v7 == 2) r = launch_stem7<2, 1, 2>(d, KWP * 4, s);
+    if (v7 == 2 && d.kt == 5) r = launch_stem7<2, 1, 2, 5>(d, KWP * 4, s);   // SlowFast's fast stem
+    else if (v7 == 2) r = launch_stem7<2, 1, 2>(d, KWP * 4, s);
     else if (d.cout == 64) r = launch_stem7<1, 4, 2>(d, KWP * 4, s);
     else if (d.cout == 48) r = launch_stem7<1, 3, 2>(d, KWP * 4, s);
     else if (d.cout == 32) r = launch_stem7<1, 2, 2>(d, KWP * 4, s);
