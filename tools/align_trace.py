@@ -10,7 +10,7 @@ import re
 import sys
 
 
-def main(per_op, trace, first="stem_c4"):
+def main(per_op, trace, first="stem"):
     ops = []
     for line in open(per_op):
         m = re.match(r"\s+op (.+?)\s+([0-9.]+) ms", line)
