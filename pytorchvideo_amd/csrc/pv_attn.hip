@@ -24,6 +24,7 @@
 // stores); K rows are padded to 16*odd+... bytes so that ds_read_b128 is bank-conflict free.
 // fp32 (parity mode) uses v_mfma_f32_32x32x2_f32 with the same lane-private structure.
 #include <math.h>
+#include <type_traits>
 #include "pv_common.h"
 
 namespace {
@@ -343,10 +344,306 @@ __global__ __launch_bounds__(kThreads, 2) void attn_kernel(const pv_attention_de
   }
 }
 
+// bf16, software-pipelined over key tiles: the S^T = K Q^T MFMAs of tile t+1 are issued in the same instruction
+// stream as the exponentials of tile t (two score register sets, sA / sB, swapped by unrolling the tile loop twice),
+// so the matrix pipe works while the VALU / transcendental unit does the softmax -- a wave is in-order, an MFMA only
+// overlaps VALU work that follows it in program order and does not depend on it.  K and V live in separate double
+// buffers because their lifetimes now differ by half a step: K(t+1) is written before the tile's one barrier and
+// read right after it, V(t+1) is written after the barrier (PV(t-1) was the last reader of that buffer) and read
+// one barrier later.  The lane<->lane+32 max exchange is a v_permlane32_swap (VALU) instead of an LDS bpermute.
+template <int D>
+__global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attention_desc d, int nqb, int total) {
+  using T = bf16_t;
+  using Cfg = AttnCfg<bf16_t, D>;
+  constexpr int KT = Cfg::KT, KLD = Cfg::KLD, VLD = Cfg::VLD;
+  constexpr int NSUB = KT / 32, NDB = D / 32, NKS = D / 16, CPR = D / 8;
+  static_assert(NSUB == 2, "two 32-key sub-tiles per tile");
+  __shared__ __attribute__((aligned(16))) T smem[2 * (Cfg::K_ELEMS + Cfg::V_ELEMS)];
+  T* const kb0 = smem;
+  T* const kb1 = smem + Cfg::K_ELEMS;
+  T* const vb0 = smem + 2 * Cfg::K_ELEMS;
+  T* const vb1 = vb0 + Cfg::V_ELEMS;
+
+  int w;
+  {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int qn = total >> 3, rn = total & 7;
+    w = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+  }
+  const int bh = w / nqb;
+  const int qb = w - bh * nqb;
+  const int b = bh / d.heads;
+  const int h = bh - b * d.heads;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+
+  const T* __restrict__ Q = static_cast<const T*>(d.q) + (long)b * d.q_bs + h * D;
+  const T* __restrict__ K = static_cast<const T*>(d.k) + (long)b * d.k_bs + h * D;
+  const T* __restrict__ V = static_cast<const T*>(d.v) + (long)b * d.v_bs + h * D;
+  T* __restrict__ O = static_cast<T*>(d.o) + (long)b * d.o_bs + h * D;
+
+  const int q_row = qb * kQB + wave * 32 + l31;
+  const bool q_ok = q_row < d.Nq;
+  const int ntiles = (d.Nk + KT - 1) / KT;
+  const float sc = d.scale * 1.44269504088896340736f;
+
+  bf16x8 qf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if (q_ok) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (long)q_row * d.ldq + ks * 16 + hi * 8);
+    else qf[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+
+  // K / V rows through buffer resources: keys past Nk (and idle staging threads) read zeros by the range check,
+  // no exec-mask branches around the loads (the tile offset goes into the VGPR offset: the SGPR offset of a raw
+  // buffer access is not range-checked)
+  constexpr int KCH = (KT * CPR + kThreads - 1) / kThreads;
+  constexpr unsigned kOOB = 0x80000000u;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(K), 0, (int)(((long)(d.Nk - 1) * d.ldk + D) * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(V), 0, (int)(((long)(d.Nk - 1) * d.ldv + D) * 2), 0x00020000);
+  unsigned koff[KCH], voff;
+#pragma unroll
+  for (int i = 0; i < KCH; ++i) {
+    const int c = tid + i * kThreads;
+    const int row = c / CPR, col = c - row * CPR;
+    koff[i] = c < KT * CPR ? (unsigned)(row * d.ldk + col * 8) * 2u : kOOB;
+  }
+  {
+    const int kg = tid & 15, dc = tid >> 4;
+    voff = dc < CPR ? (unsigned)(kg * 4 * d.ldv + dc * 8) * 2u : kOOB;
+  }
+  const unsigned ktile_b = (unsigned)(KT * d.ldk) * 2u, vtile_b = (unsigned)(KT * d.ldv) * 2u, vrow_b = (unsigned)d.ldv * 2u;
+  bf16x8 kreg[KCH], vreg[4];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < KCH; ++i)
+      kreg[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(koff[i] + (unsigned)t * ktile_b), 0, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      vreg[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(voff + (unsigned)i * vrow_b + (unsigned)t * vtile_b), 0, 0));
+  };
+  auto store_k = [&](T* ks_) {
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      const int c = tid + i * kThreads;
+      const int row = c / CPR, col = c - row * CPR;
+      if (c < KT * CPR) *reinterpret_cast<bf16x8*>(ks_ + row * KLD + col * 8) = kreg[i];
+    }
+  };
+  auto store_v = [&](T* vs_) {
+    const int kg = tid & 15, dc = tid >> 4;
+    if (dc < CPR) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bf16x4 t4 = {vreg[0][j], vreg[1][j], vreg[2][j], vreg[3][j]};
+        *reinterpret_cast<bf16x4*>(vs_ + (dc * 8 + j) * VLD + kg * 4) = t4;
+      }
+    }
+  };
+  auto mask_tail = [&](int t, f32x16 (&sx)[NSUB]) {   // keys past Nk of tile t
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if ((t * KT + sub * 32 + crow(r, hi)) >= d.Nk) sx[sub][r] = -INFINITY;
+  };
+
+  f32x16 o[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  f32x16 sA[NSUB], sB[NSUB];
+
+  // one tile step: softmax + PV of tile t (scores in sc_), scores of tile t+1 into sn
+  // One tile step: softmax + PV of tile t (scores in sc_); MORE: there is a tile t+1 and its scores are produced
+  // here, into sn.  Between the rescale branch and the next barrier a step is straight-line code -- with a branch in
+  // between, LLVM sinks the exponentials below it, next to their use in the PV product.  That is why the key mask of a
+  // ragged last tile is not applied to finished scores: the accumulators of that tile START at -1e30 for keys >= Nk
+  // (a wave-uniform choice made before the MFMAs), and exp2 turns them into exact zeros.
+  auto step = [&](auto more_c, int t, f32x16 (&sc_)[NSUB], f32x16 (&sn)[NSUB]) {
+    constexpr bool more = decltype(more_c)::value;
+    T* const kn = ((t + 1) & 1) ? kb1 : kb0;
+    T* const vn = ((t + 1) & 1) ? vb1 : vb0;
+    const T* const vc = (t & 1) ? vb1 : vb0;
+    if constexpr (more) store_k(kn);
+    __syncthreads();
+    if constexpr (more) {
+      store_v(vn);
+      if (t + 2 < ntiles) load_tile(t + 2);
+      if ((t + 2) * KT > d.Nk) {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sn[sub][r] = ((t + 1) * KT + sub * 32 + crow(r, hi)) >= d.Nk ? -1e30f : 0.f;
+      } else {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sn[sub][r] = 0.f;
+      }
+    }
+
+    // ---- running max, deferred rescale (see attn_kernel) ----
+    constexpr float kDefer = 8.0f;
+    float mx = -1e30f;
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc_[sub][r]);
+    mx *= sc;
+    {
+      const unsigned mu = __builtin_bit_cast(unsigned, mx);
+      auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+      mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+    }
+    if (__any(mx > m_run + kDefer)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
+    const float neg_m = -m_run;
+    float ps0 = 0.f, ps1 = 0.f;
+    auto exp_range = [&](int v0, int v1) {
+#pragma unroll
+      for (int v = v0; v < v1; ++v) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sc_[v >> 4][v & 15], sc, neg_m));
+        sc_[v >> 4][v & 15] = pv;
+        if (v & 1) ps1 += pv; else ps0 += pv;
+      }
+    };
+    if constexpr (more) {
+      // ---- S^T(t+1) = K Q^T on the matrix pipe, exp2 of tile t on the VALU, interleaved in program order ----
+      bf16x8 kf[2][NSUB];
+      auto read_k = [&](int slot, int ks) {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+          kf[slot][sub] = *reinterpret_cast<const bf16x8*>(kn + (sub * 32 + l31) * KLD + ks * 16 + hi * 8);
+      };
+      read_k(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + 1 < NKS) read_k((ks + 1) & 1, ks + 1);
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+          sn[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][sub], qf[ks], sn[sub], 0, 0, 0);
+          const int i = ks * NSUB + sub;                       // NKS * NSUB slices of the 32 exponentials
+          exp_range(i * 32 / (NKS * NSUB), (i + 1) * 32 / (NKS * NSUB));
+          __builtin_amdgcn_sched_barrier(0);                   // keep the slice behind ITS MFMA (hipcc would sink all
+        }                                                      // 32 exponentials below the last MFMA otherwise)
+      }
+    } else {
+      exp_range(0, 32);
+    }
+    l_run += ps0 + ps1;
+
+    // ---- O^T += V^T P^T ----
+    bf16x8 pb[NSUB * 2];
+    constexpr int NF = NSUB * 2 * NDB;
+    bf16x8 vf[3];
+    auto read_v = [&](int slot, int i) {
+      const int sk = i / NDB, db = i - sk * NDB;
+      const T* vp = vc + (db * 32 + l31) * VLD + sk * 16 + hi * 4;
+      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vp);
+      const bf16x4 up = *reinterpret_cast<const bf16x4*>(vp + 8);
+      vf[slot] = bf16x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+    };
+    read_v(0, 0);
+    read_v(1, 1);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      if (i + 2 < NF) read_v((i + 2) % 3, i + 2);
+      const int sk = i / NDB, db = i - sk * NDB;
+      if (db == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[sk][j] = (bf16_t)sc_[sk >> 1][(sk & 1) * 8 + j];
+      }
+      o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pb[sk], o[db], 0, 0, 0);
+    }
+  };
+
+  // prologue: tile 0 staged, its scores computed the plain way
+  load_tile(0);
+  store_k(kb0);
+  store_v(vb0);
+  __syncthreads();
+  if (ntiles > 1) load_tile(1);
+  {
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sA[sub][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+        const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(kb0 + (sub * 32 + l31) * KLD + ks * 16 + hi * 8);
+        sA[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[ks], sA[sub], 0, 0, 0);
+      }
+    if (KT > d.Nk) mask_tail(0, sA);
+  }
+  {
+    using Y = std::integral_constant<bool, true>;
+    using N = std::integral_constant<bool, false>;
+    int t = 0;
+    for (; t + 2 < ntiles; t += 2) {
+      step(Y{}, t, sA, sB);
+      step(Y{}, t + 1, sB, sA);
+    }
+    if (ntiles - t == 2) {       // the current scores are in sA
+      step(Y{}, t, sA, sB);
+      step(N{}, t + 1, sB, sA);
+    } else {
+      step(N{}, t, sA, sB);
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q_ok) {
+    T* orow = O + (long)q_row * d.ldo;
+    const T* qrow = Q + (long)q_row * d.ldq;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = db * 32 + 8 * g + 4 * hi;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = o[db][g * 4 + j] * inv;
+        if (d.residual_q) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)qrow[d0 + j];
+        }
+        bf16x4 ov = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(orow + d0) = ov;
+      }
+  }
+}
+
 template <typename T, int D> int launch_attn(const pv_attention_desc& d, hipStream_t s) {
   const int nqb = (d.Nq + kQB - 1) / kQB;
   const long total = (long)d.B * d.heads * nqb;
   if (total <= 0 || total > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
+  if constexpr (sizeof(T) == 2 && D <= 96) {   // (D = 128 would spill: two score sets + 64 O accumulators)
+    const long kv_bytes = ((long)(d.Nk + 64) * (d.ldk > d.ldv ? d.ldk : d.ldv) + D) * 2;
+    if (pv_tune("attn_pipe", 1) && kv_bytes < 0x7fffffffL) {
+      hipLaunchKernelGGL((attn_pipe_kernel<D>), dim3((unsigned)total), dim3(kThreads), 0, s, d, nqb, (int)total);
+      PV_LAUNCH_CHECK();
+      return PV_OK;
+    }
+  }
   hipLaunchKernelGGL((attn_kernel<T, D>), dim3((unsigned)total), dim3(kThreads), 0, s, d, nqb, (int)total);
   PV_LAUNCH_CHECK();
   return PV_OK;
