@@ -419,10 +419,12 @@ __global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attenti
   }
   const unsigned ktile_b = (unsigned)(KT * d.ldk) * 2u, vtile_b = (unsigned)(KT * d.ldv) * 2u, vrow_b = (unsigned)d.ldv * 2u;
   bf16x8 kreg[KCH], vreg[4];
-  auto load_tile = [&](int t) {
+  auto load_k = [&](int t) {
 #pragma unroll
     for (int i = 0; i < KCH; ++i)
       kreg[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(koff[i] + (unsigned)t * ktile_b), 0, 0));
+  };
+  auto load_v = [&](int t) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       vreg[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(voff + (unsigned)i * vrow_b + (unsigned)t * vtile_b), 0, 0));
@@ -432,27 +434,21 @@ __global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attenti
     for (int i = 0; i < KCH; ++i) {
       const int c = tid + i * kThreads;
       const int row = c / CPR, col = c - row * CPR;
-      if (c < KT * CPR) *reinterpret_cast<bf16x8*>(ks_ + row * KLD + col * 8) = kreg[i];
+      if ((KT * CPR) % kThreads == 0 || c < KT * CPR) *reinterpret_cast<bf16x8*>(ks_ + row * KLD + col * 8) = kreg[i];
     }
   };
-  auto store_v = [&](T* vs_) {
-    const int kg = tid & 15, dc = tid >> 4;
-    if (dc < CPR) {
+  // staging threads without a channel chunk (tid/16 >= D/8) hold zeros and drop them into the 8-byte pad at the end of
+  // a V^T row: no exec-mask branch, so the stores can sit between the PV MFMAs without splitting the block
+  const int v_col = (tid >> 4) < CPR ? (tid & 15) * 4 : KT;
+  const int v_dc = (tid >> 4) < CPR ? (tid >> 4) : CPR - 1;
+  auto store_v_part = [&](T* vs_, int j0, int j1) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        bf16x4 t4 = {vreg[0][j], vreg[1][j], vreg[2][j], vreg[3][j]};
-        *reinterpret_cast<bf16x4*>(vs_ + (dc * 8 + j) * VLD + kg * 4) = t4;
-      }
+    for (int j = j0; j < j1; ++j) {
+      bf16x4 t4 = {vreg[0][j], vreg[1][j], vreg[2][j], vreg[3][j]};
+      *reinterpret_cast<bf16x4*>(vs_ + (v_dc * 8 + j) * VLD + v_col) = t4;
     }
   };
-  auto mask_tail = [&](int t, f32x16 (&sx)[NSUB]) {   // keys past Nk of tile t
-#pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if ((t * KT + sub * 32 + crow(r, hi)) >= d.Nk) sx[sub][r] = -INFINITY;
-  };
-
+  auto store_v = [&](T* vs_) { store_v_part(vs_, 0, 8); };
   f32x16 o[NDB];
 #pragma unroll
   for (int i = 0; i < NDB; ++i)
@@ -467,16 +463,27 @@ __global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attenti
   // between, LLVM sinks the exponentials below it, next to their use in the PV product.  That is why the key mask of a
   // ragged last tile is not applied to finished scores: the accumulators of that tile START at -1e30 for keys >= Nk
   // (a wave-uniform choice made before the MFMAs), and exp2 turns them into exact zeros.
+  float mx_next = -1e30f;   // scaled row max of the scores the NEXT step will consume (computed under this step's PV)
+  auto row_max = [&](f32x16 (&sx)[NSUB]) {
+    float mx = -1e30f;
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sx[sub][r]);
+    return mx;
+  };
   auto step = [&](auto more_c, int t, f32x16 (&sc_)[NSUB], f32x16 (&sn)[NSUB]) {
     constexpr bool more = decltype(more_c)::value;
     T* const kn = ((t + 1) & 1) ? kb1 : kb0;
     T* const vn = ((t + 1) & 1) ? vb1 : vb0;
     const T* const vc = (t & 1) ? vb1 : vb0;
-    if constexpr (more) store_k(kn);
+    if constexpr (more) {
+      store_k(kn);                       // K(t+1): loaded one step ago
+      load_k(t + 2);                     // ... and its registers go straight back to memory for K(t+2) (past the
+                                         // last tile the range check returns zeros; nobody reads them)
+    }
     __syncthreads();
     if constexpr (more) {
-      store_v(vn);
-      if (t + 2 < ntiles) load_tile(t + 2);
       if ((t + 2) * KT > d.Nk) {
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub)
@@ -490,28 +497,23 @@ __global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attenti
       }
     }
 
-    // ---- running max, deferred rescale (see attn_kernel) ----
+    // ---- deferred rescale (see attn_kernel); the row max came out of the previous step's PV phase ----
     constexpr float kDefer = 8.0f;
-    float mx = -1e30f;
-#pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc_[sub][r]);
-    mx *= sc;
     {
+      float mx = mx_next * sc;
       const unsigned mu = __builtin_bit_cast(unsigned, mx);
       auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
       mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
-    }
-    if (__any(mx > m_run + kDefer)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      l_run *= alpha;
+      if (__any(mx > m_run + kDefer)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
 #pragma unroll
-      for (int i = 0; i < NDB; ++i)
+        for (int i = 0; i < NDB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      }
     }
     const float neg_m = -m_run;
     float ps0 = 0.f, ps1 = 0.f;
@@ -548,7 +550,8 @@ __global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attenti
     }
     l_run += ps0 + ps1;
 
-    // ---- O^T += V^T P^T ----
+    // ---- O^T += V^T P^T on the matrix pipe; under it, on the VALU / LDS: P -> bf16, V(t+1) transposed into its
+    //      buffer (then V(t+2) requested), and the row max of the scores just produced ----
     bf16x8 pb[NSUB * 2];
     constexpr int NF = NSUB * 2 * NDB;
     bf16x8 vf[3];
@@ -561,6 +564,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attenti
     };
     read_v(0, 0);
     read_v(1, 1);
+    float mxa = -1e30f, mxb = -1e30f;
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       if (i + 2 < NF) read_v((i + 2) % 3, i + 2);
@@ -570,20 +574,49 @@ __global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attenti
         for (int j = 0; j < 8; ++j) pb[sk][j] = (bf16_t)sc_[sk >> 1][(sk & 1) * 8 + j];
       }
       o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pb[sk], o[db], 0, 0, 0);
+      if constexpr (more) {
+        // the side work in 8 parts (one V^T row group + 4 score registers each) spread over iterations I0..L
+        constexpr int I0 = NF >= 12 ? 2 : 0, L = NF >= 12 ? NF - 2 : NF - 1, CNT = L - I0 + 1;
+        if (i >= I0 && i <= L) {
+          const int j0 = (i - I0) * 8 / CNT, j1 = (i - I0 + 1) * 8 / CNT;
+          store_v_part(vn, j0, j1);
+#pragma unroll
+          for (int r = j0 * 2; r < j1 * 2; ++r) {
+            mxa = fmaxf(mxa, sn[0][r]);
+            mxb = fmaxf(mxb, sn[1][r]);
+          }
+          asm volatile("" : "+v"(mxa), "+v"(mxb));   // pin the partial maxima to this slice (see below)
+        }
+        if (i == (L + 1 < NF ? L + 1 : NF - 1)) load_v(t + 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    mx_next = fmaxf(mxa, mxb);
+    asm volatile("" : "+v"(mx_next));   // pin: without a use HERE LLVM sinks the whole max chain below the next barrier
   };
 
-  // prologue: tile 0 staged, its scores computed the plain way
-  load_tile(0);
+  // prologue: tile 0 staged, tile 1 requested, the scores of tile 0 computed the plain way
+  load_k(0);
+  load_v(0);
   store_k(kb0);
   store_v(vb0);
+  if (ntiles > 1) {
+    load_k(1);
+    load_v(1);
+  }
   __syncthreads();
-  if (ntiles > 1) load_tile(1);
   {
+    if (KT > d.Nk) {
 #pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub)
+      for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sA[sub][r] = 0.f;
+        for (int r = 0; r < 16; ++r) sA[sub][r] = (sub * 32 + crow(r, hi)) >= d.Nk ? -1e30f : 0.f;
+    } else {
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sA[sub][r] = 0.f;
+    }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -591,7 +624,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attenti
         const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(kb0 + (sub * 32 + l31) * KLD + ks * 16 + hi * 8);
         sA[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[ks], sA[sub], 0, 0, 0);
       }
-    if (KT > d.Nk) mask_tail(0, sA);
+    mx_next = row_max(sA);
   }
   {
     using Y = std::integral_constant<bool, true>;
@@ -637,7 +670,7 @@ template <typename T, int D> int launch_attn(const pv_attention_desc& d, hipStre
   const long total = (long)d.B * d.heads * nqb;
   if (total <= 0 || total > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
   if constexpr (sizeof(T) == 2 && D <= 96) {   // (D = 128 would spill: two score sets + 64 O accumulators)
-    const long kv_bytes = ((long)(d.Nk + 64) * (d.ldk > d.ldv ? d.ldk : d.ldv) + D) * 2;
+    const long kv_bytes = ((long)(d.Nk + 192) * (d.ldk > d.ldv ? d.ldk : d.ldv) + D) * 2;   // 32-bit offsets, 2 tiles past the end
     if (pv_tune("attn_pipe", 1) && kv_bytes < 0x7fffffffL) {
       hipLaunchKernelGGL((attn_pipe_kernel<D>), dim3((unsigned)total), dim3(kThreads), 0, s, d, nqb, (int)total);
       PV_LAUNCH_CHECK();
