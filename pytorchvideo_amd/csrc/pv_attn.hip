@@ -456,13 +456,14 @@ __global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attenti
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
   f32x16 sA[NSUB], sB[NSUB];
+  const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   // one tile step: softmax + PV of tile t (scores in sc_), scores of tile t+1 into sn
   // One tile step: softmax + PV of tile t (scores in sc_); MORE: there is a tile t+1 and its scores are produced
   // here, into sn.  Between the rescale branch and the next barrier a step is straight-line code -- with a branch in
   // between, LLVM sinks the exponentials below it, next to their use in the PV product.  That is why the key mask of a
-  // ragged last tile is not applied to finished scores: the accumulators of that tile START at -1e30 for keys >= Nk
-  // (a wave-uniform choice made before the MFMAs), and exp2 turns them into exact zeros.
+  // ragged last tile is applied by the step that CONSUMES the scores, before its rescale decision, not by the step that
+  // produced them.
   float mx_next = -1e30f;   // scaled row max of the scores the NEXT step will consume (computed under this step's PV)
   auto row_max = [&](f32x16 (&sx)[NSUB]) {
     float mx = -1e30f;
@@ -483,18 +484,13 @@ __global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attenti
                                          // last tile the range check returns zeros; nobody reads them)
     }
     __syncthreads();
-    if constexpr (more) {
-      if ((t + 2) * KT > d.Nk) {
+    if ((t + 1) * KT > d.Nk) {   // ragged last tile: keys >= Nk out of the softmax (zero K rows scored 0), exact row max
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
+      for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sn[sub][r] = ((t + 1) * KT + sub * 32 + crow(r, hi)) >= d.Nk ? -1e30f : 0.f;
-      } else {
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sn[sub][r] = 0.f;
-      }
+        for (int r = 0; r < 16; ++r)
+          if ((t * KT + sub * 32 + crow(r, hi)) >= d.Nk) sc_[sub][r] = -1e30f;
+      mx_next = row_max(sc_);
     }
 
     // ---- deferred rescale (see attn_kernel); the row max came out of the previous step's PV phase ----
@@ -516,13 +512,19 @@ __global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attenti
       }
     }
     const float neg_m = -m_run;
-    float ps0 = 0.f, ps1 = 0.f;
-    auto exp_range = [&](int v0, int v1) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 sc2 = {sc, sc}, nm2 = {neg_m, neg_m};
+    f32x2 ps = {0.f, 0.f};
+    auto exp_range = [&](int v0, int v1) {   // even-aligned pairs: v_pk_fma_f32 / v_pk_add_f32 halve the plain VALU issue
 #pragma unroll
-      for (int v = v0; v < v1; ++v) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(sc_[v >> 4][v & 15], sc, neg_m));
-        sc_[v >> 4][v & 15] = pv;
-        if (v & 1) ps1 += pv; else ps0 += pv;
+      for (int v = v0; v < v1; v += 2) {
+        f32x2 x = {sc_[v >> 4][v & 15], sc_[v >> 4][(v & 15) + 1]};
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(x) : "v"(x), "v"(sc2), "v"(nm2));   // (hipcc scalarises the builtin)
+        x[0] = __builtin_amdgcn_exp2f(x[0]);
+        x[1] = __builtin_amdgcn_exp2f(x[1]);
+        sc_[v >> 4][v & 15] = x[0];
+        sc_[v >> 4][(v & 15) + 1] = x[1];
+        ps += x;
       }
     };
     if constexpr (more) {
@@ -539,16 +541,16 @@ __global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attenti
         if (ks + 1 < NKS) read_k((ks + 1) & 1, ks + 1);
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
-          sn[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][sub], qf[ks], sn[sub], 0, 0, 0);
-          const int i = ks * NSUB + sub;                       // NKS * NSUB slices of the 32 exponentials
-          exp_range(i * 32 / (NKS * NSUB), (i + 1) * 32 / (NKS * NSUB));
+          sn[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][sub], qf[ks], ks == 0 ? kZero16 : sn[sub], 0, 0, 0);
+          const int i = ks * NSUB + sub;                       // NKS * NSUB slices of the 16 pairs of exponentials
+          exp_range(2 * (i * 16 / (NKS * NSUB)), 2 * ((i + 1) * 16 / (NKS * NSUB)));
           __builtin_amdgcn_sched_barrier(0);                   // keep the slice behind ITS MFMA (hipcc would sink all
         }                                                      // 32 exponentials below the last MFMA otherwise)
       }
     } else {
       exp_range(0, 32);
     }
-    l_run += ps0 + ps1;
+    l_run += ps[0] + ps[1];
 
     // ---- O^T += V^T P^T on the matrix pipe; under it, on the VALU / LDS: P -> bf16, V(t+1) transposed into its
     //      buffer (then V(t+2) requested), and the row max of the scores just produced ----
@@ -606,25 +608,14 @@ __global__ __launch_bounds__(kThreads, 2) void attn_pipe_kernel(const pv_attenti
   }
   __syncthreads();
   {
-    if (KT > d.Nk) {
-#pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sA[sub][r] = (sub * 32 + crow(r, hi)) >= d.Nk ? -1e30f : 0.f;
-    } else {
-#pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sA[sub][r] = 0.f;
-    }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
       for (int sub = 0; sub < NSUB; ++sub) {
         const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(kb0 + (sub * 32 + l31) * KLD + ks * 16 + hi * 8);
-        sA[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[ks], sA[sub], 0, 0, 0);
+        sA[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[ks], ks == 0 ? kZero16 : sA[sub], 0, 0, 0);
       }
-    mx_next = row_max(sA);
+    mx_next = row_max(sA);   // (a ragged single tile is masked, and its max redone, at the top of its step)
   }
   {
     using Y = std::integral_constant<bool, true>;
