@@ -15,7 +15,7 @@ for WL in "$@"; do
   PV_BENCH_VERBOSE=2 python $R/bench.py --workload $WL --streams 1 --no-secondary --no-cpu-baseline > $OUT/${WL}_bench_streams1.json 2> $S/per_op.err
   grep -v amdgpu.ids $S/per_op.err > $OUT/${WL}_per_op.txt
   python $R/bench.py --workload $WL --no-secondary > $OUT/${WL}_bench_default.json 2>/dev/null
-  CMD="python $R/bench.py --workload $WL --streams 1 --no-secondary --no-cpu-baseline --no-sustained --steps 10 --warmup 2"
+  CMD="python $R/bench.py --workload $WL --streams 1 --no-secondary --no-cpu-baseline --no-sustained --no-roofline --steps 10 --warmup 2"   # replays only: the in-situ per-op profiler would add partial replays to the trace
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $S -o trace -- $CMD > $S/trace.log 2>&1
   cp $(find $S -name 'trace_kernel_stats.csv' | head -1) $OUT/${WL}_kernel_stats.csv
   python $R/tools/align_trace.py $OUT/${WL}_per_op.txt $(find $S -name 'trace_kernel_trace.csv' | head -1) > $OUT/${WL}_rocprof_vs_events.md 2>$S/align.err || cat $S/align.err

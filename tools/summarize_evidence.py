@@ -46,10 +46,52 @@ def find(d, pat):
 FAMILIES = {   # op family of bench.py's roofline object -> kernel symbols behind it
     "x3d_m": {"conv_c": r"pw_stream_kernel<\d, \d, (true|false), \d+, false, (true|false)>|conv_igemm", "conv_ab": r"pwdw_plane_kernel",
               "conv_b": r"dw3_plane_kernel", "stem.conv01": r"stem_c4_dwt_kernel"},
-    "mvit_b_32x3": {"attn.core": r"attn_kernel", "gemm": r"gemm_glds_kernel", "layernorm": r"layernorm", "stream": r"pw_stream_kernel"},
-    "slowfast_r50": {"conv_a": r"gemm_glds_kernel<false|pw_stream_kernel|conv_igemm", "gemm": r"gemm_glds_kernel", "stem.conv": r"stem_c4_kernel",
+    "mvit_b_32x3": {"attn.core": r"attn_(pipe_)?kernel", "gemm": r"gemm_glds_kernel", "layernorm": r"layernorm", "stream": r"pw_stream_kernel"},
+    "slowfast_r50": {"conv_a": r"gemm_glds_kernel<false|pw_stream_kernel|conv_igemm", "gemm": r"gemm_glds_kernel", "stem.conv": r"stem7_kernel|stem_c4_kernel",
                      "narrow+lateral": r"tap_stream_kernel"},
 }
+
+
+def by_plan_order(d, per_op):
+    """HBM bytes per op family, attributing dispatches to plan ops BY ORDER (every op is one launch; the PMC passes run
+    whole replays only): exact where one kernel symbol serves several families.  {} if the passes do not line up."""
+    ops = []
+    for line in open(per_op):
+        m = re.match(r"\s+op (.+?)\s+([0-9.]+) ms", line)
+        if m:
+            lab = m.group(1).split("|")[0]
+            ops.append(lab.split(".")[0] if lab.startswith(("conv_b", "conv_ab")) else lab)
+    out = {}
+    for key, pat, ctr in (("fetch", "fetch_counter_collection.csv", "FETCH_SIZE"), ("write", "write_counter_collection.csv", "WRITE_SIZE")):
+        disp = {}
+        for row in csv.DictReader(open(find(d, pat))):
+            if row["Counter_Name"] == ctr:
+                e = disp.setdefault(int(row["Dispatch_Id"]), [row["Kernel_Name"], 0.0])
+                e[1] += float(row["Counter_Value"])
+        seq = [disp[i] for i in sorted(disp)]
+        starts = [i for i, (name, _) in enumerate(seq) if "stem" in name]
+        reps, last = [], -len(ops)
+        for i in starts:
+            if i - last >= len(ops) and i + len(ops) <= len(seq):
+                reps.append(i)
+                last = i
+        if not reps:
+            return {}
+        acc, cnt = collections.defaultdict(float), collections.Counter(ops)
+        for i in reps:
+            for lab, (_, v) in zip(ops, seq[i:i + len(ops)]):
+                acc[lab] += v * 1024
+        for lab in acc:
+            out.setdefault(lab, {})[key] = acc[lab] / (len(reps) * cnt[lab])
+            out[lab]["n"] = len(reps) * cnt[lab]
+    res = {}
+    for lab, v in out.items():
+        if "fetch" in v and "write" in v:
+            res[lab] = {"attribution": "plan order (dispatch i of a replay = op i)", "dispatches_profiled": v["n"],
+                        "fetch_bytes_per_launch": round(2 * v["fetch"]), "write_bytes_per_launch": round(v["write"]),
+                        "hbm_bytes_per_launch": round(2 * v["fetch"] + v["write"]),
+                        "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, gfx950 FETCH_SIZE x2 correction"}
+    return res
 
 
 def main():
@@ -74,8 +116,10 @@ def main():
         print("| `%s` | %d | %.1f | %.1f | %.1f %% | %.0f %% | %.0f %% | %.0f %% |" % (
             k, len(dur[k]), tot[k] / len(dur[k]), hb, 100 * mf, 100 * c.get("SQ_ACTIVE_INST_VALU", 0) / wc,
             100 * c.get("SQ_WAIT_ANY", 0) / wc, 100 * c.get("SQ_WAIT_INST_ANY", 0) / wc))
-    traffic = {}
+    traffic = by_plan_order(d, sys.argv[3]) if len(sys.argv) > 3 else {}
     for label, rx in FAMILIES.get(wl, {}).items():
+        if traffic:
+            break     # exact attribution available: dispatch i of a replay is op i of the launch plan
         pat = re.compile(rx)
         ks = [k for k in nf if pat.search(k)]
         n1, n2 = sum(nf[k] for k in ks), sum(nw.get(k, 0) for k in ks)
