@@ -68,7 +68,7 @@ def by_plan_order(d, per_op):
             if row["Counter_Name"] == ctr:
                 e = disp.setdefault(int(row["Dispatch_Id"]), [row["Kernel_Name"], 0.0])
                 e[1] += float(row["Counter_Value"])
-        seq = [disp[i] for i in sorted(disp)]
+        seq = [disp[i] for i in sorted(disp) if "_prefix_kernel" not in disp[i][0]]   # (an op's second, cls-row launch)
         starts = [i for i, (name, _) in enumerate(seq) if "stem" in name]
         reps, last = [], -len(ops)
         for i in starts:
