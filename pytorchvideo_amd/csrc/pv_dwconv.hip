@@ -418,7 +418,11 @@ int plane_variant(const pv_dwconv3d_desc& d) {
   if (d.act != PV_ACT_NONE && d.act != PV_ACT_RELU && d.act != PV_ACT_SWISH) return 0;
   if ((long)d.Ti * d.Hi * d.Wi * d.ldx > 0x3fffffffL || (long)d.To * d.Ho * d.Wo * d.ldy > 0x3fffffffL)
     return 0;   // 31-bit byte offsets inside a clip (buffer addressing)
-  return d.Wo >= 12 ? 4 : 2;
+  // 4 outputs per lane (16-wide tiles, 186+ VGPRs: 2 waves per SIMD) or 2 (8-wide tiles, 134 VGPRs: 3 waves per SIMD).
+  // The plain kernel lives on the number of waves with loads in flight: narrow tiles win on every grid measured (X3D-M 14^2, MViT 56^2 pool_q)
+  // (X3D-M res4 conv_b: -7 %); the fused conv_a producer (pw_cin > 0) recomputes its halo, so it keeps the wide tile.
+  const bool fused = d.pw_w != nullptr || d.pw_cin > 0;
+  return d.Wo >= (fused ? 12 : pv_tune("dw_wide_min_wo", 64)) ? 4 : 2;
 }
 
 int plane_tiles(const pv_dwconv3d_desc& d, int nw) { return ((d.Ho + kPR - 1) / kPR) * ((d.Wo + 4 * nw - 1) / (4 * nw)); }
