@@ -194,6 +194,11 @@ typedef struct pv_dwconv3d_desc {
   const float* pw_scale;     /* [C] or NULL */
   const float* pw_shift;     /* [C] or NULL */
   int32_t pw_cin, pw_act;
+  /* Channel-wise GROUPED convolution (create_csn(stage_conv_b_width_per_group = gw), models/csn.py:34,169 ->
+   * nn.Conv3d(C, C, groups = C / gw)): gw = 2, 4 or 8 input channels per output channel, all inside the output
+   * channel's own 8-channel chunk.  0 / 1 = depthwise.  Weights [taps][gw][round_up(C,8)] fp32: w[t][j][c]
+   * multiplies input channel (c / gw) * gw + j.  No w_mod, no fused producer, C % gw == 0. */
+  int32_t gw;
 } pv_dwconv3d_desc;
 int pv_dwconv3d(const pv_dwconv3d_desc* d, pv_stream_t stream);
 int pv_dwconv3d_psum_blocks(const pv_dwconv3d_desc* d);

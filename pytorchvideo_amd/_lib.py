@@ -43,7 +43,7 @@ DwConv3dDesc = _struct("DwConv3dDesc", [
     ("x_bs", _i64), ("y_bs", _i64)]
     + _ints("ldx", "ldy", "B", "Ti", "Hi", "Wi", "C", "To", "Ho", "Wo",
             "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "w_mod", "act", "dtype", "n_prefix")
-    + [("pw_w", _p), ("pw_scale", _p), ("pw_shift", _p)] + _ints("pw_cin", "pw_act"))
+    + [("pw_w", _p), ("pw_scale", _p), ("pw_shift", _p)] + _ints("pw_cin", "pw_act", "gw"))
 
 LateralDesc = _struct("LateralDesc", [
     ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("x_bs", _i64), ("y_bs", _i64)]
@@ -142,7 +142,7 @@ _SYMBOLS = [
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _lib = None
 

@@ -92,11 +92,23 @@ def check_conv3d(conv):
     if conv.padding_mode != "zeros" or isinstance(conv.padding, str):
         raise Unsupported("padding mode")
     depthwise = conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1
-    if conv.groups != 1 and not depthwise:
-        raise Unsupported("grouped conv (groups=%d)" % conv.groups)
     if depthwise and tuple(conv.dilation) != (1, 1, 1):
         raise Unsupported("dilated depthwise conv")
-    return depthwise
+    # channel-wise grouped conv with 2 / 4 / 8 channels per group (create_csn(stage_conv_b_width_per_group=...),
+    # reference models/csn.py:34,169) rides in the depthwise kernel (pv_dwconv3d_desc.gw); every other grouping is
+    # evaluated as a dense conv with block-diagonal weights (emit_conv) -- slower than a grouped kernel would be,
+    # but on the HIP path like the rest of the deployed model
+    return depthwise or group_width(conv) > 1
+
+
+def group_width(conv):
+    """Input channels per group if `conv` can run as a channel-wise grouped conv in the depthwise kernel, else 0/1."""
+    if not isinstance(conv, nn.Conv3d) or conv.groups <= 1 or conv.in_channels != conv.out_channels:
+        return 0
+    gw = conv.in_channels // conv.groups
+    if gw == 1:
+        return 1
+    return gw if gw in (2, 4, 8) and tuple(conv.dilation) == (1, 1, 1) else 0
 
 
 def is_add_fusion(fn):
@@ -177,7 +189,13 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
     if (y.B, y.T, y.H, y.W) != (x.B, To, Ho, Wo) or y.C != cout:
         raise RuntimeError("conv output buffer geometry mismatch")
     # pack [cout][taps][cin_p]
-    w = conv.weight.detach().float().cpu()  # [cout, cin, kt, kh, kw]
+    w = conv.weight.detach().float().cpu()  # [cout, cin / groups, kt, kh, kw]
+    if conv.groups > 1:   # grouped, not channel-wise: block-diagonal dense weights
+        cg_in, cg_out = conv.in_channels // conv.groups, cout // conv.groups
+        wd = torch.zeros((cout, conv.in_channels) + tuple(w.shape[2:]), dtype=w.dtype)
+        for g in range(conv.groups):
+            wd[g * cg_out:(g + 1) * cg_out, g * cg_in:(g + 1) * cg_in] = w[g * cg_out:(g + 1) * cg_out]
+        w = wd
     wpair = 0
     if c4 and pad8(cout) <= 8 and dwt is None and not y_f32 and tuning.get("stem_wpair"):
         # <= 8 output channels (SlowFast's fast stem): two W-adjacent outputs per MFMA column; row (j, co) of the
@@ -304,7 +322,7 @@ def can_fuse_pointwise_into_dw(sess, conv_a, conv_b, x):
             or conv_a.groups != 1 or conv_a.in_channels != x.C or conv_a.out_channels != conv_b.in_channels:
         return False
     try:
-        if check_conv3d(conv_a) or not check_conv3d(conv_b):
+        if check_conv3d(conv_a) or not check_conv3d(conv_b) or group_width(conv_b) != 1:
             return False
     except Unsupported:
         return False
@@ -346,9 +364,15 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
         raise RuntimeError("conv output would be empty")
     Cc = x.C if producer is None else conv.in_channels
     wc = w_mod if w_mod else Cc
-    w = conv.weight.detach().float().cpu().reshape(wc, kt * kh * kw)
-    wp = torch.zeros(kt * kh * kw, pad8(wc), dtype=torch.float32)
-    wp[:, :wc] = w.t()
+    gw = 0 if (w_mod or producer is not None) else group_width(conv)
+    if gw > 1:    # [taps][gw][C]: w[t][j][c] multiplies input channel (c // gw) * gw + j
+        w = conv.weight.detach().float().cpu().reshape(Cc, gw, kt * kh * kw)
+        wp = torch.zeros(kt * kh * kw, gw, pad8(Cc), dtype=torch.float32)
+        wp[:, :, :Cc] = w.permute(2, 1, 0)
+    else:
+        w = conv.weight.detach().float().cpu().reshape(wc, kt * kh * kw)
+        wp = torch.zeros(kt * kh * kw, pad8(wc), dtype=torch.float32)
+        wp[:, :wc] = w.t()
     if out is not None:
         y = out
     elif grid is not None:
@@ -365,7 +389,7 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
         psum=None, x_bs=x.bs, y_bs=y.bs, ldx=x.ld, ldy=y.ld,
         B=x.B, Ti=Ti, Hi=Hi, Wi=Wi, C=Cc, To=To, Ho=Ho, Wo=Wo,
         kt=kt, kh=kh, kw=kw, st=st, sh=sh, sw=sw, pt=pt, ph=ph, pw=pw,
-        w_mod=w_mod, act=act, dtype=sess.pv_dtype, n_prefix=n_prefix,
+        w_mod=w_mod, act=act, dtype=sess.pv_dtype, n_prefix=n_prefix, gw=gw if gw > 1 else 0,
     )
     if producer is not None:
         f.update(_pointwise_producer_fields(sess, producer, x, Cc))
@@ -381,7 +405,7 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
         psum = sess.alloc_raw(4 * x.B * nblk * pad8(Cc))
         f["psum"] = psum
     vin, vout = x.B * Ti * Hi * Wi, x.B * To * Ho * Wo
-    flops = 2 * vout * Cc * kt * kh * kw
+    flops = 2 * vout * Cc * kt * kh * kw * max(gw, 1)
     if producer is None:
         alg = sess.itemsize * (min(vin, vout * kt * kh * kw) + vout) * pad8(Cc)
         detail = "|%dx%dx%dx%d c%d k%dx%dx%d s%d%d%d%s" % (x.B, To, Ho, Wo, Cc, kt, kh, kw, st, sh, sw, " psum" if want_psum else "")

@@ -14,21 +14,38 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// one tap of a channel-wise grouped conv: output channel c of the chunk sums GW inputs of its own group
+template <int GW> __device__ __forceinline__ void grouped_taps(float (&acc)[8], const float (&f)[8], const float* wp, int w_p) {
+#pragma unroll
+  for (int j = 0; j < GW; ++j) {
+    const float4 w0v = *reinterpret_cast<const float4*>(wp + j * w_p);
+    const float4 w1v = *reinterpret_cast<const float4*>(wp + j * w_p + 4);
+    const float w[8] = {w0v.x, w0v.y, w0v.z, w0v.w, w1v.x, w1v.y, w1v.z, w1v.w};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] += f[(c / GW) * GW + j] * w[c];
+  }
+}
+
 // KW = 0 selects the fully runtime (one output per thread) variant.
 template <typename T, int KW, int SW, int NW>
 __global__ __launch_bounds__(kThreads) void dwconv_kernel(const pv_dwconv3d_desc d, int gpb,
-                                                          int wgroups, int units_per_batch) {
+                                                          int wgroups, int units_per_batch, int w_global) {
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   const int c_p = pv_round_up(d.C, 8);
   const int CG = c_p / 8;
   const int w_p = d.w_mod > 0 ? pv_round_up(d.w_mod, 8) : c_p;
   const int taps = d.kt * d.kh * d.kw;
-  float* s_w = s_mem;                 // [taps][w_p]
-  float* s_red = s_mem + taps * w_p;  // [gpb][c_p]   (psum only)
+  const int gw = d.gw > 1 ? d.gw : 1;  // input channels per output channel (grouped conv: KW == 0 variant only)
+  // filter taps in LDS, [taps][gw][w_p] -- unless they would not fit (grouped conv over hundreds of channels): then
+  // they are read where they lie (L1 / L2 hits: every workgroup reads the same few hundred KB)
+  const float* s_w = w_global ? d.w : s_mem;
+  float* s_red = s_mem + (w_global ? 0 : taps * gw * w_p);  // [gpb][c_p]   (psum only)
 
   const int tid = threadIdx.x;
-  for (int i = tid; i < taps * w_p; i += kThreads) s_w[i] = d.w[i];
-  __syncthreads();
+  if (!w_global) {
+    for (int i = tid; i < taps * gw * w_p; i += kThreads) s_mem[i] = d.w[i];
+    __syncthreads();
+  }
 
   const int cg = tid % CG;
   const int g = tid / CG;
@@ -70,13 +87,21 @@ __global__ __launch_bounds__(kThreads) void dwconv_kernel(const pv_dwconv3d_desc
             c.load(row + (long)wi * d.ldx);
             float f[8];
             c.to_f32(f);
-            const float* wp = s_w + ((dt * d.kh + dh) * d.kw + dw) * w_p + wc0;
-            const float4 w0v = *reinterpret_cast<const float4*>(wp);
-            const float4 w1v = *reinterpret_cast<const float4*>(wp + 4);
-            acc[0][0] += f[0] * w0v.x; acc[0][1] += f[1] * w0v.y;
-            acc[0][2] += f[2] * w0v.z; acc[0][3] += f[3] * w0v.w;
-            acc[0][4] += f[4] * w1v.x; acc[0][5] += f[5] * w1v.y;
-            acc[0][6] += f[6] * w1v.z; acc[0][7] += f[7] * w1v.w;
+            const float* wp = s_w + (((dt * d.kh + dh) * d.kw + dw) * gw) * w_p + wc0;
+            if (gw == 1) {
+              const float4 w0v = *reinterpret_cast<const float4*>(wp);
+              const float4 w1v = *reinterpret_cast<const float4*>(wp + 4);
+              acc[0][0] += f[0] * w0v.x; acc[0][1] += f[1] * w0v.y;
+              acc[0][2] += f[2] * w0v.z; acc[0][3] += f[3] * w0v.w;
+              acc[0][4] += f[4] * w1v.x; acc[0][5] += f[5] * w1v.y;
+              acc[0][6] += f[6] * w1v.z; acc[0][7] += f[7] * w1v.w;
+            } else if (gw == 2) {
+              grouped_taps<2>(acc[0], f, wp, w_p);
+            } else if (gw == 4) {
+              grouped_taps<4>(acc[0], f, wp, w_p);
+            } else {
+              grouped_taps<8>(acc[0], f, wp, w_p);
+            }
           }
         }
       }
@@ -412,7 +437,7 @@ __global__ __launch_bounds__(kPlaneThreads) void dw3_plane_kernel(const pv_dwcon
 
 // which layers the plane-streaming kernel takes, and with how many outputs per lane
 int plane_variant(const pv_dwconv3d_desc& d) {
-  if (d.dtype != PV_BF16 || (d.n_prefix != 0 && d.psum)) return 0;
+  if (d.dtype != PV_BF16 || (d.n_prefix != 0 && d.psum) || d.gw > 1) return 0;
   if (d.kt != 3 || d.kh != 3 || d.kw != 3 || d.st != 1 || d.pt != 1 || d.ph != 1 || d.pw != 1) return 0;
   if (d.sh != d.sw || (d.sw != 1 && d.sw != 2)) return 0;
   if (d.act != PV_ACT_NONE && d.act != PV_ACT_RELU && d.act != PV_ACT_SWISH) return 0;
@@ -446,7 +471,7 @@ template <int S, int NW> int launch_plane(const pv_dwconv3d_desc& d, hipStream_t
 }
 
 struct DwGeom {
-  int nw, gpb, wgroups, units_per_batch, nblk;
+  int nw, gpb, wgroups, units_per_batch, nblk, w_global;
   size_t lds;
 };
 
@@ -460,7 +485,7 @@ bool geom(const pv_dwconv3d_desc& d, DwGeom* g) {
   const int c_p = pv_round_up(d.C, 8);
   const int CG = c_p / 8;
   if (CG > kThreads) return false;
-  g->nw = variant_nw(d);
+  g->nw = d.gw > 1 ? 1 : variant_nw(d);
   g->gpb = kThreads / CG;
   g->wgroups = (d.Wo + g->nw - 1) / g->nw;
   const long upb = (long)d.To * d.Ho * g->wgroups;
@@ -468,7 +493,10 @@ bool geom(const pv_dwconv3d_desc& d, DwGeom* g) {
   g->units_per_batch = (int)upb;
   g->nblk = (int)pv_ceil_div(upb, g->gpb);
   const int w_p = d.w_mod > 0 ? pv_round_up(d.w_mod, 8) : c_p;
-  g->lds = sizeof(float) * ((size_t)d.kt * d.kh * d.kw * w_p + (d.psum ? (size_t)g->gpb * c_p : 0));
+  const size_t w_bytes = sizeof(float) * (size_t)d.kt * d.kh * d.kw * (d.gw > 1 ? d.gw : 1) * w_p;
+  const size_t red_bytes = sizeof(float) * (d.psum ? (size_t)g->gpb * c_p : 0);
+  g->w_global = w_bytes + red_bytes > 96 * 1024;
+  g->lds = (g->w_global ? 0 : w_bytes) + red_bytes;
   return true;
 }
 
@@ -481,7 +509,7 @@ int launch_variant(const pv_dwconv3d_desc& d, const DwGeom& g, hipStream_t s) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
   }
   dim3 grid(g.nblk, d.B), block(kThreads);
-  hipLaunchKernelGGL(kern, grid, block, g.lds, s, d, g.gpb, g.wgroups, g.units_per_batch);
+  hipLaunchKernelGGL(kern, grid, block, g.lds, s, d, g.gpb, g.wgroups, g.units_per_batch, g.w_global);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }
@@ -492,6 +520,7 @@ template <typename T> int launch_dw(const pv_dwconv3d_desc& d, const DwGeom& g, 
     hipLaunchKernelGGL(dw_prefix_kernel<T>, dim3((unsigned)pv_ceil_div(total, kThreads)), dim3(kThreads), 0, s, d);
     PV_LAUNCH_CHECK();
   }
+  if (d.gw > 1) return launch_variant<T, 0, 1, 1>(d, g, s);   // channel-wise grouped: the runtime variant
   if (d.kw == 3 && d.sw == 1) return launch_variant<T, 3, 1, 4>(d, g, s);
   if (d.kw == 3 && d.sw == 2) return launch_variant<T, 3, 2, 4>(d, g, s);
   if (d.kw == 1 && d.sw == 1) return launch_variant<T, 1, 1, 4>(d, g, s);
@@ -509,6 +538,8 @@ int validate(const pv_dwconv3d_desc& d) {
     return PV_ERR_INVALID;
   if (d.B > 65535) return PV_ERR_UNSUPPORTED;
   if (d.n_prefix < 0 || (d.n_prefix > 0 && d.psum)) return PV_ERR_INVALID;
+  if (d.gw < 0 || (d.gw > 1 && d.gw != 2 && d.gw != 4 && d.gw != 8)) return PV_ERR_UNSUPPORTED;
+  if (d.gw > 1 && (d.C % d.gw || d.w_mod > 0 || d.pw_w != nullptr)) return PV_ERR_INVALID;
   return PV_OK;
 }
 

@@ -9,7 +9,7 @@
 
 namespace {
 thread_local std::string g_last_error;
-constexpr int kAbiVersion = 17;
+constexpr int kAbiVersion = 18;
 }  // namespace
 
 int pv_set_hip_error(hipError_t e, const char* what) {

@@ -380,6 +380,41 @@ def test_first_layer_conv_two_outputs_per_mfma_column(B, T, H, W, cout, k, s, p)
     assert torch.all(y[..., cout:] == 0)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,H,W,Cn,gw,k,s,p", [
+    (2, 4, 9, 11, 32, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # create_csn(stage_conv_b_width_per_group=4)
+    (1, 3, 10, 7, 24, 2, (3, 3, 3), (1, 2, 2), (1, 1, 1)),     # strided, Cn not a multiple of 16
+    (1, 5, 6, 6, 40, 8, (3, 1, 1), (2, 1, 1), (1, 0, 0)),      # whole 8-channel chunks per group, temporal stride
+])
+def test_channelwise_grouped_conv(B, T, H, W, Cn, gw, k, s, p, dtype):
+    """pv_dwconv3d with gw input channels per output channel = nn.Conv3d(C, C, groups=C // gw) + BN + ReLU
+    (reference models/csn.py:34,169: conv_b_num_groups = dim_inner // stage_conv_b_width_per_group)."""
+    x = _rand((B, Cn, T, H, W), 301, dtype)
+    w = _rand((Cn, gw) + k, 302, torch.float32, (gw * k[0] * k[1] * k[2]) ** -0.5)
+    scale, shift = _rand((Cn,), 303, torch.float32) * 0.2 + 1.0, _rand((Cn,), 304, torch.float32) * 0.5
+    want = F.conv3d(x.float(), w, None, stride=s, padding=p, groups=Cn // gw)
+    want = F.relu(want * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1))
+    To, Ho, Wo = want.shape[2:]
+    cp = (Cn + 7) // 8 * 8
+    xl = torch.zeros(B, T, H, W, cp, dtype=dtype, device="cuda")
+    xl[..., :Cn] = x.permute(0, 2, 3, 4, 1)
+    taps = k[0] * k[1] * k[2]
+    wp = torch.zeros(taps, gw, cp, dtype=torch.float32, device="cuda")
+    wp[:, :, :Cn] = w.reshape(Cn, gw, taps).permute(2, 1, 0)
+    y = torch.full((B, To, Ho, Wo, cp), 5.0, dtype=dtype, device="cuda")
+    d = L.DwConv3dDesc()
+    d.x, d.w, d.y, d.scale, d.shift = xl.data_ptr(), wp.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr()
+    d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * cp, To * Ho * Wo * cp, cp, cp
+    d.B, d.Ti, d.Hi, d.Wi, d.C, d.To, d.Ho, d.Wo = B, T, H, W, Cn, To, Ho, Wo
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *s, *p)
+    d.act, d.dtype, d.gw = L.ACT_RELU, L.PV_F32 if dtype == torch.float32 else L.PV_BF16, gw
+    call("pv_dwconv3d", d)
+    assert rel_err(y[..., :Cn].permute(0, 4, 1, 2, 3).float(), want) <= (1e-5 if dtype == torch.float32 else 1e-2)
+    assert torch.all(y[..., Cn:] == 0)
+    d.gw = 3                                        # only 2 / 4 / 8 channels per group
+    assert L.lib().pv_dwconv3d(C.byref(d), None) == L.PV_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("B,T,H,W,cout,dk,act", [
     (2, 16, 30, 34, 24, 5, L.ACT_RELU),   # X3D stem: 1x3x3 s(1,2,2) 3->24, then depthwise 5x1x1, BN, ReLU
     (1, 4, 18, 22, 24, 5, L.ACT_RELU),    # clip shorter than one unrolled ring turn

@@ -281,7 +281,11 @@ def test_slowfast_variants_match_the_host_mirror(extra, alpha, dtype, tol):
     ("create_resnet", dict(model_depth=50, model_num_class=9, head_pool_kernel_size=(4, 2, 2),
                            stage_conv_b_dilation=((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 2, 2)),
                            stage_spatial_h_stride=(1, 2, 2, 1), stage_spatial_w_stride=(1, 2, 2, 1)), (1, 3, 4, 64, 64)),
-], ids=["csn_stem_pool", "r2plus1d_short", "resnet_dilated_res5"])
+    ("create_csn", dict(model_depth=50, model_num_class=9, head_pool_kernel_size=(1, 1, 1), stage_conv_b_width_per_group=4),
+     (2, 3, 4, 64, 64)),                               # channel-wise grouped conv_b, 4 channels per group (csn.py:34,169)
+    ("create_csn", dict(model_depth=50, model_num_class=9, head_pool_kernel_size=(1, 1, 1), stage_conv_b_width_per_group=16),
+     (1, 3, 4, 64, 64)),                               # 16 per group: block-diagonal dense weights
+], ids=["csn_stem_pool", "r2plus1d_short", "resnet_dilated_res5", "csn_group4", "csn_group16"])
 def test_resnet_family_variants_match_the_host_mirror(factory, cfg, shape, dtype, tol):
     """Other builders of the family, incl. the dilated res5 of slow_r50_detection's backbone (hub/resnet.py:72-88)."""
     import pytorchvideo_amd.models as M

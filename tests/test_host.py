@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from pytorchvideo_amd.accelerator import (EFFICIENT_BLOCK_TRANSMUTER_REGISTRY, EfficientBlockBase,
                                           transmute_model)
+from pytorchvideo_amd import _lib as L
 from pytorchvideo_amd.accelerator.mi355x import emit as E
 from pytorchvideo_amd.accelerator.mi355x.blocks import Mi355xBlock
 from pytorchvideo_amd.accelerator.mi355x.session import Session, _Arena
@@ -68,6 +69,37 @@ def test_plan_build_without_gpu_counts_ops():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):
             sess.finalize()  # no GPU -> loud failure, never a CPU fallback
+
+
+@pytest.mark.parametrize("width,label", [(4, "dwconv"), (16, "conv_b")])
+def test_grouped_conv_b_of_csn_is_planned_not_declined(width, label):
+    """create_csn(stage_conv_b_width_per_group=w) (reference models/csn.py:34,169): 2/4/8 channels per group ride in
+    the depthwise kernel (pv_dwconv3d_desc.gw), other widths become block-diagonal dense convs -- no block stays torch."""
+    from pytorchvideo_amd.models import create_csn
+    m = create_csn(model_depth=50, model_num_class=5, head_pool_kernel_size=(1, 1, 1), stage_conv_b_width_per_group=width).eval()
+    transmute_model(m, "mi355x")
+    assert all(isinstance(b, Mi355xBlock) for b in m.blocks)
+    sess, cur = Session(dtype=torch.bfloat16), None
+    for i, b in enumerate(m.blocks):
+        b.convert((1, 3, 4, 32, 32) if i == 0 else None, session=sess, input_ref=cur)
+        cur = b._out_ref
+    convs_b = [o for o in sess.ops if o[3].split("|")[0] == "conv_b"]
+    assert len(convs_b) == 16                                      # 3 + 4 + 6 + 3 bottlenecks
+    if width == 4:
+        assert all(o[0] == L.OP_DWCONV3D and o[2]["gw"] == 4 for o in convs_b)
+    else:
+        assert all(o[0] == L.OP_CONV3D for o in convs_b)
+
+
+def test_block_diagonal_expansion_of_a_grouped_conv_is_exact():
+    conv = nn.Conv3d(12, 18, (1, 3, 3), padding=(0, 1, 1), groups=3, bias=False)
+    x = torch.randn(1, 12, 2, 5, 5)
+    cg_in, cg_out = 4, 6
+    wd = torch.zeros(18, 12, 1, 3, 3)
+    for g in range(3):
+        wd[g * cg_out:(g + 1) * cg_out, g * cg_in:(g + 1) * cg_in] = conv.weight.detach()[g * cg_out:(g + 1) * cg_out]
+    with torch.no_grad():
+        assert torch.allclose(torch.nn.functional.conv3d(x, wd, padding=(0, 1, 1)), conv(x), atol=1e-6)
 
 
 def test_fold_norm_matches_batchnorm_eval():
