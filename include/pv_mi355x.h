@@ -313,8 +313,20 @@ typedef struct pv_rows_desc {
   int32_t g_period;                       /* layernorm: 0, or gamma/beta are [g_period][C] tables and row r */
                                           /* uses table row r % g_period (per-head norms of several tensors  */
                                           /* packed side by side, layers/attention.py:202-205); C <= 256    */
+  int32_t act;                            /* affine_rows only: PV_ACT_* applied after the affine map                */
+  int32_t n_prefix;                       /* affine_rows only: the first n_prefix rows of every rows_per_batch block */
+                                          /* (the cls token) pass through untouched                                 */
 } pv_rows_desc;
 int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream);
+/* BatchNorm in eval mode on token rows -- the norm="batchnorm" MViT (models/vision_transformers.py:336-339):
+ * y[r][c] = act(x[r][c] * gamma[c] + beta[c]) with gamma / beta the folded running statistics.
+ *   nn.BatchNorm1d block norms (layers/attention.py:738-753): x fp32 stream (x_f32) -> bf16 GEMM operand;
+ *   nn.BatchNorm3d(head_dim) + GELU BEFORE the pooling conv (layers/attention.py:186-190): in place on the q / k / v
+ *   columns of the qkv GEMM output (ldx = ldy = row stride, C = heads * head_dim with g_period = 0 and per-channel
+ *   tables repeated per head by the caller), cls rows skipped (rows_per_batch, n_prefix).
+ * gamma == NULL: scale 1; beta == NULL: shift 0 (a plain fp32 -> bf16 copy of rows, used for the cls rows of a head
+ * without a final norm). */
+int pv_affine_rows(const pv_rows_desc* d, pv_stream_t stream);
 int pv_softmax_rows(const pv_rows_desc* d, pv_stream_t stream);
 int pv_mean_rows(const pv_rows_desc* d, pv_stream_t stream);
 
@@ -408,7 +420,7 @@ enum pv_op_kind {
   PV_OP_CONV3D = 1, PV_OP_DWCONV3D = 2, PV_OP_SE_GATE = 3, PV_OP_POOL3D = 4,
   PV_OP_LAYERNORM = 5, PV_OP_SOFTMAX_ROWS = 6, PV_OP_MEAN_ROWS = 7, PV_OP_POSENC = 8,
   PV_OP_ATTENTION = 9, PV_OP_ADD_ACT = 10, PV_OP_INGEST = 11, PV_OP_EGRESS = 12, PV_OP_TOKEN_POOL = 13,
-  PV_OP_ROI_ALIGN = 14, PV_OP_LATERAL = 15
+  PV_OP_ROI_ALIGN = 14, PV_OP_LATERAL = 15, PV_OP_AFFINE_ROWS = 16
 };
 typedef struct pv_plan pv_plan;
 pv_plan* pv_plan_create(void);

@@ -368,6 +368,14 @@ def _ln(x, sd, p, eps=1e-6):
     return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps)
 
 
+def _block_norm(x, sd, p):
+    """norm1 / norm2 of a MultiScaleBlock: LayerNorm, or -- norm="batchnorm", models/vision_transformers.py:336-339 --
+    nn.BatchNorm1d over the channel dim in eval mode (layers/attention.py:738-753: permute, BN, permute back)."""
+    if (p + ".running_mean") in sd:
+        return _bn(x.permute(0, 2, 1), sd, p).permute(0, 2, 1)
+    return _ln(x, sd, p)
+
+
 def mvit_schedule(cfg):
     """Per-block (heads, kernel_q, stride_q, kernel_kv, stride_kv) of
     create_multiscale_vision_transformers (models/vision_transformers.py:394-445)."""
@@ -414,6 +422,10 @@ def _attention_pool(sd, t, thw, p, kernel, stride, has_cls, norm_p=None, pool_fn
     B, N, L, C = t.shape
     T, H, W = thw
     g = t.reshape(B * N, T, H, W, C).permute(0, 4, 1, 2, 3).contiguous()
+    bn_first = norm_p is not None and (norm_p + ".running_mean") in sd
+    if bn_first:   # BatchNorm3d(head_dim) + GELU BEFORE the pool, cls token aside (layers/attention.py:186-190)
+        g = F.gelu(_bn(g, sd, norm_p))
+        norm_p = None
     if pool_fn is not None:
         g = pool_fn(g)
     else:
@@ -433,7 +445,7 @@ def multiscale_block(sd, x, thw, p, heads, kq, sq, kkv, skv, has_cls=True, resid
     """MultiScaleBlock.forward (layers/attention.py:729-757) with MultiScaleAttention.forward
     (:501-544), pool_mode="conv", depthwise, separate q/k/v, layernorm."""
     B, N, _ = x.shape
-    xn = _ln(x, sd, p + ".norm1")
+    xn = _block_norm(x, sd, p + ".norm1")
     a = p + ".attn"
 
     def heads_of(t):
@@ -463,7 +475,7 @@ def multiscale_block(sd, x, thw, p, heads, kq, sq, kkv, skv, has_cls=True, resid
     else:
         x_res = x
     x = x_res + x_block
-    xn = _ln(x, sd, p + ".norm2")
+    xn = _block_norm(x, sd, p + ".norm2")
     h = F.gelu(F.linear(xn, sd[p + ".mlp.fc1.weight"], sd.get(p + ".mlp.fc1.bias")))
     x_mlp = F.linear(h, sd[p + ".mlp.fc2.weight"], sd.get(p + ".mlp.fc2.bias"))
     if (not dim_mul_in_att) and widen:
@@ -499,7 +511,8 @@ def mvit_forward(sd, x, cfg, return_blocks=False):
         y, thw = multiscale_block(sd, y, thw, "blocks.%d" % i, heads, kq, sq, kkv, skv, has_cls,
                                   cfg.get("residual_pool", False), cfg.get("dim_mul_in_att", False))
         outs.append(y)
-    y = _ln(y, sd, "norm_embed")
+    if "norm_embed.weight" in sd:   # (the norm="batchnorm" model has no final norm: vision_transformers.py:337,486)
+        y = _ln(y, sd, "norm_embed")
     # VisionTransformerBasicHead.forward (models/head.py:521-535), dropout = identity in eval
     y = y[:, 0] if has_cls else y.mean(1)
     y = F.linear(y, sd["head.proj.weight"], sd["head.proj.bias"])

@@ -16,7 +16,8 @@ PV_F32, PV_BF16, PV_U8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 POOL_MAX, POOL_AVG = 0, 1
 (OP_CONV3D, OP_DWCONV3D, OP_SE_GATE, OP_POOL3D, OP_LAYERNORM, OP_SOFTMAX_ROWS, OP_MEAN_ROWS,
- OP_POSENC, OP_ATTENTION, OP_ADD_ACT, OP_INGEST, OP_EGRESS, OP_TOKEN_POOL, OP_ROI_ALIGN, OP_LATERAL) = range(1, 16)
+ OP_POSENC, OP_ATTENTION, OP_ADD_ACT, OP_INGEST, OP_EGRESS, OP_TOKEN_POOL, OP_ROI_ALIGN, OP_LATERAL,
+ OP_AFFINE_ROWS) = range(1, 17)
 
 _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -68,7 +69,8 @@ LayoutDesc = _struct("LayoutDesc", [
 
 RowsDesc = _struct("RowsDesc", [
     ("x", _p), ("y", _p), ("gamma", _p), ("beta", _p), ("rows", _i64)]
-    + _ints("C", "ldx", "ldy", "rows_per_batch") + [("eps", _f32), ("dtype", _i32), ("x_f32", _i32), ("g_period", _i32)])
+    + _ints("C", "ldx", "ldy", "rows_per_batch") + [("eps", _f32), ("dtype", _i32), ("x_f32", _i32), ("g_period", _i32),
+                                                    ("act", _i32), ("n_prefix", _i32)])
 
 PosencDesc = _struct("PosencDesc", [
     ("x", _p), ("cls_token", _p), ("pos_spatial", _p), ("pos_temporal", _p), ("pos_class", _p)]
@@ -100,7 +102,7 @@ DESC_FOR_OP = {
     OP_CONV3D: Conv3dDesc, OP_DWCONV3D: DwConv3dDesc, OP_SE_GATE: SeGateDesc, OP_POOL3D: Pool3dDesc,
     OP_LAYERNORM: RowsDesc, OP_SOFTMAX_ROWS: RowsDesc, OP_MEAN_ROWS: RowsDesc, OP_POSENC: PosencDesc,
     OP_ATTENTION: AttentionDesc, OP_ADD_ACT: AddDesc, OP_INGEST: LayoutDesc, OP_EGRESS: LayoutDesc,
-    OP_TOKEN_POOL: TokenPoolDesc, OP_ROI_ALIGN: RoiAlignDesc, OP_LATERAL: LateralDesc,
+    OP_TOKEN_POOL: TokenPoolDesc, OP_ROI_ALIGN: RoiAlignDesc, OP_LATERAL: LateralDesc, OP_AFFINE_ROWS: RowsDesc,
 }
 
 # every symbol the header declares: (name, restype, argtypes)
@@ -120,6 +122,7 @@ _SYMBOLS = [
     ("pv_ingest_ncdhw", C.c_int, [C.POINTER(LayoutDesc), _p]),
     ("pv_egress_ncdhw", C.c_int, [C.POINTER(LayoutDesc), _p]),
     ("pv_layernorm", C.c_int, [C.POINTER(RowsDesc), _p]),
+    ("pv_affine_rows", C.c_int, [C.POINTER(RowsDesc), _p]),
     ("pv_softmax_rows", C.c_int, [C.POINTER(RowsDesc), _p]),
     ("pv_mean_rows", C.c_int, [C.POINTER(RowsDesc), _p]),
     ("pv_add_posenc", C.c_int, [C.POINTER(PosencDesc), _p]),
@@ -142,7 +145,7 @@ _SYMBOLS = [
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _lib = None
 

@@ -79,6 +79,76 @@ def emit_layernorm(sess, norm, x, out=None, rows=None, ldx=None, label="layernor
     return y
 
 
+def _bn_affine(norm, C):
+    """Folded eval-mode BatchNorm: per-channel (gamma, beta) with y = x * gamma + beta."""
+    if norm.running_mean is None or norm.num_features != C:
+        raise Unsupported("BatchNorm without running statistics / channel mismatch")
+    g = (norm.running_var.detach().double() + norm.eps).rsqrt()
+    if norm.weight is not None:
+        g = g * norm.weight.detach().double()
+    b = -norm.running_mean.detach().double() * g
+    if norm.bias is not None:
+        b = b + norm.bias.detach().double()
+    return g.float(), b.float()
+
+
+def emit_affine_rows(sess, x, gamma, beta, act=L.ACT_NONE, out=None, rows=None, ldx=None, rows_per_batch=0, n_prefix=0,
+                     label="batchnorm"):
+    """y = act(x * gamma + beta) on token rows (pv_affine_rows): BatchNorm in eval mode for the norm="batchnorm" MViT
+    (reference models/vision_transformers.py:336-339).  `out=None`: a new bf16 operand tensor; `out is x`: in place."""
+    y = out if out is not None else sess.alloc_act(x.B, x.T, x.H, x.W, x.C)
+    if y is not x:
+        y.thw, y.has_cls = x.thw, x.has_cls
+    if y.f32 and sess.pv_dtype != L.PV_F32 and y is not x:
+        raise Unsupported("fp32 output in a bf16 session")
+    n_rows = x.B * x.voxels if rows is None else rows
+    f = dict(x=x.ptr, y=y.ptr, gamma=sess.add_weight(gamma) if gamma is not None else None,
+             beta=sess.add_weight(beta) if beta is not None else None,
+             rows=n_rows, C=x.C, ldx=x.ld if ldx is None else ldx, ldy=y.ld, rows_per_batch=rows_per_batch, eps=0.0,
+             dtype=sess.pv_dtype, x_f32=1 if (x.f32 and sess.pv_dtype != L.PV_F32) else 0, g_period=0,
+             act=act, n_prefix=n_prefix)
+    sess.add_op(L.OP_AFFINE_ROWS, f, label=label, alg_bytes=(x.itemsize + sess.itemsize) * n_rows * pad8(x.C))
+    return y
+
+
+def emit_block_norm(sess, norm, x, label):
+    """norm1 / norm2 of a MultiScaleBlock: LayerNorm, or BatchNorm1d over the channel dim (attention.py:738-753)."""
+    if isinstance(norm, nn.BatchNorm1d):
+        if x.bs != x.voxels * x.ld:
+            raise Unsupported("BatchNorm1d on a non-dense token tensor")
+        g, b = _bn_affine(norm, x.C)
+        return emit_affine_rows(sess, x, g, b, label=label)
+    return emit_layernorm(sess, norm, x, label=label)
+
+
+class _PoolAfterNorm:
+    """View of an _AttentionPool whose norm (BatchNorm3d + GELU BEFORE the pool, attention.py:186-190) has already
+    been applied to its input: what is left is the pool and the cls pass-through."""
+    has_norm, norm_before_pool, norm = False, False, None
+
+    def __init__(self, ap):
+        self.has_pool, self.pool, self.has_cls_embed = ap.has_pool, ap.pool, ap.has_cls_embed
+
+
+def emit_norm_before_pool(sess, ap, x, heads, label):
+    """BatchNorm3d(head_dim) (or Identity) + GELU on the non-cls tokens of `x`, in place; returns the pool view."""
+    if not ap.has_pool or not (ap.has_norm and ap.norm_before_pool):
+        return ap
+    hd = x.C // heads
+    norm = ap.norm
+    if isinstance(norm, nn.Identity):
+        g = b = None
+    elif isinstance(norm, nn.BatchNorm3d):
+        g, b = _bn_affine(norm, hd)
+        g, b = g.repeat(heads), b.repeat(heads)          # the same statistics for every head (tensor is (B*heads, hd, T, H, W))
+    else:
+        raise Unsupported("pre-pooling norm %s" % _cls_name(norm))
+    n_prefix = 1 if ap.has_cls_embed else 0
+    emit_affine_rows(sess, x, g, b, act=L.ACT_GELU, out=x, rows=x.B * x.voxels, rows_per_batch=x.voxels,
+                     n_prefix=n_prefix, label=label + ".bn_gelu")
+    return _PoolAfterNorm(ap)
+
+
 def emit_head_layernorm(sess, norm, x, heads, label="pool.norm"):
     """LayerNorm(head_dim) applied to every (token, head) of a dense (B, N, heads*head_dim)
     tensor, in place (reference: _AttentionPool norm after pool, attention.py:202-205)."""
@@ -327,8 +397,9 @@ def emit_multiscale_attention(sess, attn, xn, residual, label="attn"):
             t = qkv.channel_slice(i * attn.dim_out, attn.dim_out)
             t.thw, t.has_cls = xn.thw, xn.has_cls
             parts.append(t)
-        pools = (attn._attention_pool_q, attn._attention_pool_k, attn._attention_pool_v)
         names = (".pool_q", ".pool_k", ".pool_v")
+        pools = tuple(emit_norm_before_pool(sess, ap, t, heads, label + n) for ap, t, n in
+                      zip((attn._attention_pool_q, attn._attention_pool_k, attn._attention_pool_v), parts, names))
         outs = list(parts)
         big = [i for i in range(3) if _streams_well(pools[i], parts[i])]
         kv = None
@@ -367,13 +438,11 @@ def emit_multiscale_attention(sess, attn, xn, residual, label="attn"):
 
 def emit_multiscale_block(sess, blk, x):
     """MultiScaleBlock.forward (attention.py:729-757).  Consumes nothing: the caller releases x."""
-    if blk.norm1_is_batchnorm_1d or blk.norm2_is_batchnorm_1d:
-        raise Unsupported("BatchNorm1d block norm")
     if not isinstance(blk.drop_path, nn.Identity) and _cls_name(blk.drop_path) != "DropPath":
         raise Unsupported("drop_path %s" % _cls_name(blk.drop_path))
     act = E.act_code(blk.mlp.act)
     widen = blk.dim != blk.dim_out
-    xn = emit_layernorm(sess, blk.norm1, x, label="norm1")
+    xn = emit_block_norm(sess, blk.norm1, x, label="norm1")
     skip_src = x
     if blk.dim_mul_in_att and widen:
         skip_src = emit_linear(sess, blk.proj, xn, y_f32=True, label="proj_dim")
@@ -389,7 +458,7 @@ def emit_multiscale_block(sess, blk, x):
         sess.release(x_res)
     if skip_src is not x:
         sess.release(skip_src)
-    xn2 = emit_layernorm(sess, blk.norm2, x1, label="norm2")
+    xn2 = emit_block_norm(sess, blk.norm2, x1, label="norm2")
     hmid = emit_linear(sess, blk.mlp.fc1, xn2, act=act, label="mlp.fc1")
     if (not blk.dim_mul_in_att) and widen:
         res2 = emit_linear(sess, blk.proj, xn2, y_f32=True, label="proj_dim")
@@ -470,11 +539,17 @@ def emit_vit_head(sess, norm_embed, head, x):
         raise Unsupported("head without sequence pooling")
     if sp.mode == "cls":
         pooled = sess.alloc_act(x.B, 1, 1, 1, x.C)
-        if isinstance(norm_embed, nn.Identity):
-            raise Unsupported("cls pooling without final norm")
-        emit_layernorm(sess, norm_embed, x, out=pooled, rows=x.B, ldx=x.bs, label="norm_embed")
+        if isinstance(norm_embed, nn.Identity):   # norm="batchnorm" models have no final norm: the cls rows as they are
+            emit_affine_rows(sess, x, None, None, out=pooled, rows=x.B, ldx=x.bs, label="cls_rows")
+        else:
+            emit_layernorm(sess, norm_embed, x, out=pooled, rows=x.B, ldx=x.bs, label="norm_embed")
     elif sp.mode == "mean":
-        xn = x if isinstance(norm_embed, nn.Identity) else emit_layernorm(sess, norm_embed, x, label="norm_embed")
+        if not isinstance(norm_embed, nn.Identity):
+            xn = emit_layernorm(sess, norm_embed, x, label="norm_embed")
+        elif x.f32 and sess.pv_dtype != L.PV_F32:      # no final norm: the fp32 stream as a bf16 operand of the mean
+            xn = emit_affine_rows(sess, x, None, None, label="stream_rows")
+        else:
+            xn = x
         pooled32 = sess.alloc_act(x.B, 1, 1, 1, x.C, f32=True)
         f = dict(x=xn.ptr, y=pooled32.ptr, gamma=None, beta=None, rows=x.B * x.voxels, C=x.C, ldx=xn.ld,
                  ldy=pooled32.ld, rows_per_batch=x.voxels, eps=0.0, dtype=sess.pv_dtype, x_f32=0)

@@ -905,6 +905,59 @@ static int rows_check(const pv_rows_desc* d) {
   return PV_OK;
 }
 
+// BatchNorm (eval) on token rows: y = act(x * gamma + beta), 8 channels per thread, rows over the grid.
+// TX = float: fp32 stream in, T out (the block norms); TX = T: same type, in place allowed (the pre-pooling norm).
+template <typename TX, typename T>
+__global__ __launch_bounds__(kThreads) void affine_rows_kernel(const pv_rows_desc d, long total, int CG) {
+  for (long id = (long)blockIdx.x * kThreads + threadIdx.x; id < total; id += (long)gridDim.x * kThreads) {
+    const long row = id / CG;
+    const int c0 = (int)(id - row * CG) * 8;
+    const bool skip = d.rows_per_batch > 0 && (int)(row % d.rows_per_batch) < d.n_prefix;
+    const TX* xp = static_cast<const TX*>(d.x) + row * d.ldx + c0;
+    T* yp = static_cast<T*>(d.y) + row * d.ldy + c0;
+    if (skip && static_cast<const void*>(xp) == static_cast<const void*>(yp)) continue;
+    float v[8];
+    Chunk8<TX> in;
+    in.load(xp);
+    in.to_f32(v);
+    if (!skip) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = c0 + j < d.C;
+        const float g = ok ? (d.gamma ? d.gamma[c0 + j] : 1.f) : 0.f;
+        const float b = ok ? (d.beta ? d.beta[c0 + j] : 0.f) : 0.f;
+        v[j] = v[j] * g + b;
+      }
+      pv_apply_act_n<sizeof(T) == 2>(v, d.act);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (c0 + j >= d.C) v[j] = 0.f;
+    }
+    Chunk8<T> o;
+    o.from_f32(v);
+    o.store(yp);
+  }
+}
+
+extern "C" int pv_affine_rows(const pv_rows_desc* d, pv_stream_t stream) {
+  int v = rows_check(d);
+  if (v != PV_OK) return v;
+  if (d->ldx % 8 || d->ldy % 8 || d->g_period != 0 || d->n_prefix < 0 || d->rows_per_batch < 0) return PV_ERR_INVALID;
+  if (d->n_prefix > 0 && d->rows_per_batch <= 0) return PV_ERR_INVALID;
+  const int CG = pv_round_up(d->C, 8) / 8;
+  const long total = d->rows * CG;
+  long nb = pv_ceil_div(total, kThreads);
+  nb = nb < 8192 ? nb : 8192;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)nb), block(kThreads);
+  if (d->dtype == PV_BF16 && d->x_f32) hipLaunchKernelGGL((affine_rows_kernel<float, bf16_t>), grid, block, 0, s, *d, total, CG);
+  else if (d->dtype == PV_BF16) hipLaunchKernelGGL((affine_rows_kernel<bf16_t, bf16_t>), grid, block, 0, s, *d, total, CG);
+  else if (d->dtype == PV_F32) hipLaunchKernelGGL((affine_rows_kernel<float, float>), grid, block, 0, s, *d, total, CG);
+  else return PV_ERR_UNSUPPORTED;
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
 extern "C" int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream) {
   int v = rows_check(d);
   if (v != PV_OK) return v;

@@ -9,7 +9,7 @@
 
 namespace {
 thread_local std::string g_last_error;
-constexpr int kAbiVersion = 18;
+constexpr int kAbiVersion = 19;
 }  // namespace
 
 int pv_set_hip_error(hipError_t e, const char* what) {
@@ -71,7 +71,8 @@ size_t desc_size(int kind) {
     case PV_OP_POOL3D: return sizeof(pv_pool3d_desc);
     case PV_OP_LAYERNORM:
     case PV_OP_SOFTMAX_ROWS:
-    case PV_OP_MEAN_ROWS: return sizeof(pv_rows_desc);
+    case PV_OP_MEAN_ROWS:
+    case PV_OP_AFFINE_ROWS: return sizeof(pv_rows_desc);
     case PV_OP_POSENC: return sizeof(pv_posenc_desc);
     case PV_OP_ATTENTION: return sizeof(pv_attention_desc);
     case PV_OP_ADD_ACT: return sizeof(pv_add_desc);
@@ -102,6 +103,7 @@ int run_op(const pv_plan::Op& op, pv_stream_t s) {
     case PV_OP_TOKEN_POOL: return pv_token_pool(static_cast<const pv_token_pool_desc*>(p), s);
     case PV_OP_ROI_ALIGN: return pv_roi_align(static_cast<const pv_roi_align_desc*>(p), s);
     case PV_OP_LATERAL: return pv_lateral_fuse(static_cast<const pv_lateral_desc*>(p), s);
+    case PV_OP_AFFINE_ROWS: return pv_affine_rows(static_cast<const pv_rows_desc*>(p), s);
     default: return PV_ERR_INVALID;
   }
 }

@@ -380,6 +380,44 @@ def test_first_layer_conv_two_outputs_per_mfma_column(B, T, H, W, cout, k, s, p)
     assert torch.all(y[..., cout:] == 0)
 
 
+@pytest.mark.parametrize("mode", ["block_norm", "pre_pool", "copy_rows"])
+def test_affine_rows_is_batchnorm_eval_on_tokens(mode):
+    """pv_affine_rows: nn.BatchNorm1d block norms (fp32 stream -> bf16 operand), nn.BatchNorm3d(head_dim) + GELU before
+    the pooling conv in place on a column slice with the cls rows untouched (reference layers/attention.py:186-190,
+    738-753), and the plain fp32 -> bf16 row copy used for the cls rows of a head without a final norm."""
+    B, N, Cn = 3, 37, 88
+    g, b = _rand((Cn,), 311, torch.float32) * 0.3 + 1.0, _rand((Cn,), 312, torch.float32) * 0.4
+    d = L.RowsDesc()
+    if mode == "block_norm":
+        x = _rand((B, N, Cn), 313, torch.float32)
+        y = torch.full((B, N, Cn), 7.0, dtype=torch.bfloat16, device="cuda")
+        want = x * g + b
+        d.x, d.y, d.gamma, d.beta = x.data_ptr(), y.data_ptr(), g.data_ptr(), b.data_ptr()
+        d.rows, d.C, d.ldx, d.ldy, d.dtype, d.x_f32 = B * N, Cn, Cn, Cn, L.PV_BF16, 1
+        call("pv_affine_rows", d)
+        assert rel_err(y.float(), want) <= 4e-3
+    elif mode == "pre_pool":
+        ld = 3 * Cn                                   # the k slice of a qkv GEMM output
+        buf = _rand((B, N, ld), 314, torch.bfloat16)
+        before = buf.clone()
+        want = F.gelu(before[:, :, Cn:2 * Cn].float() * g + b)
+        d.x = d.y = buf.data_ptr() + Cn * 2
+        d.gamma, d.beta = g.data_ptr(), b.data_ptr()
+        d.rows, d.C, d.ldx, d.ldy, d.dtype = B * N, Cn, ld, ld, L.PV_BF16
+        d.rows_per_batch, d.n_prefix, d.act = N, 1, L.ACT_GELU
+        call("pv_affine_rows", d)
+        assert rel_err(buf[:, 1:, Cn:2 * Cn].float(), want[:, 1:]) <= 8e-3
+        assert torch.equal(buf[:, 0], before[:, 0])                                   # cls rows untouched
+        assert torch.equal(buf[:, :, :Cn], before[:, :, :Cn]) and torch.equal(buf[:, :, 2 * Cn:], before[:, :, 2 * Cn:])
+    else:
+        x = _rand((B, N, Cn), 315, torch.float32)     # row 0 of every batch item -> dense [B, C]
+        y = torch.full((B, Cn), 7.0, dtype=torch.bfloat16, device="cuda")
+        d.x, d.y = x.data_ptr(), y.data_ptr()
+        d.rows, d.C, d.ldx, d.ldy, d.dtype, d.x_f32 = B, Cn, N * Cn, Cn, L.PV_BF16, 1
+        call("pv_affine_rows", d)
+        assert torch.equal(y, x[:, 0].bfloat16())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,T,H,W,Cn,gw,k,s,p", [
     (2, 4, 9, 11, 32, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # create_csn(stage_conv_b_width_per_group=4)

@@ -28,6 +28,8 @@ def _golden_case(name, factory):
     g = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
     m = factory(**g["cfg"])
     deterministic_fill(m, g["seed"]).eval()
+    if g.get("state_override"):      # e.g. calibrated BatchNorm statistics (tests/golden/make_golden.py)
+        m.load_state_dict(g["state_override"], strict=False)
     shapes = g["input_shape"]
     if isinstance(shapes[0], (tuple, list)):
         fast = seeded_input(shapes[1], g["seed"])
@@ -49,7 +51,7 @@ def _oracle(sd, x, dtype, fn):
 
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)
-@pytest.mark.parametrize("name", ["mvit_b_small", "mvit_v2ish_small"])
+@pytest.mark.parametrize("name", ["mvit_b_small", "mvit_v2ish_small", "mvit_bn_small"])
 def test_mvit_matches_oracle(name, dtype, tol):
     from pytorchvideo_amd.models import create_multiscale_vision_transformers
     g, m, x = _golden_case(name, create_multiscale_vision_transformers)
@@ -60,6 +62,14 @@ def test_mvit_matches_oracle(name, dtype, tol):
     assert type(dm.blocks[0]).__name__ == "Mi355xMViTBlock" and dm.blocks[0].convert_flag
     got = dm(xd)
     assert got.shape == want.shape
+    if name == "mvit_bn_small" and dtype == torch.bfloat16:
+        # The BatchNorm variant (no per-token renormalisation anywhere) is the most rounding-sensitive of the three
+        # instances: storing only its WEIGHTS and input in bf16 and evaluating in exact fp32 on the CPU -- no kernel
+        # involved -- already moves the logits by 1.6e-2 (LayerNorm instances: 3e-3 / 8e-3; tools/mvit_variant_errors.py).
+        # Activation storage in bf16 perturbs every layer by the same 2^-9 relative amount, so the kernel-isolating
+        # error is bounded by that measured figure (x 1.5), not by the 1e-2 of the better-conditioned instances.
+        want32 = OF.mvit_forward(m.state_dict(), x, g["cfg"])
+        tol = max(tol, 1.5 * rel_err(want, want32))
     assert rel_err(got, want) <= tol
     assert torch.equal(dm(xd), got)  # graph replay, no atomics: bitwise reproducible
 

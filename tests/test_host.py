@@ -91,6 +91,29 @@ def test_grouped_conv_b_of_csn_is_planned_not_declined(width, label):
         assert all(o[0] == L.OP_CONV3D for o in convs_b)
 
 
+def test_batchnorm_mvit_blocks_are_transmuted_and_planned():
+    """create_multiscale_vision_transformers(norm="batchnorm") (reference models/vision_transformers.py:336-339): BatchNorm1d
+    block norms and BatchNorm3d + GELU before the pooling convs become pv_affine_rows launches -- no block stays torch."""
+    from pytorchvideo_amd.accelerator.mi355x import emit_mvit as EM
+    from pytorchvideo_amd.models import create_multiscale_vision_transformers
+    m = create_multiscale_vision_transformers(
+        spatial_size=64, temporal_size=4, depth=2, head_num_classes=5, norm="batchnorm", embed_dim_mul=[[1, 2.0]],
+        atten_head_mul=[[1, 2.0]], pool_q_stride_size=[[1, 1, 2, 2]], pool_kv_stride_adaptive=[1, 4, 4],
+        pool_kvq_kernel=[3, 3, 3]).eval()
+    transmute_model(m, "mi355x")
+    assert all(type(b).__name__ == "Mi355xMViTBlock" for b in m.blocks)
+    sess = Session(dtype=torch.bfloat16)
+    x = sess.alloc_act(1, 1, 1, 2 * 16 * 16 + 1, m.blocks[1].dim, f32=True)
+    x.thw, x.has_cls = (2, 16, 16), True
+    EM.emit_multiscale_block(sess, m.blocks[1], x)
+    labels = [o[3].split("|")[0] for o in sess.ops]
+    assert labels.count("norm1") == 1 and labels.count("norm2") == 1 and not any("layernorm" in l for l in labels)
+    assert all(o[0] == L.OP_AFFINE_ROWS for o in sess.ops if o[3] in ("norm1", "norm2"))
+    bn = [o for o in sess.ops if o[3].endswith(".bn_gelu")]
+    assert len(bn) == 3 and all(o[2]["act"] == L.ACT_GELU and o[2]["n_prefix"] == 1 for o in bn)    # q, k and v
+    assert not any(o[0] == L.OP_LAYERNORM for o in sess.ops)
+
+
 def test_block_diagonal_expansion_of_a_grouped_conv_is_exact():
     conv = nn.Conv3d(12, 18, (1, 3, 3), padding=(0, 1, 1), groups=3, bias=False)
     x = torch.randn(1, 12, 2, 5, 5)
