@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pytorchvideo_amd import _lib as L
 
+ACT = L.ACT_RELU     # --act=gelu|none|relu
+
 SHAPES = [  # (label, B, T,H,W in, cin, cout, k(t,h,w), s(t,h,w), p)
     ("mvit qkv b0   M401k K96  N288", 8, 1, 1, 50177, 96, 288, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("mvit fc1 b0   M401k K96  N384", 8, 1, 1, 50177, 96, 384, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
@@ -61,7 +63,7 @@ def run(label, B, T, H, W, cin, cout, k, s, p, iters=20):
     d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * cin, To * Ho * Wo * cp, cin, cp
     d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, cin, To, Ho, Wo, cout
     d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *s, *p)
-    d.act, d.a_act, d.dtype = L.ACT_RELU, L.ACT_NONE, L.PV_BF16
+    d.act, d.a_act, d.dtype = ACT, L.ACT_NONE, L.PV_BF16
     lib = L.lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
@@ -79,7 +81,10 @@ def run(label, B, T, H, W, cin, cout, k, s, p, iters=20):
 
 
 if __name__ == "__main__":
-    sel = [a for a in sys.argv[1:] if not a.startswith("--tune=")]
+    sel = [a for a in sys.argv[1:] if not a.startswith("--")]
+    for a in sys.argv[1:]:
+        if a.startswith("--act="):
+            ACT = {"gelu": L.ACT_GELU, "none": L.ACT_NONE, "relu": L.ACT_RELU}[a[6:]]
     for a in sys.argv[1:]:
         if a.startswith("--tune="):      # e.g. --tune=gemm8=0,conv_route=2
             from pytorchvideo_amd.accelerator.mi355x import tuning
