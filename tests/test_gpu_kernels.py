@@ -60,6 +60,10 @@ def _run_attention(q, k, v, heads, scale, residual_q, pad=0):
     (3, 1, 32, 7, 5, False),         # smaller than one tile
     (1, 2, 64, 200, 130, True),
     (1, 1, 128, 140, 70, False),
+    (1, 2, 96, 70, 64, False),       # exactly one full key tile (pipelined kernel: prologue + last step only)
+    (1, 1, 96, 130, 128, True),      # two full tiles: nothing to mask in the last one
+    (2, 1, 64, 40, 192, False),      # three full tiles, odd tile count
+    (1, 1, 32, 300, 256, False),     # four full tiles, head_dim 32 (side work spread over 4 PV MFMAs)
 ])
 def test_attention_matches_reference(dtype, B, heads, hd, Nq, Nk, res):
     Cw = heads * hd
