@@ -474,6 +474,197 @@ __global__ __launch_bounds__(kThreads) void stem7_kernel(const pv_conv3d_desc d,
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// MViT patch embedding: (kt,7,7) conv, stride (st,4,4), 3 -> 96 channels, fp32 tokens + position tables
+// (models/stem.py:289-338, models/vision_transformers.py:357-368).
+//
+// 96 x 672 filter values are 126 KB as MFMA fragments: with them in LDS no input tile fits beside them twice, and the
+// generic kernel above re-gathers every window through L1 (PMC: 736 MB per launch against 257 MB algorithmic).  Here the
+// FILTER never enters LDS: wave w owns output channels 16w..16w+15 and streams its kt * 7 A fragments (one per (dt, dh)
+// window row: kw = 7 padded to 8 voxels x 4 channels = one K = 32 step) from L2 into registers, one temporal tap ahead; LDS holds only the input halo tile of the kt frames (8 x 16 outputs: 35 x 68 voxels x 8 B per frame),
+// staged once and read by every wave -- the B operand of output column n, voxel pair q is ONE aligned 16-byte
+// ds_read at a compile-time offset (the halo is zero-filled at staging time: no tap table, no bounds tests).
+// 57 KB of LDS and ~170 VGPRs: two workgroups per CU, one loading while the other multiplies.
+template <int KT, int NW>
+__global__ __launch_bounds__(NW * 64, 3) void stem_pe_kernel(const pv_conv3d_desc d, int tiles_h, int tiles_w, int wpitch) {
+  constexpr int TH = 8, TW = 16, S = 4;
+  constexpr int IH = (TH - 1) * S + 7;       // 35 input rows
+  constexpr int IW = (TW - 1) * S + 8;       // 68 input columns = 34 voxel pairs
+  constexpr int HP = IW / 4;                 // 17 even (or odd) pairs per row
+  constexpr int NVOX = IH * IW;
+  constexpr int NTHR = NW * 64;
+  constexpr int NLD = (NVOX + NTHR - 1) / NTHR;   // 8-byte loads per thread per frame
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // [KT][IH][even pairs 0..16 | odd pairs 0..16][2 voxels][4]: output column n reads pair 2n + q -- with the pairs of
+  // one parity stored contiguously the 16 lanes of a ds_read_b128 phase touch 16 consecutive 16-byte chunks (the
+  // natural layout would put lanes n and n + 8 on the same banks: columns are 32 bytes apart)
+  bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, q = lane >> 4;
+  int bid = blockIdx.x;
+  const int tw = bid % tiles_w; bid /= tiles_w;
+  const int th = bid % tiles_h; bid /= tiles_h;
+  const int to = bid % d.To;
+  const int b = bid / d.To;
+  const int ho0 = th * TH, wo0 = tw * TW;
+  const int hi0 = ho0 * S - 3, wi0 = wo0 * S - 3, ti0 = to * d.st - d.pt;
+
+  constexpr unsigned kOOB = 0x80000000u;
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const bf16_t* X = static_cast<const bf16_t*>(d.x) + (long)b * d.x_bs;
+  const unsigned frame_bytes = (unsigned)(d.Hi * d.Wi) * 8u;
+  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)(frame_bytes * (unsigned)d.Ti), 0x00020000);
+  // per-thread staging geometry of one frame (the same for every frame): global byte offset, LDS element index
+  unsigned g_off[NLD];
+  int l_idx[NLD];
+#pragma unroll
+  for (int n = 0; n < NLD; ++n) {
+    const int i = tid + n * NTHR;
+    const int ir = i / IW, ic = i - ir * IW;
+    const int hi = hi0 + ir, wi = wi0 + ic;
+    const bool ok = i < NVOX && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
+    g_off[n] = ok ? (unsigned)(hi * d.Wi + wi) * 8u : kOOB;
+    const int pr = ic >> 1;
+    l_idx[n] = i < NVOX ? ((ir * (IW / 2) + (pr & 1) * HP + (pr >> 1)) * 2 + (ic & 1)) * 4 : -1;
+  }
+  u32x2 st[2][NLD];   // two frames in flight
+  auto load_frame = [&](int fr) {
+    const int ti = ti0 + fr;
+    const bool live = (unsigned)ti < (unsigned)d.Ti;
+#pragma unroll
+    for (int n = 0; n < NLD; ++n)
+      st[fr & 1][n] = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)((live && g_off[n] != kOOB) ? g_off[n] + (unsigned)ti * frame_bytes : kOOB), 0, 0);
+  };
+  auto store_frame = [&](int fr) {
+#pragma unroll
+    for (int n = 0; n < NLD; ++n)
+      if (l_idx[n] >= 0) *reinterpret_cast<u32x2*>(tile + (size_t)fr * NVOX * 4 + l_idx[n]) = st[fr & 1][n];
+  };
+
+  load_frame(0);
+  if (KT > 1) load_frame(1);
+  // ---- this wave's filter rows as A fragments, streamed from L2 one temporal tap ahead of their use: every fragment
+  //      feeds exactly 8 MFMAs of this workgroup, so nothing is gained by holding all kt * 7 of them (84 VGPRs) ----
+  const int ch = wave * 16 + n16;
+  const bf16_t* __restrict__ Wt = static_cast<const bf16_t*>(d.w) + (long)(ch < d.cout ? ch : 0) * KT * 7 * wpitch + q * 8;
+  bf16x8 areg[2][7];
+  auto load_a = [&](int dt, bf16x8 (&a)[7]) {
+#pragma unroll
+    for (int dh = 0; dh < 7; ++dh) {
+      a[dh] = *reinterpret_cast<const bf16x8*>(Wt + (long)(dt * 7 + dh) * wpitch);
+      if (ch >= d.cout) a[dh] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  };
+  load_a(0, areg[0]);
+#pragma unroll
+  for (int fr = 0; fr < KT; ++fr) {
+    store_frame(fr);
+    if (fr + 2 < KT) load_frame(fr + 2);
+  }
+  __syncthreads();
+
+  // ---- 8 output rows x 16 columns x this wave's 16 channels ----
+  f32x4 acc[TH];
+#pragma unroll
+  for (int r = 0; r < TH; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16_t* bbase = tile + ((q & 1) * HP + n16 + (q >> 1)) * 8;   // pair 2 n16 + q: parity q & 1, index n16 + q / 2
+#pragma unroll
+  for (int dt = 0; dt < KT; ++dt) {
+    if (dt + 1 < KT) load_a(dt + 1, areg[(dt + 1) & 1]);
+#pragma unroll
+    for (int dh = 0; dh < 7; ++dh) {
+      const bf16x8 af = areg[dt & 1][dh];
+#pragma unroll
+      for (int r = 0; r < TH; ++r) {
+        const bf16x8 bfv = *reinterpret_cast<const bf16x8*>(bbase + ((size_t)dt * NVOX + (S * r + dh) * IW) * 4);
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfv, acc[r], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keeps tap dt+2's fragment loads from being hoisted up here (registers)
+  }
+
+  // ---- epilogue: lane holds channels 16*wave + 4q .. +3 of column n16 for every row ----
+  const int c0 = wave * 16 + 4 * q;
+  const int wo = wo0 + n16;
+  if (c0 >= pv_round_up(d.cout, 8) || wo >= d.Wo) return;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool ok = c0 + j < d.cout;
+    sc[j] = ok ? (d.scale ? d.scale[c0 + j] : 1.f) : 0.f;
+    sh[j] = ok ? (d.shift ? d.shift[c0 + j] : 0.f) : 0.f;
+  }
+  // every position-table value of the tile is requested BEFORE the first store: the compiler cannot prove that y does
+  // not alias the tables and would otherwise wait for each row's loads behind the previous row's store (8 round trips)
+  float pos[TH][4];
+#pragma unroll
+  for (int r = 0; r < TH; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pos[r][j] = 0.f;
+  if (d.pos_spatial != nullptr) {
+    float pt[4] = {0.f, 0.f, 0.f, 0.f};
+    if (d.pos_temporal != nullptr) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < d.cout) pt[j] = d.pos_temporal[(long)to * d.cout + c0 + j];
+    }
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      const int ho = ho0 + r < d.Ho ? ho0 + r : d.Ho - 1;
+      const long ps = d.pos_temporal ? (long)ho * d.Wo + wo : ((long)to * d.Ho + ho) * d.Wo + wo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < d.cout) pos[r][j] = d.pos_spatial[ps * d.cout + c0 + j] + pt[j];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < TH; ++r) {
+    const int ho = ho0 + r;
+    if (ho >= d.Ho) break;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = acc[r][j] * sc[j] + sh[j];
+    pv_apply_act_n<true>(v, d.act);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += pos[r][j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j >= d.cout) v[j] = 0.f;
+    const long yo = (long)b * d.y_bs + (((long)to * d.Ho + ho) * d.Wo + wo) * d.ldy + c0;
+    if (d.y_f32) {
+      *reinterpret_cast<f32x4*>(static_cast<float*>(d.y) + yo) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+      const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      *reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(d.y) + yo) = o;
+    }
+  }
+}
+
+// number of waves (16-channel tiles) if the patch-embedding kernel takes this conv, else 0
+int stem_pe_waves(const pv_conv3d_desc& d) {
+  if (d.dtype != PV_BF16 || d.cin != 4 || d.ldx != 4 || d.dwt_w || d.c4_wpair == 2) return 0;
+  if (d.kh != 7 || d.kw != 7 || d.sh != 4 || d.sw != 4 || d.ph != 3 || d.pw != 3) return 0;
+  if ((d.kt != 1 && d.kt != 3) || d.pt != d.kt / 2 || d.st < 1) return 0;
+  if (d.dil_t > 1 || d.dil_h > 1 || d.dil_w > 1) return 0;
+  if ((long)d.Ti * d.Hi * d.Wi * 8 > 0x7fffffffL) return 0;
+  const int nw = pv_round_up(d.cout, 16) / 16;
+  return (nw == 4 || nw == 6 || nw == 8) ? nw : 0;
+}
+
+template <int KT, int NW> int launch_stem_pe(const pv_conv3d_desc& d, int wpitch, hipStream_t s) {
+  constexpr int TH = 8, TW = 16;
+  const int tiles_h = (d.Ho + TH - 1) / TH, tiles_w = (d.Wo + TW - 1) / TW;
+  const size_t lds = (size_t)KT * ((TH - 1) * 4 + 7) * ((TW - 1) * 4 + 8) * 8;
+  const long blocks = (long)d.B * d.To * tiles_h * tiles_w;
+  if (blocks > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((stem_pe_kernel<KT, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, d, tiles_h, tiles_w, wpitch);
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
 // geometry of the LDS-staged 7 x 7 stem kernel: 0 = not this kernel's
 int stem7_variant(const pv_conv3d_desc& d) {
   if (d.dtype != PV_BF16 || d.cin != 4 || d.ldx != 4 || d.y_f32 || d.pos_spatial || d.pos_temporal || d.dwt_w) return 0;
@@ -733,6 +924,14 @@ int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s) {
   }
   if (ksteps * 4 > kMaxPairs || d.kt > 255 || d.kh > 255 || d.kw > 255) return PV_ERR_UNSUPPORTED;
   const int cout_p8 = pv_round_up(d.cout, 8);
+  if (const int nw = pv_tune("stem_pe", 1) ? stem_pe_waves(d) : 0) {   // 7 x 7 / stride 4: filter in registers, tile in LDS
+#define PV_PE(KT_)                                                              \
+    (nw == 6 ? launch_stem_pe<KT_, 6>(d, KWP * 4, s) : nw == 4 ? launch_stem_pe<KT_, 4>(d, KWP * 4, s) \
+             : launch_stem_pe<KT_, 8>(d, KWP * 4, s))
+    const int r = d.kt == 3 ? PV_PE(3) : PV_PE(1);
+#undef PV_PE
+    if (r != PV_ERR_UNSUPPORTED) return r;
+  }
   if (const int v7 = pv_tune("stem7", 1) ? stem7_variant(d) : 0) {   // 7 x 7 / stride 2: input tiles through LDS
     int r;
     if (v7 == 2 && d.kt == 5) r = launch_stem7<2, 1, 2, 5>(d, KWP * 4, s);   // SlowFast's fast stem

@@ -322,6 +322,11 @@ def test_pointwise_conv_with_se_gate_swish_and_residual(dtype, B, S, K, N, gate,
     (1, 5, 40, 70, 32, (3, 7, 7), (1, 2, 2), (1, 3, 3), False),
     (1, 3, 21, 37, 6, (7, 7, 7), (1, 2, 2), (3, 3, 3), False),
     (1, 2, 33, 66, 16, (1, 7, 7), (1, 2, 2), (0, 3, 3), False),
+    # MViT patch embedding geometries on stem_pe_kernel (filter in registers across the waves, input tile in LDS)
+    (2, 5, 30, 50, 96, (3, 7, 7), (2, 4, 4), (1, 3, 3), True),      # ragged tiles, odd T
+    (1, 1, 64, 64, 96, (1, 7, 7), (1, 4, 4), (0, 3, 3), True),      # mvit_base_16: the image model's Conv2d as one frame
+    (1, 4, 36, 68, 64, (3, 7, 7), (2, 4, 4), (1, 3, 3), False),     # 4 waves, bf16 out
+    (1, 3, 40, 40, 120, (3, 7, 7), (1, 4, 4), (1, 3, 3), True),     # 8 waves, channel tail, temporal stride 1
 ])
 def test_first_layer_conv_on_c4_layout(B, T, H, W, cout, k, s, p, f32out):
     x = _rand((B, 3, T, H, W), 61, torch.bfloat16)
