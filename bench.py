@@ -416,7 +416,7 @@ def main():
     res, model, x, step = run_workload(args.workload, args, world, rank, device, args.steps, args.warmup,
                                        sustained_s=0.0 if args.no_sustained else 2.0)
     batch = res["per_gpu_batch"]
-    pcie = pcie_leg(model, x, step, batch, args.steps, device) if (args.with_h2d and not hasattr(model, "parts")) else None
+    pcie = pcie_leg(model, x, step, batch, args.steps, device) if args.with_h2d else None
     if args.no_roofline:
         roof, prof, agg = None, [], {}
     else:

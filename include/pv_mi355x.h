@@ -432,9 +432,17 @@ int pv_plan_launch_range(pv_plan* p, int first, int last, pv_stream_t stream);
 int pv_plan_graph_build(pv_plan* p, pv_stream_t stream);           /* capture+instantiate */
 int pv_plan_graph_launch(pv_plan* p, pv_stream_t stream);
 /* `n` independent plans (sub-batches of one forward: pytorchvideo_amd.accelerator.mi355x.conversion.SplitBatchDeployed)
- * captured as `n` PARALLEL branches of ONE graph, owned by plans[0] and replayed with pv_plan_graph_launch(plans[0]):
- * the runtime runs the branches side by side, so the tail of one sub-batch's kernel overlaps the other's work */
-int pv_plan_graph_build_joint(pv_plan* const* plans, int n, pv_stream_t stream);
+ * captured as `n` PARALLEL branches of ONE graph: the runtime runs the branches side by side, so the tail of one
+ * sub-batch's kernel overlaps the other's work.  The joint graph is its OWN object (round 3): it does not live in,
+ * and is not disturbed by, the graph slot of any member plan (pv_plan_graph_build on a member leaves it intact);
+ * rebuild it after pv_plan_add on a member.  Replaces the Python loop over sub-batches; the reference has no
+ * counterpart (its forward is one ATen call sequence per batch, models/net.py:41-44). */
+typedef struct pv_joint pv_joint;
+pv_joint* pv_joint_create(void);
+void pv_joint_destroy(pv_joint* j);
+int pv_joint_build(pv_joint* j, pv_plan* const* plans, int n);     /* capture + instantiate, 1 <= n <= 16 */
+int pv_joint_launch(pv_joint* j, pv_stream_t stream);
+int pv_joint_branches(const pv_joint* j);                          /* 0 until built */
 /* per-op device time in ms: every op timed in situ between its own pair of HIP events on `stream`, behind a
  * queued un-instrumented replay (the host never paces the measurement); minimum over `iters` passes, minus the
  * null interval of an empty event pair */

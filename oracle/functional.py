@@ -13,6 +13,46 @@ import math
 import torch
 import torch.nn.functional as F
 
+# ----------------------------------------------------------------------------- 16-bit storage emulation
+# Default (None): the exact fp32 restatement of the reference -- the north-star comparator.
+# Inside `with storage_emulation(torch.bfloat16):` the SAME restatement additionally rounds every tensor the bf16
+# deploy form holds in 16 bits, at the point where it is stored / becomes an MFMA operand (DESIGN.md section 2:
+# conv outputs after the folded BN + activation (+ residual), squeeze-excited operands, LayerNorm outputs, q/k/v,
+# softmax probabilities, the attention output, the MLP hidden; the MViT token stream, logits, SE gates, BN / LN
+# statistics stay fp32).  Together with `oracle.weights.quantize_like_kernels` this is "the reference evaluated
+# with bf16 storage": what is left between it and the HIP path is the kernels' own arithmetic (accumulation order,
+# exp / erf / sigmoid approximations).  It is also the kernel-independent measure of what 16-bit storage alone costs
+# against the fp32 reference (tools/storage_floor.py).
+_STORE = None
+_BATCH_HINT = 1     # clips in the deploy form's batch: the MViT plan routes pooling convs by tensor size
+
+
+class storage_emulation:
+    def __init__(self, dtype=torch.bfloat16, batch=1):
+        self.dtype, self.batch = dtype, batch
+
+    def __enter__(self):
+        global _STORE, _BATCH_HINT
+        dt = self.dtype
+        _STORE, _BATCH_HINT = (lambda t: t.to(dt).to(torch.float32)), self.batch
+        return self
+
+    def __exit__(self, *exc):
+        global _STORE, _BATCH_HINT
+        _STORE, _BATCH_HINT = None, 1
+        return False
+
+
+def _st(x):
+    """A tensor the 16-bit deploy form stores (identity unless inside `storage_emulation`)."""
+    return x if _STORE is None else _STORE(x)
+
+
+def _shortcut_is_second_operand(cin_c, cin_x):
+    """Under emulation: does the projection shortcut ride in conv_c as a second K operand (no stored copy)?
+    Same rule as csrc/pv_pwconv.hip::pv_pwconv_x2_supported (both operands within 8 K-steps of 32)."""
+    return _STORE is not None and (cin_c + 31) // 32 + (cin_x + 31) // 32 <= 8
+
 
 def _bn(x, sd, p, eps=1e-5):
     """BatchNorm3d in eval mode: (x-mean)/sqrt(var+eps)*gamma+beta (torch semantics)."""
@@ -50,7 +90,7 @@ def x3d_stem(sd, x, p="blocks.0"):
     x = F.conv3d(x, w, stride=(1, 2, 2), padding=(0, w.shape[3] // 2, w.shape[4] // 2))
     w = sd[p + ".conv.conv_xy.weight"]
     x = F.conv3d(x, w, stride=1, padding=(w.shape[2] // 2, 0, 0), groups=w.shape[0])
-    return F.relu(_bn(x, sd, p + ".norm"))
+    return _st(F.relu(_bn(x, sd, p + ".norm")))
 
 
 def squeeze_excite(sd, x, p):
@@ -58,7 +98,7 @@ def squeeze_excite(sd, x, p):
     x * sigmoid(W2 relu(W1 mean_{T,H,W}(x) + b1) + b2)."""
     m = x.mean(dim=[2, 3, 4], keepdim=True)
     h = F.relu(F.conv3d(m, sd[p + ".block.0.weight"], sd[p + ".block.0.bias"]))
-    return x * torch.sigmoid(F.conv3d(h, sd[p + ".block.2.weight"], sd[p + ".block.2.bias"]))
+    return _st(x) * torch.sigmoid(F.conv3d(h, sd[p + ".block.2.weight"], sd[p + ".block.2.bias"]))
 
 
 def x3d_res_block(sd, x, p, stride):
@@ -69,25 +109,27 @@ def x3d_res_block(sd, x, p, stride):
         sc = F.conv3d(x, sd[p + ".branch1_conv.weight"], stride=stride)
         if _has(sd, p + ".branch1_norm"):
             sc = _bn(sc, sd, p + ".branch1_norm")
+        if not _shortcut_is_second_operand(sd[b + ".conv_c.weight"].shape[1], x.shape[1]):
+            sc = _st(sc)
     else:
         sc = x
-    y = F.relu(_bn(F.conv3d(x, sd[b + ".conv_a.weight"]), sd, b + ".norm_a"))
+    y = _st(F.relu(_bn(F.conv3d(x, sd[b + ".conv_a.weight"]), sd, b + ".norm_a")))
     w = sd[b + ".conv_b.weight"]
     y = F.conv3d(y, w, stride=stride, padding=[k // 2 for k in w.shape[2:]], groups=w.shape[0])
     y = _bn(y, sd, b + ".norm_b.0")
     if (b + ".norm_b.1.block.0.weight") in sd:
-        y = squeeze_excite(sd, y, b + ".norm_b.1")
-    y = swish(y)
+        y = squeeze_excite(sd, y, b + ".norm_b.1")     # (stored before the gate, gated + swished on conv_c's load)
+    y = _st(swish(y))
     y = _bn(F.conv3d(y, sd[b + ".conv_c.weight"]), sd, b + ".norm_c")
-    return F.relu(sc + y)
+    return _st(F.relu(sc + y))
 
 
 def x3d_head(sd, x, p, pool_kernel):
     """ProjectedPool.forward (x3d.py:791-806) + ResNetBasicHead.forward (models/head.py:371-391),
     head_activation=None (create_x3d default, x3d.py:577)."""
-    x = F.relu(_bn(F.conv3d(x, sd[p + ".pool.pre_conv.weight"]), sd, p + ".pool.pre_norm"))
-    x = F.avg_pool3d(x, pool_kernel, stride=1)
-    x = F.relu(F.conv3d(x, sd[p + ".pool.post_conv.weight"]))
+    x = _st(F.relu(_bn(F.conv3d(x, sd[p + ".pool.pre_conv.weight"]), sd, p + ".pool.pre_norm")))
+    x = _st(F.avg_pool3d(x, pool_kernel, stride=1))
+    x = _st(F.relu(F.conv3d(x, sd[p + ".pool.post_conv.weight"])))
     x = F.linear(x.permute(0, 2, 3, 4, 1), sd[p + ".proj.weight"], sd[p + ".proj.bias"]).permute(0, 4, 1, 2, 3)
     return x.mean(dim=[2, 3, 4])
 
@@ -119,7 +161,7 @@ def _conv_same(x, w, stride, groups=1, bias=None):
 
 def res_basic_stem(sd, x, p, stride=(1, 2, 2), pool=True):
     """create_res_basic_stem (models/stem.py:11-107) + ResNetBasicStem.forward (:252-260)."""
-    x = F.relu(_bn(_conv_same(x, sd[p + ".conv.weight"], stride), sd, p + ".norm"))
+    x = _st(F.relu(_bn(_conv_same(x, sd[p + ".conv.weight"], stride), sd, p + ".norm")))
     if pool:
         x = F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
     return x
@@ -135,12 +177,15 @@ def bottleneck_res_block(sd, x, p, stride_a, stride_b, dilation_b=(1, 1, 1)):
         sc = F.conv3d(x, sd[p + ".branch1_conv.weight"], stride=s)
         if _has(sd, p + ".branch1_norm"):
             sc = _bn(sc, sd, p + ".branch1_norm")
+        wc = sd[b + ".conv_c.weight"]
+        if not (_shortcut_is_second_operand(wc.shape[1], x.shape[1]) and wc.shape[1] <= 128):
+            sc = _st(sc)
     else:
         sc = x
-    y = F.relu(_bn(_conv_same(x, sd[b + ".conv_a.weight"], stride_a), sd, b + ".norm_a"))
+    y = _st(F.relu(_bn(_conv_same(x, sd[b + ".conv_a.weight"], stride_a), sd, b + ".norm_a")))
     if (b + ".conv_b.conv_t.weight") in sd:  # (2+1)D: temporal conv -> BN -> ReLU -> spatial conv
         y = _conv_same(y, sd[b + ".conv_b.conv_t.weight"], (stride_b[0], 1, 1))
-        y = F.relu(_bn(y, sd, b + ".conv_b.norm"))
+        y = _st(F.relu(_bn(y, sd, b + ".conv_b.norm")))
         y = _conv_same(y, sd[b + ".conv_b.conv_xy.weight"], (1, stride_b[1], stride_b[2]))
     else:
         w = sd[b + ".conv_b.weight"]
@@ -152,9 +197,9 @@ def bottleneck_res_block(sd, x, p, stride_a, stride_b, dilation_b=(1, 1, 1)):
             pad = (k[0] // 2, dilation_b[1] if dilation_b[1] > 1 else k[1] // 2,
                    dilation_b[2] if dilation_b[2] > 1 else k[2] // 2)
             y = F.conv3d(y, w, None, stride=stride_b, padding=pad, dilation=tuple(dilation_b), groups=groups)
-    y = F.relu(_bn(y, sd, b + ".norm_b"))
+    y = _st(F.relu(_bn(y, sd, b + ".norm_b")))
     y = _bn(F.conv3d(y, sd[b + ".conv_c.weight"]), sd, b + ".norm_c")
-    return F.relu(sc + y)
+    return _st(F.relu(sc + y))
 
 
 def res_stage(sd, x, p, stride_a, stride_b, dilation_b=(1, 1, 1)):
@@ -170,7 +215,7 @@ def res_stage(sd, x, p, stride_a, stride_b, dilation_b=(1, 1, 1)):
 def res_basic_head(sd, x, p, pool_kernel=None, softmax=False):
     """create_res_basic_head (models/head.py:39-131) + ResNetBasicHead.forward (:371-391)."""
     if pool_kernel is not None:
-        x = F.avg_pool3d(x, pool_kernel, stride=1)
+        x = _st(F.avg_pool3d(x, pool_kernel, stride=1))
     x = F.linear(x.permute(0, 2, 3, 4, 1), sd[p + ".proj.weight"], sd[p + ".proj.bias"]).permute(0, 4, 1, 2, 3)
     if softmax:
         x = torch.softmax(x, dim=1)
@@ -221,7 +266,7 @@ def slowfast_forward(sd, slow, fast, head_pool_kernels=((8, 7, 7), (32, 7, 7)), 
             return s
         w = sd[p + ".conv_fast_to_slow.weight"]
         z = F.conv3d(f, w, stride=(4, 1, 1), padding=(w.shape[2] // 2, 0, 0))
-        z = F.relu(_bn(z, sd, p + ".norm"))
+        z = _st(F.relu(_bn(z, sd, p + ".norm")))
         return torch.cat([s, z], 1)
 
     s = res_basic_stem(sd, slow, "blocks.0.multipathway_blocks.0")
@@ -235,8 +280,8 @@ def slowfast_forward(sd, slow, fast, head_pool_kernels=((8, 7, 7), (32, 7, 7)), 
         f = res_stage(sd, f, p + ".multipathway_blocks.1", (1, 1, 1), (1, spatial[i], spatial[i]))
         s = fuse(s, f, p + ".multipathway_fusion")
         outs.append((s, f))
-    x = torch.cat([F.avg_pool3d(s, head_pool_kernels[0], stride=1),
-                   F.avg_pool3d(f, head_pool_kernels[1], stride=1)], 1)
+    x = _st(torch.cat([F.avg_pool3d(s, head_pool_kernels[0], stride=1),
+                       F.avg_pool3d(f, head_pool_kernels[1], stride=1)], 1))
     outs.append(x)
     y = res_basic_head(sd, x, "blocks.6")
     outs.append(y)
@@ -424,19 +469,24 @@ def _attention_pool(sd, t, thw, p, kernel, stride, has_cls, norm_p=None, pool_fn
     g = t.reshape(B * N, T, H, W, C).permute(0, 4, 1, 2, 3).contiguous()
     bn_first = norm_p is not None and (norm_p + ".running_mean") in sd
     if bn_first:   # BatchNorm3d(head_dim) + GELU BEFORE the pool, cls token aside (layers/attention.py:186-190)
-        g = F.gelu(_bn(g, sd, norm_p))
+        g = _st(F.gelu(_bn(g, sd, norm_p)))
         norm_p = None
     if pool_fn is not None:
         g = pool_fn(g)
     else:
         w = sd[p + ".weight"]
         g = F.conv3d(g, w, None, stride=stride, padding=[k // 2 for k in kernel], groups=w.shape[0])
+        # the deploy form pools big grids with the plane-streaming depthwise kernel (its output is stored, the per-head
+        # LayerNorm is a second launch) and small ones with the fused pool + LayerNorm kernel (emit_mvit._streams_well)
+        if norm_p is None or (tuple(kernel) == (3, 3, 3) and stride[0] == 1 and stride[1] == stride[2] and stride[1] in (1, 2)
+                              and _BATCH_HINT * T * H * W * N * C >= (1 << 23)):
+            g = _st(g)
     thw = [g.shape[2], g.shape[3], g.shape[4]]
     t = g.reshape(B, N, C, -1).transpose(2, 3)
     if cls_tok is not None:
         t = torch.cat((cls_tok, t), dim=2)
     if norm_p is not None:
-        t = _ln(t, sd, norm_p)
+        t = _st(_ln(t, sd, norm_p))
     return t, thw
 
 
@@ -445,11 +495,11 @@ def multiscale_block(sd, x, thw, p, heads, kq, sq, kkv, skv, has_cls=True, resid
     """MultiScaleBlock.forward (layers/attention.py:729-757) with MultiScaleAttention.forward
     (:501-544), pool_mode="conv", depthwise, separate q/k/v, layernorm."""
     B, N, _ = x.shape
-    xn = _block_norm(x, sd, p + ".norm1")
+    xn = _st(_block_norm(x, sd, p + ".norm1"))
     a = p + ".attn"
 
     def heads_of(t):
-        return t.reshape(B, N, heads, -1).permute(0, 2, 1, 3)
+        return _st(t).reshape(B, N, heads, -1).permute(0, 2, 1, 3)
 
     q = heads_of(F.linear(xn, sd[a + ".q.weight"], sd.get(a + ".q.bias")))
     k = heads_of(F.linear(xn, sd[a + ".k.weight"], sd.get(a + ".k.bias")))
@@ -458,11 +508,16 @@ def multiscale_block(sd, x, thw, p, heads, kq, sq, kkv, skv, has_cls=True, resid
     k, _ = _attention_pool(sd, k, thw, a + ".pool_k", kkv, skv, has_cls, a + ".norm_k")
     v, _ = _attention_pool(sd, v, thw, a + ".pool_v", kkv, skv, has_cls, a + ".norm_v")
     hd = q.shape[-1]
-    attn = torch.softmax((q * hd ** -0.5) @ k.transpose(-2, -1), dim=-1)
-    o = attn @ v
+    if _STORE is None:
+        attn = torch.softmax((q * hd ** -0.5) @ k.transpose(-2, -1), dim=-1)
+        o = attn @ v
+    else:   # the fused kernel: fp32 scores, un-normalised probabilities as a 16-bit MFMA operand, fp32 row sums
+        sc = (q @ k.transpose(-2, -1)) * hd ** -0.5
+        e = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
+        o = (_st(e) @ v) / e.sum(dim=-1, keepdim=True)
     if residual_pool:
         o = o + q
-    o = o.transpose(1, 2).reshape(B, -1, heads * hd)
+    o = _st(o).transpose(1, 2).reshape(B, -1, heads * hd)
     x_block = F.linear(o, sd[a + ".proj.weight"], sd.get(a + ".proj.bias"))
     widen = (p + ".proj.weight") in sd
     if dim_mul_in_att and widen:
@@ -475,8 +530,8 @@ def multiscale_block(sd, x, thw, p, heads, kq, sq, kkv, skv, has_cls=True, resid
     else:
         x_res = x
     x = x_res + x_block
-    xn = _block_norm(x, sd, p + ".norm2")
-    h = F.gelu(F.linear(xn, sd[p + ".mlp.fc1.weight"], sd.get(p + ".mlp.fc1.bias")))
+    xn = _st(_block_norm(x, sd, p + ".norm2"))
+    h = _st(F.gelu(F.linear(xn, sd[p + ".mlp.fc1.weight"], sd.get(p + ".mlp.fc1.bias"))))
     x_mlp = F.linear(h, sd[p + ".mlp.fc2.weight"], sd.get(p + ".mlp.fc2.bias"))
     if (not dim_mul_in_att) and widen:
         x = F.linear(xn, sd[p + ".proj.weight"], sd.get(p + ".proj.bias"))
@@ -512,7 +567,7 @@ def mvit_forward(sd, x, cfg, return_blocks=False):
                                   cfg.get("residual_pool", False), cfg.get("dim_mul_in_att", False))
         outs.append(y)
     if "norm_embed.weight" in sd:   # (the norm="batchnorm" model has no final norm: vision_transformers.py:337,486)
-        y = _ln(y, sd, "norm_embed")
+        y = _st(_ln(y, sd, "norm_embed"))
     # VisionTransformerBasicHead.forward (models/head.py:521-535), dropout = identity in eval
     y = y[:, 0] if has_cls else y.mean(1)
     y = F.linear(y, sd["head.proj.weight"], sd["head.proj.bias"])

@@ -141,11 +141,15 @@ _SYMBOLS = [
     ("pv_plan_launch_range", C.c_int, [_p, C.c_int, C.c_int, _p]),
     ("pv_plan_graph_build", C.c_int, [_p, _p]),
     ("pv_plan_graph_launch", C.c_int, [_p, _p]),
-    ("pv_plan_graph_build_joint", C.c_int, [C.POINTER(_p), C.c_int, _p]),
+    ("pv_joint_create", _p, []),
+    ("pv_joint_destroy", None, [_p]),
+    ("pv_joint_build", C.c_int, [_p, C.POINTER(_p), C.c_int]),
+    ("pv_joint_launch", C.c_int, [_p, _p]),
+    ("pv_joint_branches", C.c_int, [_p]),
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _lib = None
 

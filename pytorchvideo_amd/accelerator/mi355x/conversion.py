@@ -93,7 +93,9 @@ class SplitBatchDeployed(nn.Module):
     filled with the other sub-batch's work.  Measured (tools/gpu_stream_sweep.sh, same box, 1 -> 2 sub-batches):
     X3D-M b=32 +10 %, X3D-L b=32 +10 %, MViT-B b=8 +7 %, SlowFast-R50 b=16 -2 % (its kernels already fill the
     chip); 3 and 4 sub-batches give nothing more.  By default the sub-plans are captured as parallel branches of
-    ONE hipGraph (pv_plan_graph_build_joint): a forward is the ingests, one graph launch and one concatenation."""
+    ONE hipGraph (pv_joint_*: its own handle, untouched by whatever the parts' sessions do with their own graphs): a
+    forward is the ingests, one graph launch and one concatenation.  Whether a graph is used is decided at FORWARD
+    time from the parts' `_pv_use_graph` (bench.py --no-graph flips it after construction)."""
 
     def __init__(self, parts, splits, device, joint=True):
         super().__init__()
@@ -107,13 +109,48 @@ class SplitBatchDeployed(nn.Module):
         self.__dict__["_pv_sessions"] = [p._pv_session for p in parts]
         # one graph with the sub-plans as parallel branches (one launch per forward) when every part is a
         # whole-model plan with a known input buffer; else one graph per part on its own stream
-        self._joint = joint and all(getattr(p, "_pv_inputs", None) is not None and hasattr(p, "_pv_result")
-                                    and getattr(p, "_pv_use_graph", False) for p in parts)
-        self._joint_ready = False
+        self._joint = joint and all(getattr(p, "_pv_inputs", None) is not None and hasattr(p, "_pv_result") for p in parts)
+        self.__dict__["_joint_handle"] = None
+        self.__dict__["_joint_ops"] = None       # op counts of the member plans the joint graph was captured from
 
-    def _forward_joint(self, x, multi):
+    def __del__(self):
+        h = self.__dict__.get("_joint_handle")
+        if h:
+            try:
+                L.lib().pv_joint_destroy(h)
+            except Exception:
+                pass
+
+    def _use_joint(self):
+        return self._joint and all(getattr(p, "_pv_use_graph", False) for p in self.parts)
+
+    def _launch_joint(self):
+        """One launch of the joint graph (built on first use, rebuilt when a member plan changed)."""
         import ctypes as C
         lib = L.lib()
+        s0 = self.parts[0]._pv_session
+        with torch.cuda.device(self._device):
+            ops = [lib.pv_plan_size(p._pv_session.plan) for p in self.parts]
+            if self._joint_handle is None or ops != self._joint_ops:
+                if self._joint_handle is None:
+                    self.__dict__["_joint_handle"] = lib.pv_joint_create()
+                arr = (C.c_void_p * len(self.parts))(*[p._pv_session.plan for p in self.parts])
+                L.check(lib.pv_joint_build(self._joint_handle, arr, len(self.parts)), "joint graph build")
+                self.__dict__["_joint_ops"] = ops
+            L.check(lib.pv_joint_launch(self._joint_handle, s0._stream()), "joint graph launch")
+
+    def _pv_launch(self):
+        """Run every sub-plan on inputs that are already in the parts' input buffers (transforms.DevicePacker)."""
+        if self._use_joint():
+            self._launch_joint()
+        else:
+            for p in self.parts:
+                p._pv_session.launch(use_graph=p._pv_use_graph)
+
+    def _pv_result(self):
+        return torch.cat([p._pv_result() for p in self.parts], dim=0)     # cat copies: a fresh tensor
+
+    def _forward_joint(self, x, multi):
         lo = 0
         for part, b in zip(self.parts, self._splits):
             xc = [t[lo:lo + b] for t in x] if multi else x[lo:lo + b]
@@ -121,21 +158,15 @@ class SplitBatchDeployed(nn.Module):
             if not multi and xc.dim() == 4:
                 xc = xc.unsqueeze(2)                    # image model: a clip of one frame
             _ingest_inputs(part._pv_session, xc, part._pv_inputs, multi)
-        s0 = self.parts[0]._pv_session
-        with torch.cuda.device(self._device):
-            if not self._joint_ready:
-                arr = (C.c_void_p * len(self.parts))(*[p._pv_session.plan for p in self.parts])
-                L.check(lib.pv_plan_graph_build_joint(arr, len(self.parts), s0._stream()), "joint graph build")
-                self._joint_ready = True
-            L.check(lib.pv_plan_graph_launch(s0.plan, s0._stream()), "graph launch")
-        return torch.cat([p._pv_result() for p in self.parts], dim=0)     # cat copies: a fresh tensor
+        self._launch_joint()
+        return self._pv_result()
 
     def forward(self, x):
         multi = isinstance(x, (list, tuple))
         n = (x[0] if multi else x).shape[0]
         if n != sum(self._splits):
             raise L.PvError("deploy form was converted for a batch of %d, got %d" % (sum(self._splits), n))
-        if self._joint:
+        if self._use_joint():
             return self._forward_joint(x, multi)
         cs = torch.cuda.current_stream(self._device)
         outs, lo = [], 0

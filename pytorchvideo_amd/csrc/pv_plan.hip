@@ -9,7 +9,7 @@
 
 namespace {
 thread_local std::string g_last_error;
-constexpr int kAbiVersion = 19;
+constexpr int kAbiVersion = 20;
 }  // namespace
 
 int pv_set_hip_error(hipError_t e, const char* what) {
@@ -179,14 +179,39 @@ extern "C" int pv_plan_graph_build(pv_plan* p, pv_stream_t stream) {
   return PV_OK;
 }
 
-extern "C" int pv_plan_graph_build_joint(pv_plan* const* plans, int n, pv_stream_t stream) {
-  if (!plans || n <= 0 || n > 16) return PV_ERR_INVALID;
+// A joint graph: the plans of several sub-batches as parallel branches of ONE hipGraph.  It is its own object with
+// its own graph / exec (round 3; it used to live in plans[0]'s slot, where a later pv_plan_graph_build of that plan
+// silently replaced it): building or dropping the graph of a member plan does not touch it, and it holds no
+// reference to the plans beyond the captured kernel nodes -- rebuild it after pv_plan_add on a member.
+struct pv_joint {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int branches = 0;
+};
+
+namespace {
+void drop_joint(pv_joint* j) {
+  if (j->exec) { (void)hipGraphExecDestroy(j->exec); j->exec = nullptr; }
+  if (j->graph) { (void)hipGraphDestroy(j->graph); j->graph = nullptr; }
+  j->branches = 0;
+}
+}  // namespace
+
+extern "C" pv_joint* pv_joint_create(void) { return new pv_joint(); }
+
+extern "C" void pv_joint_destroy(pv_joint* j) {
+  if (!j) return;
+  drop_joint(j);
+  delete j;
+}
+
+extern "C" int pv_joint_branches(const pv_joint* j) { return j ? j->branches : PV_ERR_INVALID; }
+
+extern "C" int pv_joint_build(pv_joint* j, pv_plan* const* plans, int n) {
+  if (!j || !plans || n <= 0 || n > 16) return PV_ERR_INVALID;
   for (int i = 0; i < n; ++i)
     if (!plans[i]) return PV_ERR_INVALID;
-  if (n == 1) return pv_plan_graph_build(plans[0], stream);
-  pv_plan* p = plans[0];
-  drop_graph(p);
-  (void)stream;
+  drop_joint(j);
   // fork / join by events inside the capture: branch i > 0 is recorded on its own stream behind a fork event of the
   // origin stream, and the origin stream waits for every branch's last event before the capture ends
   std::vector<hipStream_t> ss(n, nullptr);
@@ -220,8 +245,15 @@ extern "C" int pv_plan_graph_build_joint(pv_plan* const* plans, int n, pv_stream
     return r != PV_OK ? r : pv_set_hip_error(he, "joint graph: fork / join");
   }
   if (e != hipSuccess) return pv_set_hip_error(e, "hipStreamEndCapture");
-  p->graph = g;
-  PV_HIP_CHECK(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+  j->graph = g;
+  PV_HIP_CHECK(hipGraphInstantiate(&j->exec, j->graph, nullptr, nullptr, 0));
+  j->branches = n;
+  return PV_OK;
+}
+
+extern "C" int pv_joint_launch(pv_joint* j, pv_stream_t stream) {
+  if (!j || !j->exec) return PV_ERR_INVALID;
+  PV_HIP_CHECK(hipGraphLaunch(j->exec, static_cast<hipStream_t>(stream)));
   return PV_OK;
 }
 

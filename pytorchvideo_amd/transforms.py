@@ -74,6 +74,15 @@ class DevicePacker:
     A deployed detection model (DetectionBBoxNetwork) is called as `packer(clip, bboxes)`."""
 
     def __init__(self, deployed, mean=None, std=None, div255=False, frame_ratios=None):
+        self.subs = None
+        if hasattr(deployed, "parts") and hasattr(deployed, "_pv_launch"):
+            # split-batch deploy form (convert_to_deployable_form(..., streams=k)): one packer per sub-batch fills that
+            # sub-plan's input buffers, then ONE launch of the joint graph
+            self.model = deployed
+            self.subs = [DevicePacker(p, mean, std, div255, frame_ratios) for p in deployed.parts]
+            self.sess, self.refs = self.subs[0].sess, self.subs[0].refs
+            self.frame_ratios = self.subs[0].frame_ratios
+            return
         inputs = getattr(deployed, "_pv_inputs", None)
         if inputs is None:
             raise RuntimeError("DevicePacker needs a model converted as a whole by convert_to_deployable_form(model, x)")
@@ -116,12 +125,24 @@ class DevicePacker:
         if clip.dim() != 5:
             raise RuntimeError("expected a [B,C,T,H,W] clip, got %s" % (tuple(clip.shape),))
         clip = clip.to(self.sess.device, non_blocking=True)
+        if self.subs is not None:
+            lo = 0
+            for sub, b in zip(self.subs, self.model._splits):
+                sub._fill(clip[lo:lo + b])
+                lo += b
+            if lo != clip.shape[0]:
+                raise RuntimeError("deploy form was converted for a batch of %d, got %d" % (lo, clip.shape[0]))
+            self.model._pv_launch()
+            return self.model._pv_result()
+        self._fill(clip)
+        if load_boxes is not None:
+            load_boxes(bboxes)
+        self.sess.launch(use_graph=self.model._pv_use_graph)
+        return self.model._pv_result()
+
+    def _fill(self, clip):
         t_src = clip.shape[2]
         for ratio, ref in zip(self.frame_ratios, self.refs):
             if t_src // ratio != ref.T:
                 raise RuntimeError("pathway with frame ratio %d expects %d frames, the clip gives %d" % (ratio, ref.T, t_src // ratio))
             self.sess.ingest(clip, ref, t_index=self._t_index(t_src, ref), ch_scale=self.scale, ch_shift=self.shift)
-        if load_boxes is not None:
-            load_boxes(bboxes)
-        self.sess.launch(use_graph=self.model._pv_use_graph)
-        return self.model._pv_result()

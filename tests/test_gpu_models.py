@@ -64,12 +64,12 @@ def test_mvit_matches_oracle(name, dtype, tol):
     assert got.shape == want.shape
     if name == "mvit_bn_small" and dtype == torch.bfloat16:
         # The BatchNorm variant (no per-token renormalisation anywhere) is the most rounding-sensitive of the three
-        # instances: storing only its WEIGHTS and input in bf16 and evaluating in exact fp32 on the CPU -- no kernel
-        # involved -- already moves the logits by 1.6e-2 (LayerNorm instances: 3e-3 / 8e-3; tools/mvit_variant_errors.py).
-        # Activation storage in bf16 perturbs every layer by the same 2^-9 relative amount, so the kernel-isolating
-        # error is bounded by that measured figure (x 1.5), not by the 1e-2 of the better-conditioned instances.
-        want32 = OF.mvit_forward(m.state_dict(), x, g["cfg"])
-        tol = max(tol, 1.5 * rel_err(want, want32))
+        # instances: bf16 STORAGE of the activations alone moves an exact evaluation by more than 1e-2.  The kernels
+        # are therefore held (fixed bound) to the oracle evaluated with the same bf16 storage points
+        # (oracle/functional.py::storage_emulation): what is left is their own arithmetic.
+        sd_q, xq = quantize_like_kernels(m.state_dict(), x)
+        with OF.storage_emulation(torch.bfloat16, batch=x.shape[0]):
+            want = OF.mvit_forward(sd_q, xq, g["cfg"])
     assert rel_err(got, want) <= tol
     assert torch.equal(dm(xd), got)  # graph replay, no atomics: bitwise reproducible
 
@@ -333,3 +333,15 @@ def test_split_batch_streams_give_the_one_plan_result(family):
         torch.cuda.synchronize()
         assert got.shape == want.shape and torch.equal(got, want)
         assert torch.equal(dm(list(xd) if isinstance(xd, list) else xd), want)     # replays are idempotent
+        if k == 2:
+            # the joint graph is its own object: a part used on its own (which builds THAT part's single-plan graph)
+            # must not disturb it -- it used to live in parts[0]'s graph slot and was silently replaced
+            b0 = dm._splits[0]
+            x0 = [t[:b0] for t in xd] if isinstance(xd, list) else xd[:b0]
+            assert torch.equal(dm.parts[0](list(x0) if isinstance(x0, list) else x0), want[:b0])
+            assert torch.equal(dm(list(xd) if isinstance(xd, list) else xd), want)
+            # ... and `_pv_use_graph` is read at forward time (bench.py --no-graph flips it after construction)
+            for part in dm.parts:
+                part.__dict__["_pv_use_graph"] = False
+            assert not dm._use_joint()
+            assert torch.equal(dm(list(xd) if isinstance(xd, list) else xd), want)

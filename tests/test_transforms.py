@@ -113,32 +113,54 @@ def test_device_packer_equals_host_packing_on_slowfast_and_x3d():
     want3 = dep3(x).clone()
     got3 = TR.DevicePacker(dep3, mean, std, div255=True)(clip.cuda())
     assert rel_err(got3, want3) <= 1e-2
+    # the split-batch deploy form (streams=2) takes the packer too: one packer per sub-batch, one joint-graph launch
+    dep3s = convert_to_deployable_form(x3, x, dtype=torch.bfloat16, streams=2)
+    assert torch.equal(TR.DevicePacker(dep3s, mean, std, div255=True)(clip.cuda()), got3)
+    deps = convert_to_deployable_form(sf, [slow.cuda().bfloat16(), fast.cuda().bfloat16()], dtype=torch.bfloat16, streams=2)
+    assert torch.equal(TR.DevicePacker(deps, mean, std, div255=True, frame_ratios=(4, 1))(clip.cuda()), got)
+
+
+def _ensemble_fixture():
+    """tests/golden/ensemble.pt: outputs of the reference's OWN method bodies (_test_step_with_data_ensembling,
+    _ensemble_at_video_level, on_test_epoch_end -- pytorchvideo_trainer/module/video_classification.py:244-311), lifted
+    out of the reference source with `ast` and executed unchanged by tests/golden/make_ensemble_golden.py."""
+    import os
+    return torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ensemble.pt"), weights_only=False)
+
+
+@pytest.mark.parametrize("method", ["sum", "max"])
+def test_ensembling_restatement_is_pinned_to_the_reference_fixture(method):
+    """The dict loop of video_classification.py:290-311 restated on the host (the multi-rank comparator of
+    tests/test_distributed_gloo.py) reproduces the reference's own outputs bit for bit."""
+    fx = _ensemble_fixture()
+    ref = fx["methods"][method]
+    preds, cnts = {}, {}
+    for logits, ids, _labels in fx["batches"]:
+        p = torch.softmax(logits, dim=-1)
+        for i, v in enumerate(ids):
+            if v not in preds:
+                preds[v], cnts[v] = torch.zeros(p.shape[1]), 0
+            preds[v] = preds[v] + p[i] if method == "sum" else torch.max(preds[v], p[i])
+            cnts[v] += 1
+    assert list(preds.keys()) == ref["video_order"] and [cnts[v] for v in ref["video_order"]] == ref["counts"]
+    assert torch.equal(torch.stack([preds[v] / cnts[v] for v in ref["video_order"]]), ref["video_preds"])
+    assert set(fx["source"]) == {"_test_step_with_data_ensembling", "_ensemble_at_video_level", "on_test_epoch_end"}
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("method", ["sum", "max"])
-def test_video_level_ensembling_matches_the_reference_loop(method):
-    """pytorchvideo_trainer/module/video_classification.py:286-306 restated as the dict loop it is."""
+def test_video_level_ensembling_matches_the_reference_fixture(method):
+    """pv_ensemble_scores / VideoEnsembler against what the reference's own loop produced on the same logits."""
     from pytorchvideo_amd.ensemble import VideoEnsembler
-    V, Cc = 6, 400
-    g = torch.Generator().manual_seed(21)
-    batches = [(torch.randn(8, Cc, generator=g) * 3, [0, 0, 1, 5, 1, 0, 3, 3]),
-               (torch.randn(5, Cc, generator=g) * 3, [3, 2, 2, 0, 5]),
-               (torch.randn(1, Cc, generator=g) * 3, [4])]
-    preds, cnts = {}, {}
-    for logits, ids in batches:
-        p = torch.softmax(logits, dim=-1)
-        for i, v in enumerate(ids):
-            if v not in preds:
-                preds[v], cnts[v] = torch.zeros(Cc), 0
-            preds[v] = preds[v] + p[i] if method == "sum" else torch.max(preds[v], p[i])
-            cnts[v] += 1
-    want = torch.stack([preds[v] / cnts[v] for v in range(V)])
+    fx = _ensemble_fixture()
+    ref = fx["methods"][method]
+    V, Cc = max(ref["video_order"]) + 1, ref["video_preds"].shape[1]
     e = VideoEnsembler(V, Cc, method=method)
-    for logits, ids in batches:
+    for logits, ids, _labels in fx["batches"]:
         e.update(logits.cuda(), ids)
-    assert e.counts.tolist() == [cnts[v] for v in range(V)]
-    got = e.merge().result().cpu()
-    assert (got - want).abs().max().item() <= 1e-6
+    assert e.counts.cpu()[ref["video_order"]].tolist() == ref["counts"]
+    got = e.merge().result().cpu()[ref["video_order"]]
+    # softmax in fp32 on both sides; the 30-clip video sums 30 terms in index order on the device as in the loop
+    assert (got - ref["video_preds"]).abs().max().item() <= 1e-6
     with pytest.raises(RuntimeError):
         e.update(torch.zeros(2, Cc + 1, device="cuda"), [0, 1])
