@@ -410,6 +410,40 @@ typedef struct pv_roi_align_desc {
 } pv_roi_align_desc;
 int pv_roi_align(const pv_roi_align_desc* d, pv_stream_t stream);
 
+/* ---- fused MLP of a MultiScaleBlock on token rows -------------------------------------------------------
+ * Replaces  norm2 -> Mlp.fc1 -> GELU -> Mlp.fc2 -> + residual  (pytorchvideo/layers/attention.py:102-114 Mlp.forward,
+ * :750-757 the block's second half) in ONE launch whose hidden tensor never leaves the chip (csrc/pv_mlp.hip):
+ *     y[m][:] = R[m][:] + b2 + W2 . act(W1 . xn[m][:] + b1)
+ *   ln_gamma != NULL:  x is the fp32 token stream [M][ldx]; xn = LayerNorm(x; ln_gamma, ln_beta, ln_eps) is computed
+ *                      in the kernel and R = x (the row is read once); needs C == Cout, residual == NULL.
+ *   ln_gamma == NULL:  x is a bf16 operand tensor [M][ldx] (the LayerNorm output); R = residual (fp32 [M][ldr]) or 0.
+ * y is fp32 [M][ldy].  dtype must be PV_BF16 (weights bf16, fp32 accumulation / bias / activation / LayerNorm).
+ * `w12` is the host-packed per-hidden-block LDS image, H/32 blocks of  C/16*1024 + Cout/32*2048 + 256  bytes:
+ *   [ks < C/16][hi < 2][rho < 32][j < 8]  bf16  W1[32 hb + rho][32 (ks>>1) + 16 hi + 8 (ks&1) + j]
+ *   [ob < Cout/32][i < 2][hi < 2][rho < 32][j < 8]  bf16  W2[32 ob + chi(rho)][32 hb + (j&3) + 8 (2 i + (j>>2)) + 4 hi],
+ *        chi(rho) = 16 ((rho>>2)&1) + 4 ((rho>>3)&3) + (rho&3)
+ *   [hi < 2][r < 16] fp32  b1[32 hb + (r&3) + 8 (r>>2) + 4 hi]  (zeros when the layer has no bias), then 128 bytes of padding
+ * (pytorchvideo_amd/accelerator/mi355x/emit_mvit.py::pack_mlp_weights builds it).  b2 is [Cout] fp32 or NULL.
+ * pv_mlp_rows_supported(d) == 1 for the (C, Cout) pairs the kernel is instantiated for (MViT-B: 96/192, 192/192,
+ * 192/384, 384/384; H any multiple of 32). */
+typedef struct pv_mlp_desc {
+  const void* x;
+  const void* w12;
+  void* y;
+  const float* b2;
+  const float* residual;
+  const float* ln_gamma;
+  const float* ln_beta;
+  int64_t M;             /* token rows */
+  int32_t C, H, Cout;    /* in / hidden / out widths */
+  int32_t ldx, ldr, ldy; /* row strides, elements */
+  int32_t act;           /* pv_act between the two Linears */
+  int32_t dtype;         /* PV_BF16 */
+  float ln_eps;
+} pv_mlp_desc;
+int pv_mlp_rows(const pv_mlp_desc* d, pv_stream_t stream);
+int pv_mlp_rows_supported(const pv_mlp_desc* d);
+
 /* ---- execution plan ----------------------------------------------------------------
  * A deploy-form model is specialised to one input size (reference contract:
  * accelerator/deployment/mobile_cpu/utils/model_conversion.py:100-103), so its forward
@@ -420,7 +454,7 @@ enum pv_op_kind {
   PV_OP_CONV3D = 1, PV_OP_DWCONV3D = 2, PV_OP_SE_GATE = 3, PV_OP_POOL3D = 4,
   PV_OP_LAYERNORM = 5, PV_OP_SOFTMAX_ROWS = 6, PV_OP_MEAN_ROWS = 7, PV_OP_POSENC = 8,
   PV_OP_ATTENTION = 9, PV_OP_ADD_ACT = 10, PV_OP_INGEST = 11, PV_OP_EGRESS = 12, PV_OP_TOKEN_POOL = 13,
-  PV_OP_ROI_ALIGN = 14, PV_OP_LATERAL = 15, PV_OP_AFFINE_ROWS = 16
+  PV_OP_ROI_ALIGN = 14, PV_OP_LATERAL = 15, PV_OP_AFFINE_ROWS = 16, PV_OP_MLP_ROWS = 17
 };
 typedef struct pv_plan pv_plan;
 pv_plan* pv_plan_create(void);

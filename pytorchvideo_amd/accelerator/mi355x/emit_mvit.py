@@ -19,6 +19,8 @@ epilogues add an fp32 residual and write fp32 -- so that 16 blocks of bf16 round
 pile up on the stream; every MFMA operand (x_norm, q/k/v, P, attention output, MLP hidden)
 is bf16.
 """
+import ctypes as C
+
 from . import tuning
 
 import torch
@@ -360,6 +362,98 @@ def emit_attention_core(sess, q, k, v, heads, scale, residual_q, label="attentio
     return o
 
 
+def _chi(rho):
+    """Row permutation of a 32-row MFMA tile that makes a lane's 16 accumulator registers 16 consecutive channels."""
+    return 16 * ((rho >> 2) & 1) + 4 * ((rho >> 3) & 3) + (rho & 3)
+
+
+def pack_mlp_weights(w1, b1, w2):
+    """The per-hidden-block LDS image pv_mlp_rows streams (layout: include/pv_mi355x.h, pv_mlp_desc).
+    w1 [H, C], b1 [H] or None, w2 [Cout, H] (fp32, host) -> uint8 [H/32 * (C/16*1024 + Cout/32*2048 + 256)]."""
+    H, Cin = w1.shape
+    Cout = w2.shape[0]
+    NH, KS, NOB = H // 32, Cin // 16, Cout // 32
+    w1 = w1.detach().float().cpu()
+    w2 = w2.detach().float().cpu()
+    # W1: [hb, rho, q, hi, e, j] -> [hb, ks = (q, e), hi, rho, j];  channel = 32 q + 16 hi + 8 e + j
+    w1p = w1.reshape(NH, 32, Cin // 32, 2, 2, 8).permute(0, 2, 4, 3, 1, 5).reshape(NH, KS * 512)
+    # W2: [hb, ob, i, hi, rho, j] = W2[32 ob + chi(rho)][32 hb + (j&3) + 8 (2 i + (j>>2)) + 4 hi]
+    rho = torch.arange(32)
+    rows = (32 * torch.arange(NOB)[:, None] + torch.tensor([_chi(int(r)) for r in rho])[None, :])            # [ob, rho]
+    j = torch.arange(8)
+    cols = (32 * torch.arange(NH)[:, None, None, None] + (j & 3)[None, None, None, :]
+            + 8 * (2 * torch.arange(2)[None, :, None, None] + (j >> 2)[None, None, None, :])
+            + 4 * torch.arange(2)[None, None, :, None])                                                       # [hb, i, hi, j]
+    w2p = w2[rows[None, :, None, None, :, None], cols[:, None, :, :, None, :]].reshape(NH, NOB * 1024)          # [hb, ob, i, hi, rho, j]
+    r = torch.arange(16)
+    unit = (32 * torch.arange(NH)[:, None, None] + ((r & 3) + 8 * (r >> 2))[None, None, :] + 4 * torch.arange(2)[None, :, None])
+    b1p = torch.zeros(NH, 64, dtype=torch.float32)                                                            # 128 B + 128 B padding
+    if b1 is not None:
+        b1p[:, :32] = b1.detach().float().cpu()[unit].reshape(NH, 32)
+    img = torch.cat([w1p.to(torch.bfloat16).view(torch.int16).view(torch.uint8).reshape(NH, -1),
+                     w2p.to(torch.bfloat16).view(torch.int16).view(torch.uint8).reshape(NH, -1),
+                     b1p.view(torch.uint8).reshape(NH, -1)], dim=1)
+    assert img.shape[1] == KS * 1024 + NOB * 2048 + 256
+    return img.reshape(-1).contiguous()
+
+
+def can_fuse_mlp(sess, blk, x1):
+    """norm2 -> fc1 -> act -> fc2 -> + residual of a MultiScaleBlock as ONE pv_mlp_rows launch (csrc/pv_mlp.hip)?"""
+    if not tuning.get("fuse_mlp") or sess.pv_dtype != L.PV_BF16 or not x1.f32:
+        return False
+    mlp = blk.mlp
+    if not isinstance(getattr(mlp, "fc1", None), nn.Linear) or not isinstance(getattr(mlp, "fc2", None), nn.Linear):
+        return False
+    if not isinstance(getattr(mlp, "dropout", nn.Identity()), (nn.Identity, nn.Dropout)):
+        return False
+    if x1.bs != x1.voxels * x1.ld or mlp.fc1.in_features != x1.C or mlp.fc2.in_features != mlp.fc1.out_features:
+        return False
+    d = L.MlpDesc()
+    d.x = d.w12 = d.y = 1      # non-null placeholders: only the geometry is judged
+    d.M, d.C, d.H, d.Cout = x1.B * x1.voxels, mlp.fc1.in_features, mlp.fc1.out_features, mlp.fc2.out_features
+    d.ldx, d.ldr, d.ldy, d.dtype = pad8(d.C), pad8(d.Cout), pad8(d.Cout), L.PV_BF16
+    return L.lib().pv_mlp_rows_supported(C.byref(d)) == 1
+
+
+def emit_mlp_fused(sess, blk, x1):
+    """Second half of MultiScaleBlock.forward (layers/attention.py:750-757, Mlp.forward :102-114).  With a LayerNorm
+    norm2 and an unchanged width the kernel normalises the fp32 stream itself and uses it as the residual (one read);
+    otherwise (width change: the residual is blk.proj(norm2(x)); BatchNorm norm2) norm2 stays its own launch."""
+    mlp = blk.mlp
+    widen = blk.dim != blk.dim_out
+    act = E.act_code(mlp.act)
+    Cin, H, Cout = mlp.fc1.in_features, mlp.fc1.out_features, mlp.fc2.out_features
+    w12 = sess.add_weight(pack_mlp_weights(mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight))
+    b2 = mlp.fc2.bias.detach().float() if mlp.fc2.bias is not None else torch.zeros(Cout)
+    y = sess.alloc_act(x1.B, 1, 1, x1.voxels, Cout, f32=True)
+    y.thw, y.has_cls = x1.thw, x1.has_cls
+    M = x1.B * x1.voxels
+    f = dict(w12=w12, y=y.ptr, b2=sess.add_weight(b2), M=M, C=Cin, H=H, Cout=Cout, ldy=y.ld, act=act, dtype=L.PV_BF16,
+             residual=None, ln_gamma=None, ln_beta=None, ln_eps=0.0, ldr=0)
+    in_kernel_ln = isinstance(blk.norm2, nn.LayerNorm) and not ((not blk.dim_mul_in_att) and widen) and Cin == Cout \
+        and blk.norm2.weight is not None and blk.norm2.bias is not None and tuple(blk.norm2.normalized_shape) == (Cin,)
+    flops = 2 * M * H * (Cin + Cout)
+    wbytes = 2 * H * (Cin + Cout)
+    if in_kernel_ln:
+        f.update(x=x1.ptr, ldx=x1.ld, ln_gamma=sess.add_weight(blk.norm2.weight.detach().float()),
+                 ln_beta=sess.add_weight(blk.norm2.bias.detach().float()), ln_eps=float(blk.norm2.eps))
+        sess.add_op(L.OP_MLP_ROWS, f, label="mlp.fused|%dx%d c%d->%d->%d ln" % (x1.B, x1.voxels, Cin, H, Cout),
+                    alg_bytes=4 * M * (pad8(Cin) + pad8(Cout)) + wbytes, flops=flops)
+        return y
+    xn2 = emit_block_norm(sess, blk.norm2, x1, label="norm2")
+    if (not blk.dim_mul_in_att) and widen:
+        res2 = emit_linear(sess, blk.proj, xn2, y_f32=True, label="proj_dim")
+    else:
+        res2 = x1
+    f.update(x=xn2.ptr, ldx=xn2.ld, residual=res2.ptr, ldr=res2.ld)
+    sess.add_op(L.OP_MLP_ROWS, f, label="mlp.fused|%dx%d c%d->%d->%d" % (x1.B, x1.voxels, Cin, H, Cout),
+                alg_bytes=2 * M * pad8(Cin) + 8 * M * pad8(Cout) + wbytes, flops=flops)
+    sess.release(xn2)
+    if res2 is not x1:
+        sess.release(res2)
+    return y
+
+
 # --------------------------------------------------------------------------- modules
 def emit_multiscale_attention(sess, attn, xn, residual, label="attn"):
     """MultiScaleAttention.forward (attention.py:501-544) + the block's residual join fused into
@@ -458,6 +552,10 @@ def emit_multiscale_block(sess, blk, x):
         sess.release(x_res)
     if skip_src is not x:
         sess.release(skip_src)
+    if can_fuse_mlp(sess, blk, x1):
+        y = emit_mlp_fused(sess, blk, x1)
+        sess.release(x1)
+        return y
     xn2 = emit_block_norm(sess, blk.norm2, x1, label="norm2")
     hmid = emit_linear(sess, blk.mlp.fc1, xn2, act=act, label="mlp.fc1")
     if (not blk.dim_mul_in_att) and widen:

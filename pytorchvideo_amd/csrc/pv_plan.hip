@@ -81,6 +81,7 @@ size_t desc_size(int kind) {
     case PV_OP_TOKEN_POOL: return sizeof(pv_token_pool_desc);
     case PV_OP_ROI_ALIGN: return sizeof(pv_roi_align_desc);
     case PV_OP_LATERAL: return sizeof(pv_lateral_desc);
+    case PV_OP_MLP_ROWS: return sizeof(pv_mlp_desc);
     default: return 0;
   }
 }
@@ -104,6 +105,7 @@ int run_op(const pv_plan::Op& op, pv_stream_t s) {
     case PV_OP_ROI_ALIGN: return pv_roi_align(static_cast<const pv_roi_align_desc*>(p), s);
     case PV_OP_LATERAL: return pv_lateral_fuse(static_cast<const pv_lateral_desc*>(p), s);
     case PV_OP_AFFINE_ROWS: return pv_affine_rows(static_cast<const pv_rows_desc*>(p), s);
+    case PV_OP_MLP_ROWS: return pv_mlp_rows(static_cast<const pv_mlp_desc*>(p), s);
     default: return PV_ERR_INVALID;
   }
 }

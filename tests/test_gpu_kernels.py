@@ -891,3 +891,51 @@ def test_narrow_dense_conv_on_the_tap_streaming_kernel(B, T, H, W, cin, cout, k,
     assert rel_err(y1[..., :cout].permute(0, 4, 1, 2, 3), want) <= 1e-2
     assert torch.all(y1[..., cout:] == 0)
     assert rel_err(y1, y0) <= 4e-3      # the generic kernel: same products, other summation order
+
+
+@pytest.mark.parametrize("M,Cin,H,Cout,ln,res", [
+    (300, 96, 384, 192, False, True),       # MViT-B block 0 (width change: residual = proj(norm2(x)), own launch)
+    (50, 96, 384, 96, True, False),         # 96 -> 96 with the LayerNorm in the kernel
+    (1001, 192, 768, 192, True, False),     # block 1
+    (257, 192, 768, 384, False, True),      # block 2
+    (6274, 384, 1536, 384, True, False),    # blocks 3-12 (two clips of 3137 tokens)
+    (130, 384, 1536, 384, False, False),    # bf16 operand, no residual
+    (129, 384, 64, 384, True, False),       # two hidden blocks only
+])
+def test_fused_mlp_rows(M, Cin, H, Cout, ln, res):
+    """pv_mlp_rows: norm2 -> fc1 -> GELU -> fc2 -> + residual (layers/attention.py:102-114,750-757) in one launch
+    against fp32 torch on the same bf16-rounded weights (ragged row counts: the last 128-row tile is partial)."""
+    from pytorchvideo_amd.accelerator.mi355x.emit_mvit import pack_mlp_weights
+    g = torch.Generator().manual_seed(77)
+    w1 = (torch.randn(H, Cin, generator=g) * Cin ** -0.5).bfloat16().float()
+    w2 = (torch.randn(Cout, H, generator=g) * H ** -0.5).bfloat16().float()
+    b1, b2 = torch.randn(H, generator=g) * 0.3, torch.randn(Cout, generator=g) * 0.3
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+    x32 = torch.randn(M, Cin, generator=g) * 2.0 + 3.0 * torch.randn(M, 1, generator=g)      # rows with a large mean
+    r32 = torch.randn(M, Cout, generator=g)
+    if ln:
+        xn = F.layer_norm(x32, (Cin,), gamma, beta, 1e-6)
+        want = x32 + b2 + F.linear(F.gelu(F.linear(xn, w1, b1)), w2)
+        x_dev = x32.cuda()
+    else:
+        xb = x32.bfloat16()
+        want = b2 + F.linear(F.gelu(F.linear(xb.float(), w1, b1)), w2) + (r32 if res else 0.0)
+        x_dev = xb.cuda()
+    img = pack_mlp_weights(w1, b1, w2).cuda()
+    y = torch.full((M, Cout), 7.0, dtype=torch.float32, device="cuda")
+    b2d, gd, bd, rd = b2.cuda(), gamma.cuda(), beta.cuda(), r32.cuda()
+    d = L.MlpDesc()
+    d.x, d.w12, d.y, d.b2 = x_dev.data_ptr(), img.data_ptr(), y.data_ptr(), b2d.data_ptr()
+    d.residual = rd.data_ptr() if (res and not ln) else None
+    d.ln_gamma, d.ln_beta, d.ln_eps = (gd.data_ptr(), bd.data_ptr(), 1e-6) if ln else (None, None, 0.0)
+    d.M, d.C, d.H, d.Cout, d.ldx, d.ldr, d.ldy, d.act, d.dtype = M, Cin, H, Cout, Cin, Cout, Cout, L.ACT_GELU, L.PV_BF16
+    assert L.lib().pv_mlp_rows_supported(C.byref(d)) == 1
+    call("pv_mlp_rows", d)
+    assert rel_err(y, want) <= 1e-2
+    y2 = torch.zeros_like(y)
+    d.y = y2.data_ptr()
+    call("pv_mlp_rows", d)
+    assert torch.equal(y, y2)                       # no atomics, fixed order: bitwise reproducible
+    # unsupported widths are declined, inconsistent descriptors rejected
+    d.C = 768
+    assert L.lib().pv_mlp_rows_supported(C.byref(d)) == 0

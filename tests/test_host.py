@@ -281,3 +281,33 @@ def test_slowfast_with_a_declined_head_converts_block_by_block():
     CV._convert_children(m, lut, 3, "", sess, torch.bfloat16, {})
     assert all(b.convert_flag for b in m.blocks[:-1])
     assert [r.B for r in m.blocks[0]._in_ref] == [3, 3] and len(sess.ops) > 30
+
+
+def test_fused_mlp_weight_image_follows_the_documented_layout():
+    """pack_mlp_weights builds exactly the per-hidden-block LDS image include/pv_mi355x.h documents for pv_mlp_rows."""
+    import torch
+    from pytorchvideo_amd.accelerator.mi355x.emit_mvit import _chi, pack_mlp_weights
+    torch.manual_seed(0)
+    H, Cin, Cout = 96, 64, 96
+    w1, b1, w2 = torch.randn(H, Cin), torch.randn(H), torch.randn(Cout, H)
+    img = pack_mlp_weights(w1, b1, w2)
+    KS, NOB, NH = Cin // 16, Cout // 32, H // 32
+    stage = KS * 1024 + NOB * 2048 + 256
+    assert img.dtype == torch.uint8 and img.numel() == NH * stage
+    bf = lambda t: t.to(torch.bfloat16)
+    for hb in range(NH):
+        blk = img[hb * stage:(hb + 1) * stage]
+        a = blk[:KS * 1024].view(torch.int16).view(torch.bfloat16).reshape(KS, 2, 32, 8)
+        b = blk[KS * 1024:KS * 1024 + NOB * 2048].view(torch.int16).view(torch.bfloat16).reshape(NOB, 2, 2, 32, 8)
+        c = blk[KS * 1024 + NOB * 2048:].view(torch.float32)
+        for hi in range(2):
+            for rho in (0, 5, 18, 31):
+                for j in range(8):
+                    for ks in range(KS):
+                        assert a[ks, hi, rho, j] == bf(w1[32 * hb + rho, 32 * (ks >> 1) + 16 * hi + 8 * (ks & 1) + j])
+                    for ob in range(NOB):
+                        for i in range(2):
+                            assert b[ob, i, hi, rho, j] == bf(w2[32 * ob + _chi(rho), 32 * hb + (j & 3) + 8 * (2 * i + (j >> 2)) + 4 * hi])
+            for r in range(16):
+                assert c[hi * 16 + r] == b1[32 * hb + (r & 3) + 8 * (r >> 2) + 4 * hi]
+        assert not c[32:].any()

@@ -5,7 +5,8 @@ O(1-10)) the fp32 oracle is compared with the SAME oracle evaluated with (a) the
 to the format and (b) additionally every tensor the 16-bit deploy form stores rounded where it is stored
 (oracle/functional.py::storage_emulation).  Exact fp32 arithmetic everywhere else.  Metric: max|d| / max|logits|.
 This is the floor under `bf16_vs_fp32_oracle` of tools/parity_full.py: no arithmetic that holds bf16 weights and
-activations can be closer to the fp32 reference on these instances.
+activations can be closer to the fp32 reference on these instances.  `*_self_sensitivity_1ulp` is the floor under
+`bf16_vs_emulated_oracle`: the 16-bit evaluation against ITSELF after a one-fp32-ulp nudge of every stored value.
 
     python tools/storage_floor.py [--json profiles/r3/storage_floor.json]
 """
@@ -40,7 +41,18 @@ def floors(workload, fill="calibrated"):
             xq = [t.to(dt).float() for t in x] if isinstance(x, list) else x.to(dt).float()
             out[name + "_weights_only"] = rel(fn(sd_q, xq), want)
             with OF.storage_emulation(dt):
-                out[name + "_storage"] = rel(fn(sd_q, xq), want)
+                base = fn(sd_q, xq)
+            out[name + "_storage"] = rel(base, want)
+            # how reproducible is that evaluation itself?  The same oracle with every stored value nudged by about one
+            # fp32 ulp (x (1 + 1e-7 N(0,1))) BEFORE it is rounded to the format: a few roundings flip, and the random-weight
+            # network amplifies them.  An implementation whose fp32 arithmetic differs from the oracle's in the last bit
+            # (accumulation order, FMA contraction, exp / sigmoid approximations) cannot agree with it better than this.
+            g = torch.Generator().manual_seed(1)
+            OF._STORE = lambda t: (t * (1 + 1e-7 * torch.randn(t.shape, generator=g))).to(dt).float()
+            try:
+                out[name + "_self_sensitivity_1ulp"] = rel(fn(sd_q, xq), base)
+            finally:
+                OF._STORE = None
     return out
 
 
