@@ -418,7 +418,8 @@ int pv_roi_align(const pv_roi_align_desc* d, pv_stream_t stream);
  *                      in the kernel and R = x (the row is read once); needs C == Cout, residual == NULL.
  *   ln_gamma == NULL:  x is a bf16 operand tensor [M][ldx] (the LayerNorm output); R = residual (fp32 [M][ldr]) or 0.
  * y is fp32 [M][ldy].  dtype must be PV_BF16 (weights bf16, fp32 accumulation / bias / activation / LayerNorm).
- * `w12` is the host-packed per-hidden-block LDS image, H/32 blocks of  C/16*1024 + Cout/32*2048 + 256  bytes:
+ * `w12` is the host-packed per-hidden-block LDS image, H/32 blocks of  C/16*1024 + Cout/32*2048 + 256  bytes
+ * FOLLOWED BY ONE MORE BLOCK OF PADDING (any finite values; the kernel prefetches one block ahead without a branch):
  *   [ks < C/16][hi < 2][rho < 32][j < 8]  bf16  W1[32 hb + rho][32 (ks>>1) + 16 hi + 8 (ks&1) + j]
  *   [ob < Cout/32][i < 2][hi < 2][rho < 32][j < 8]  bf16  W2[32 ob + chi(rho)][32 hb + (j&3) + 8 (2 i + (j>>2)) + 4 hi],
  *        chi(rho) = 16 ((rho>>2)&1) + 4 ((rho>>3)&3) + (rho&3)
@@ -444,6 +445,32 @@ typedef struct pv_mlp_desc {
 int pv_mlp_rows(const pv_mlp_desc* d, pv_stream_t stream);
 int pv_mlp_rows_supported(const pv_mlp_desc* d);
 
+/* ---- LayerNorm + Linear on token rows ----------------------------------------------------------------------
+ * Replaces  norm1 -> the q | k | v Linear(s)  of MultiScaleBlock / MultiScaleAttention (pytorchvideo/layers/attention.py:
+ * 729-737 norm1, :425-451 _qkv_proj; the three Linears concatenated along the output dim) in ONE launch:
+ *     y[m][:] = act( W . LayerNorm(x[m][:]; ln_gamma, ln_beta, ln_eps) + b )
+ * x is the fp32 token stream [M][ldx], y is bf16 [M][ldy]; the bf16 operand tensor between LayerNorm and the GEMM is
+ * never written.  `wb` is the host-packed per-output-block LDS image, N/32 blocks of  C/16*1024 + 256  bytes followed
+ * by one more block of padding (prefetched, never used):
+ *   [ks < C/16][hi < 2][rho < 32][j < 8]  bf16  W[32 nb + chi(rho)][32 (ks>>1) + 16 hi + 8 (ks&1) + j]   (chi as above)
+ *   [hi < 2][r < 16]  fp32  b[32 nb + 16 hi + r]  (zeros without bias), then 128 bytes of padding
+ * (pytorchvideo_amd/accelerator/mi355x/emit_mvit.py::pack_ln_linear_weights).  C in {96, 192, 384, 768}, N % 32 == 0. */
+typedef struct pv_ln_linear_desc {
+  const void* x;
+  const void* wb;
+  void* y;
+  const float* ln_gamma;
+  const float* ln_beta;
+  int64_t M;
+  int32_t C, N;
+  int32_t ldx, ldy;
+  int32_t act;
+  int32_t dtype;         /* PV_BF16 */
+  float ln_eps;
+} pv_ln_linear_desc;
+int pv_ln_linear_rows(const pv_ln_linear_desc* d, pv_stream_t stream);
+int pv_ln_linear_rows_supported(const pv_ln_linear_desc* d);
+
 /* ---- execution plan ----------------------------------------------------------------
  * A deploy-form model is specialised to one input size (reference contract:
  * accelerator/deployment/mobile_cpu/utils/model_conversion.py:100-103), so its forward
@@ -454,7 +481,7 @@ enum pv_op_kind {
   PV_OP_CONV3D = 1, PV_OP_DWCONV3D = 2, PV_OP_SE_GATE = 3, PV_OP_POOL3D = 4,
   PV_OP_LAYERNORM = 5, PV_OP_SOFTMAX_ROWS = 6, PV_OP_MEAN_ROWS = 7, PV_OP_POSENC = 8,
   PV_OP_ATTENTION = 9, PV_OP_ADD_ACT = 10, PV_OP_INGEST = 11, PV_OP_EGRESS = 12, PV_OP_TOKEN_POOL = 13,
-  PV_OP_ROI_ALIGN = 14, PV_OP_LATERAL = 15, PV_OP_AFFINE_ROWS = 16, PV_OP_MLP_ROWS = 17
+  PV_OP_ROI_ALIGN = 14, PV_OP_LATERAL = 15, PV_OP_AFFINE_ROWS = 16, PV_OP_MLP_ROWS = 17, PV_OP_LN_LINEAR = 18
 };
 typedef struct pv_plan pv_plan;
 pv_plan* pv_plan_create(void);

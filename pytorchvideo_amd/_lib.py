@@ -17,7 +17,7 @@ ACT_NONE, ACT_RELU, ACT_SWISH, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 POOL_MAX, POOL_AVG = 0, 1
 (OP_CONV3D, OP_DWCONV3D, OP_SE_GATE, OP_POOL3D, OP_LAYERNORM, OP_SOFTMAX_ROWS, OP_MEAN_ROWS,
  OP_POSENC, OP_ATTENTION, OP_ADD_ACT, OP_INGEST, OP_EGRESS, OP_TOKEN_POOL, OP_ROI_ALIGN, OP_LATERAL,
- OP_AFFINE_ROWS, OP_MLP_ROWS) = range(1, 18)
+ OP_AFFINE_ROWS, OP_MLP_ROWS, OP_LN_LINEAR) = range(1, 19)
 
 _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -102,12 +102,16 @@ MlpDesc = _struct("MlpDesc", [
     ("x", _p), ("w12", _p), ("y", _p), ("b2", _p), ("residual", _p), ("ln_gamma", _p), ("ln_beta", _p), ("M", _i64)]
     + _ints("C", "H", "Cout", "ldx", "ldr", "ldy", "act", "dtype") + [("ln_eps", _f32)])
 
+LnLinearDesc = _struct("LnLinearDesc", [
+    ("x", _p), ("wb", _p), ("y", _p), ("ln_gamma", _p), ("ln_beta", _p), ("M", _i64)]
+    + _ints("C", "N", "ldx", "ldy", "act", "dtype") + [("ln_eps", _f32)])
+
 DESC_FOR_OP = {
     OP_CONV3D: Conv3dDesc, OP_DWCONV3D: DwConv3dDesc, OP_SE_GATE: SeGateDesc, OP_POOL3D: Pool3dDesc,
     OP_LAYERNORM: RowsDesc, OP_SOFTMAX_ROWS: RowsDesc, OP_MEAN_ROWS: RowsDesc, OP_POSENC: PosencDesc,
     OP_ATTENTION: AttentionDesc, OP_ADD_ACT: AddDesc, OP_INGEST: LayoutDesc, OP_EGRESS: LayoutDesc,
     OP_TOKEN_POOL: TokenPoolDesc, OP_ROI_ALIGN: RoiAlignDesc, OP_LATERAL: LateralDesc, OP_AFFINE_ROWS: RowsDesc,
-    OP_MLP_ROWS: MlpDesc,
+    OP_MLP_ROWS: MlpDesc, OP_LN_LINEAR: LnLinearDesc,
 }
 
 # every symbol the header declares: (name, restype, argtypes)
@@ -138,6 +142,8 @@ _SYMBOLS = [
     ("pv_lateral_fuse", C.c_int, [C.POINTER(LateralDesc), _p]),
     ("pv_mlp_rows", C.c_int, [C.POINTER(MlpDesc), _p]),
     ("pv_mlp_rows_supported", C.c_int, [C.POINTER(MlpDesc)]),
+    ("pv_ln_linear_rows", C.c_int, [C.POINTER(LnLinearDesc), _p]),
+    ("pv_ln_linear_rows_supported", C.c_int, [C.POINTER(LnLinearDesc)]),
     ("pv_tune_set", C.c_int, [C.c_char_p, C.c_int]),
     ("pv_tune_clear", C.c_int, []),
     ("pv_plan_create", _p, []),
@@ -156,7 +162,7 @@ _SYMBOLS = [
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _lib = None
 

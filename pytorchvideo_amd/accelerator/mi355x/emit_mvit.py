@@ -394,7 +394,55 @@ def pack_mlp_weights(w1, b1, w2):
                      w2p.to(torch.bfloat16).view(torch.int16).view(torch.uint8).reshape(NH, -1),
                      b1p.view(torch.uint8).reshape(NH, -1)], dim=1)
     assert img.shape[1] == KS * 1024 + NOB * 2048 + 256
+    img = torch.cat([img, torch.zeros(1, img.shape[1], dtype=torch.uint8)])      # one block of padding (prefetched, never used)
     return img.reshape(-1).contiguous()
+
+
+def pack_ln_linear_weights(w, b):
+    """The per-output-block LDS image pv_ln_linear_rows streams (layout: include/pv_mi355x.h, pv_ln_linear_desc).
+    w [N, C], b [N] or None (fp32, host) -> uint8 [N/32 * (C/16*1024 + 256)]."""
+    N, Cin = w.shape
+    NB, KS = N // 32, Cin // 16
+    w = w.detach().float().cpu()
+    rows = 32 * torch.arange(NB)[:, None] + torch.tensor([_chi(r) for r in range(32)])[None, :]                # [nb, rho]
+    wr = w[rows]                                                                                              # [nb, rho, C]
+    # [nb, rho, q, hi, e, j] -> [nb, ks = (q, e), hi, rho, j];  channel = 32 q + 16 hi + 8 e + j
+    wp = wr.reshape(NB, 32, Cin // 32, 2, 2, 8).permute(0, 2, 4, 3, 1, 5).reshape(NB, KS * 512)
+    bp = torch.zeros(NB, 64, dtype=torch.float32)
+    if b is not None:
+        bp[:, :32] = b.detach().float().cpu().reshape(NB, 32)          # [hi][r] = b[32 nb + 16 hi + r]
+    img = torch.cat([wp.to(torch.bfloat16).view(torch.int16).view(torch.uint8).reshape(NB, -1),
+                     bp.view(torch.uint8).reshape(NB, -1)], dim=1)
+    assert img.shape[1] == KS * 1024 + 256
+    img = torch.cat([img, torch.zeros(1, img.shape[1], dtype=torch.uint8)])      # one block of padding (prefetched, never used)
+    return img.reshape(-1).contiguous()
+
+
+def can_fuse_ln_linear(sess, norm, lin, x):
+    """norm (LayerNorm over the fp32 stream) -> lin as ONE pv_ln_linear_rows launch (csrc/pv_mlp.hip)?"""
+    if not tuning.get("fuse_ln_qkv") or sess.pv_dtype != L.PV_BF16 or not x.f32 or not isinstance(norm, nn.LayerNorm):
+        return False
+    if not isinstance(lin, nn.Linear) or norm.weight is None or norm.bias is None:
+        return False
+    if tuple(norm.normalized_shape) != (x.C,) or lin.in_features != x.C or x.bs != x.voxels * x.ld:
+        return False
+    d = L.LnLinearDesc()
+    d.x = d.wb = d.y = d.ln_gamma = d.ln_beta = 1
+    d.M, d.C, d.N, d.ldx, d.ldy, d.dtype = x.B * x.voxels, x.C, lin.out_features, x.ld, pad8(lin.out_features), L.PV_BF16
+    return L.lib().pv_ln_linear_rows_supported(C.byref(d)) == 1
+
+
+def emit_ln_linear(sess, norm, lin, x, label):
+    y = sess.alloc_act(x.B, 1, 1, x.voxels, lin.out_features)
+    y.thw, y.has_cls = x.thw, x.has_cls
+    M = x.B * x.voxels
+    f = dict(x=x.ptr, wb=sess.add_weight(pack_ln_linear_weights(lin.weight, lin.bias)), y=y.ptr,
+             ln_gamma=sess.add_weight(norm.weight.detach().float()), ln_beta=sess.add_weight(norm.bias.detach().float()),
+             M=M, C=x.C, N=lin.out_features, ldx=x.ld, ldy=y.ld, act=L.ACT_NONE, dtype=L.PV_BF16, ln_eps=float(norm.eps))
+    sess.add_op(L.OP_LN_LINEAR, f, label="%s|%dx%d c%d->%d ln" % (label, x.B, x.voxels, x.C, lin.out_features),
+                alg_bytes=M * (4 * pad8(x.C) + 2 * pad8(lin.out_features)) + 2 * x.C * lin.out_features,
+                flops=2 * M * x.C * lin.out_features)
+    return y
 
 
 def can_fuse_mlp(sess, blk, x1):
@@ -455,9 +503,24 @@ def emit_mlp_fused(sess, blk, x1):
 
 
 # --------------------------------------------------------------------------- modules
-def emit_multiscale_attention(sess, attn, xn, residual, label="attn"):
+def _qkv_linear(attn):
+    """The q | k | v projection of a MultiScaleAttention as ONE nn.Linear (weights concatenated along the output dim)."""
+    if attn.separate_qkv:
+        ws = [attn.q.weight, attn.k.weight, attn.v.weight]
+        bs = [attn.q.bias, attn.k.bias, attn.v.bias]
+        bias = None if bs[0] is None else torch.cat([b.detach() for b in bs])
+        lin = _linear_from(torch.cat([w.detach() for w in ws]), bias)
+    else:
+        lin = attn.qkv
+    if lin.out_features != 3 * attn.dim_out or attn.dim_out % 8:
+        raise Unsupported("qkv width")
+    return lin
+
+
+def emit_multiscale_attention(sess, attn, xn, residual, label="attn", qkv=None):
     """MultiScaleAttention.forward (attention.py:501-544) + the block's residual join fused into
-    proj's epilogue.  Returns the (B, Nq, dim_out) token tensor."""
+    proj's epilogue.  Returns the (B, Nq, dim_out) token tensor.  `qkv`: the q|k|v tensor when the caller has
+    already produced it (norm1 fused into the projection, emit_ln_linear); `xn` is then not needed."""
     heads = attn.num_heads
     if attn.dropout_rate > 0.0 and not isinstance(attn.proj_drop, (nn.Dropout, nn.Identity)):
         raise Unsupported("proj_drop")
@@ -476,16 +539,9 @@ def emit_multiscale_attention(sess, attn, xn, residual, label="attn"):
                 sess.release(t)
         owned += [q, k, v]
     else:
-        if attn.separate_qkv:
-            ws = [attn.q.weight, attn.k.weight, attn.v.weight]
-            bs = [attn.q.bias, attn.k.bias, attn.v.bias]
-            bias = None if bs[0] is None else torch.cat([b.detach() for b in bs])
-            lin = _linear_from(torch.cat([w.detach() for w in ws]), bias)
-        else:
-            lin = attn.qkv
-        if lin.out_features != 3 * attn.dim_out or attn.dim_out % 8:
-            raise Unsupported("qkv width")
-        qkv = emit_linear(sess, lin, xn, label=label + ".qkv")
+        if qkv is None:
+            qkv = emit_linear(sess, _qkv_linear(attn), xn, label=label + ".qkv")
+        xn = qkv          # (only its grid / cls flag are used below)
         parts = []
         for i in range(3):
             t = qkv.channel_slice(i * attn.dim_out, attn.dim_out)
@@ -536,7 +592,14 @@ def emit_multiscale_block(sess, blk, x):
         raise Unsupported("drop_path %s" % _cls_name(blk.drop_path))
     act = E.act_code(blk.mlp.act)
     widen = blk.dim != blk.dim_out
-    xn = emit_block_norm(sess, blk.norm1, x, label="norm1")
+    qkv = xn = None
+    if not blk.attn.pool_first and not (blk.dim_mul_in_att and widen):
+        lin = _qkv_linear(blk.attn)
+        if can_fuse_ln_linear(sess, blk.norm1, lin, x):
+            # norm1 has no other consumer: LayerNorm + q|k|v projection in one launch, the bf16 operand tensor is never written
+            qkv = emit_ln_linear(sess, blk.norm1, lin, x, label="attn.qkv")
+    if qkv is None:
+        xn = emit_block_norm(sess, blk.norm1, x, label="norm1")
     skip_src = x
     if blk.dim_mul_in_att and widen:
         skip_src = emit_linear(sess, blk.proj, xn, y_f32=True, label="proj_dim")
@@ -546,8 +609,9 @@ def emit_multiscale_block(sess, blk, x):
                                 grid=skip_src.thw, label="pool_skip")
     else:
         x_res = skip_src
-    x1 = emit_multiscale_attention(sess, blk.attn, xn, residual=x_res)
-    sess.release(xn)
+    x1 = emit_multiscale_attention(sess, blk.attn, xn, residual=x_res, qkv=qkv)
+    if xn is not None:
+        sess.release(xn)
     if x_res is not skip_src:
         sess.release(x_res)
     if skip_src is not x:

@@ -34,6 +34,20 @@ namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// LDS-DMA issued from inline asm inside the MFMA streams: hipcc models `__builtin_amdgcn_global_load_lds` as an LDS access
+// and drains lgkmcnt to 0 at the next use of ANY ds_read result (every other DMA piece in the fragment-ring loops below cost
+// a full LDS round trip); an asm statement is opaque to the waitcnt pass.  The data is ordered for the readers by the
+// explicit vmcnt(0) + s_barrier at the top of the next block, nothing else (MI355X_MICROARCH.md, LDS-DMA notes).
+__device__ __forceinline__ void dma16_asm(const unsigned char* gsrc, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+}
+__device__ __forceinline__ void dma4_asm(const unsigned char* gsrc, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_offset(const void* p) {   // generic pointer into LDS -> byte offset inside the workgroup's LDS
+  return (unsigned)(unsigned long)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+
 constexpr int kB1Bytes = 256;   // b1 of one hidden block: [2 lane halves][16] fp32 = 128 B, padded to one 4-byte DMA piece
 
 template <int KS, int NOB> struct MlpGeom {
@@ -195,48 +209,84 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
   }
 
   // ---- hidden blocks ------------------------------------------------------------------------------------------
+  // One wave per SIMD: nothing hides a latency unless the instruction stream does.  The NF = C/16 + 2 Cout/32 weight
+  // fragments of a hidden block are read from LDS through a ring of PF registers sets, PF fragments ahead of the MFMA
+  // that consumes them (left to itself hipcc emits read, read, lgkmcnt(0), mfma, mfma: every pair of MFMAs then waits
+  // a full LDS round trip -- measured 4.4x the MFMA time), and the LDS-DMA pieces of the NEXT block are issued a few
+  // MFMAs apart instead of as one burst at the top.  sched_barrier(0) after every step pins that order; the waitcnt
+  // pass still emits counted lgkmcnt waits.
+  const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_offset(smem));
+  constexpr int NF = KS + 2 * NOB;
+  constexpr int PF = NF < 8 ? NF : 8;
+  constexpr int P = KS + 2 * NOB;                     // 1 KB pieces per block (the b1 piece is extra)
+  constexpr int NPW = (P + 3) / 4;                    // pieces per wave
+  auto frag_off = [](int f) { return f < KS ? f * 1024 : G::W1B + (((f - KS) % NOB) * 2 + (f - KS) / NOB) * 1024; };
   for (int hb = 0; hb < NH; ++hb) {
     __builtin_amdgcn_s_waitcnt(vm(0));      // this wave's pieces of block hb have landed ...
     __builtin_amdgcn_s_barrier();           // ... everybody's have, and everybody is done reading the other buffer
-    if (hb + 1 < NH) stage(hb + 1, (hb + 1) & 1);
-    const unsigned char* w1s = smem + (hb & 1) * G::STAGE + lane * 16;
-    const unsigned char* w2s = w1s + G::W1B;
+    // (the image carries one block of padding behind the last hidden block: the prefetch of block hb + 1 needs no branch --
+    //  a branch per piece splits the loop body into basic blocks and costs a full lgkmcnt(0) drain at every join)
+    const unsigned char* nsrc = wsrc + (long)(hb + 1) * G::STAGE;
+    const unsigned ndst_lds = smem_lds + ((hb + 1) & 1) * G::STAGE;
+    const unsigned char* ws = smem + (hb & 1) * G::STAGE + lane * 16;
     const float* b1s = reinterpret_cast<const float*>(smem + (hb & 1) * G::STAGE + G::W1B + G::W2B) + 16 * hi;
+    bf16x8 ring[PF];
+#pragma unroll
+    for (int f = 0; f < PF; ++f) ring[f] = *reinterpret_cast<const bf16x8*>(ws + frag_off(f));
+    f32x4 bb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bb[g] = *reinterpret_cast<const f32x4*>(b1s + 4 * g);
     f32x16 D0, D1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { D0[r] = 0.f; D1[r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < KS; ks += 2) {
-      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(w1s + ks * 1024);
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(w1s + (ks + 1) * 1024);
-      D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bx[ks], D0, 0, 0, 0);
-      if constexpr (ONE_D) D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bx[ks + 1], D0, 0, 0, 0);
-      else D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bx[ks + 1], D1, 0, 0, 0);
-    }
-    float h[16];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + 4 * g);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) h[4 * g + e] = D0[4 * g + e] + D1[4 * g + e] + bb[e];
-    }
-    pv_apply_act_n<true, 16>(h, d.act);
     bf16x8 hf0, hf1;
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int STEP = NF / NPW;          // a DMA piece of the next block every STEP fragments
+    auto dma = [&](int f) {
+      if (f % STEP == 0 && f / STEP < NPW) {
+        const int pc = 4 * (f / STEP) + wave;
+        if (P % 4 == 0 || pc < P) dma16_asm(nsrc + pc * 1024 + lane * 16, ndst_lds + pc * 1024);
+      }
+      if (f == NF - 1 && wave == 0) dma4_asm(nsrc + P * 1024 + lane * 4, ndst_lds + P * 1024);   // b1 block: 64 lanes x 4 bytes
+    };
+    // phase A: D[32 hidden units][32 rows]
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { hf0[j] = (bf16_t)h[j]; hf1[j] = (bf16_t)h[8 + j]; }
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(w2s + (ob * 2) * 1024);
-      Y[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hf0, Y[ob], 0, 0, 0);
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 afrag = ring[ks % PF];
+      if (ks + PF < NF) ring[ks % PF] = *reinterpret_cast<const bf16x8*>(ws + frag_off(ks + PF));
+      if (ks & 1) D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[ks], D1, 0, 0, 0);
+      else D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[ks], D0, 0, 0, 0);
+      dma(ks);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    {   // hidden activations of this block: D + b1 -> act -> bf16 = the B operand of phase B
+      float h[16];
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(w2s + (ob * 2 + 1) * 1024);
-      Y[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hf1, Y[ob], 0, 0, 0);
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[4 * g + e] = D0[4 * g + e] + D1[4 * g + e] + bb[g][e];
+      pv_apply_act_n<true, 16>(h, d.act);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { hf0[j] = (bf16_t)h[j]; hf1[j] = (bf16_t)h[8 + j]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // phase B: Y[ob] += W2blk[ob] . H
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        const int f = KS + i * NOB + ob;
+        const bf16x8 afrag = ring[f % PF];
+        if (f + PF < NF) ring[f % PF] = *reinterpret_cast<const bf16x8*>(ws + frag_off(f + PF));
+        Y[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, i == 0 ? hf0 : hf1, Y[ob], 0, 0, 0);
+        dma(f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
   // ---- epilogue: 16 consecutive channels per lane and output block ---------------------------------------------
+  __builtin_amdgcn_s_waitcnt(vm(0));        // the padding block's LDS-DMA must not outlive the workgroup
   if (ok) {
     float* yr = static_cast<float*>(d.y) + m * d.ldy + 16 * hi;
 #pragma unroll
@@ -255,6 +305,174 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm + Linear on token rows:  y[m][:] = act( W . LayerNorm(x[m][:]) + b )  -- norm1 -> the fused q|k|v Linear of a
+// MultiScaleBlock (layers/attention.py:729-737 norm1, :425-451 _qkv_proj) in one launch.  Same mapping as above, phase A
+// only: the normalised rows are MFMA B operands in registers, the weight streams through LDS one 32-channel output block
+// at a time (host-packed image, rows permuted by chi so that a lane's 16 accumulator registers are 16 consecutive
+// channels), the epilogue adds the bias and stores 32 bytes of bf16 per lane and block.  The fp32 stream is read once
+// (twice from L2 for the statistics), the bf16 operand tensor LayerNorm used to write and the GEMM to read is gone.
+template <int KS, int MINW>
+__global__ __launch_bounds__(256, MINW) void ln_linear_rows_kernel(const pv_ln_linear_desc d) {
+  constexpr int STAGE = KS * 1024 + kB1Bytes;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long m = (long)blockIdx.x * 128 + wave * 32 + l31;
+  const bool ok = m < d.M;
+  const long mm = ok ? m : 0;
+  const int NB = d.N >> 5;
+  constexpr auto vm = [](int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); };
+
+  const unsigned char* wsrc = static_cast<const unsigned char*>(d.wb);
+  auto stage = [&](int nb, int buf) {
+    const unsigned char* src = wsrc + (long)nb * STAGE;
+    unsigned char* dst = smem + buf * STAGE;
+#pragma unroll
+    for (int p0 = 0; p0 < KS; p0 += 4) {
+      const int p = p0 + wave;
+      if (p < KS)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + p * 1024 + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
+    }
+    if (wave == (KS & 3))   // bias block: 64 lanes x 4 bytes, issued by the wave with the fewest fragments
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + KS * 1024 + lane * 4), (lptr_t)(dst + KS * 1024), 4, 0, 0);
+  };
+
+  // ---- LayerNorm of this lane's half row -> MFMA B fragments (see mlp_rows_kernel for the two passes and the LDS detour)
+  bf16x8 bx[KS];
+  {
+    const float* xr = static_cast<const float*>(d.x) + mm * d.ldx + 16 * hi;
+    const float shift0 = static_cast<const float*>(d.x)[mm * d.ldx];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < KS / 2; ++q) {
+      const f32x4* p4 = reinterpret_cast<const f32x4*>(xr + 32 * q);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = p4[g];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = v[e] - shift0; s1 += t; s2 += t * t; }
+      }
+      if ((q & 3) == 3) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float inv_c = 1.0f / (float)(16 * KS);
+    const float mu_s = s1 * inv_c;
+    const float mean = shift0 + mu_s;
+    const float rstd = rsqrtf(fmaxf(s2 * inv_c - mu_s * mu_s, 0.f) + d.ln_eps);
+    constexpr int NQ = KS / 2;
+    constexpr int GQ2 = (NQ % 2 == 0) ? NQ / 2 : 1;           // groups per LDS round trip: 4 waves x GQ2 x 2 KB of the (still idle) stage buffers
+    static_assert(NQ % GQ2 == 0 && 4 * GQ2 * 2048 <= 2 * STAGE, "LayerNorm staging does not fit");
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const f32x4* g4 = reinterpret_cast<const f32x4*>(d.ln_gamma + 32 * q + 16 * hi);
+      const f32x4* b4 = reinterpret_cast<const f32x4*>(d.ln_beta + 32 * q + 16 * hi);
+      const f32x4* p4 = reinterpret_cast<const f32x4*>(xr + 32 * q);
+      float xn[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = p4[g], gg = g4[g], bb = b4[g];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xn[4 * g + e] = (v[e] - mean) * rstd * gg[e] + bb[e];
+      }
+      bf16x8 t0, t1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { t0[j] = (bf16_t)xn[j]; t1[j] = (bf16_t)xn[8 + j]; }
+      unsigned char* lp = smem + wave * (GQ2 * 2048) + (q % GQ2) * 2048 + lane * 32;
+      *reinterpret_cast<bf16x8*>(lp) = t0;
+      *reinterpret_cast<bf16x8*>(lp + 16) = t1;
+      if (q % GQ2 == GQ2 - 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int qq = q - (GQ2 - 1); qq <= q; ++qq) {
+          const unsigned char* rp = smem + wave * (GQ2 * 2048) + (qq % GQ2) * 2048 + lane * 32;
+          bx[2 * qq] = *reinterpret_cast<const bf16x8*>(rp);
+          bx[2 * qq + 1] = *reinterpret_cast<const bf16x8*>(rp + 16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  __builtin_amdgcn_s_barrier();     // every wave is done with its LayerNorm staging area: the weight stream may use the buffers
+  stage(0, 0);
+  bf16_t* yr = static_cast<bf16_t*>(d.y) + m * d.ldy + 16 * hi;
+  // a wave with at least one row in range issues both store instructions of a block (partially masked or not); a wave
+  // entirely past the last row issues none (the compiler branches around them on exec == 0) and must not count them
+  const bool wave_stores = __builtin_amdgcn_ballot_w64(ok) != 0ul;
+  bool stores_in_flight = false;
+  const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_offset(smem));
+  constexpr int PF = KS < 8 ? KS : 8;             // fragment ring (see mlp_rows_kernel)
+  constexpr int NPW = (KS + 3) / 4;
+  for (int nb = 0; nb < NB; ++nb) {
+    // the LDS-DMA of this block was issued BEFORE the previous block's two stores (in-order return): leave them in flight
+    if (stores_in_flight) __builtin_amdgcn_s_waitcnt(vm(2));
+    else __builtin_amdgcn_s_waitcnt(vm(0));
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* nsrc = wsrc + (long)(nb + 1) * STAGE;      // (one block of padding behind the last: no branch)
+    const unsigned ndst_lds = smem_lds + ((nb + 1) & 1) * STAGE;
+    const unsigned char* ws = smem + (nb & 1) * STAGE + lane * 16;
+    const float* bs = reinterpret_cast<const float*>(smem + (nb & 1) * STAGE + KS * 1024) + 16 * hi;
+    bf16x8 ring[PF];
+#pragma unroll
+    for (int f = 0; f < PF; ++f) ring[f] = *reinterpret_cast<const bf16x8*>(ws + f * 1024);
+    f32x4 bb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bb[g] = *reinterpret_cast<const f32x4*>(bs + 4 * g);
+    f32x16 D0, D1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { D0[r] = 0.f; D1[r] = 0.f; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < KS; ++f) {
+      const bf16x8 afrag = ring[f % PF];
+      if (f + PF < KS) ring[f % PF] = *reinterpret_cast<const bf16x8*>(ws + (f + PF) * 1024);
+      if (f & 1) D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[f], D1, 0, 0, 0);
+      else D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[f], D0, 0, 0, 0);
+      if (f % (KS / NPW) == 0 && f / (KS / NPW) < NPW) {
+        const int pc = 4 * (f / (KS / NPW)) + wave;
+        if (KS % 4 == 0 || pc < KS) dma16_asm(nsrc + pc * 1024 + lane * 16, ndst_lds + pc * 1024);
+      }
+      if (f == KS - 1 && wave == (KS & 3)) dma4_asm(nsrc + KS * 1024 + lane * 4, ndst_lds + KS * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float h[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[4 * g + e] = D0[4 * g + e] + D1[4 * g + e] + bb[g][e];
+    if (d.act != PV_ACT_NONE) pv_apply_act_n<true, 16>(h, d.act);
+    bf16x8 o0, o1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o0[j] = (bf16_t)h[j]; o1[j] = (bf16_t)h[8 + j]; }
+    if (ok) {
+      *reinterpret_cast<bf16x8*>(yr + 32 * nb) = o0;
+      *reinterpret_cast<bf16x8*>(yr + 32 * nb + 8) = o1;
+    }
+    stores_in_flight = wave_stores;
+  }
+  __builtin_amdgcn_s_waitcnt(vm(0));        // the padding block's LDS-DMA must not outlive the workgroup
+}
+
+template <int KS, int MINW> int launch_ln_linear(const pv_ln_linear_desc& d, hipStream_t s) {
+  hipLaunchKernelGGL((ln_linear_rows_kernel<KS, MINW>), dim3((unsigned)pv_ceil_div(d.M, 128)), dim3(256), 0, s, d);
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
+int check_ln_linear(const pv_ln_linear_desc& d) {
+  if (!d.x || !d.wb || !d.y || !d.ln_gamma || !d.ln_beta || d.M <= 0 || d.M > 0x7fffffffL) return PV_ERR_INVALID;
+  if (d.dtype != PV_BF16) return PV_ERR_UNSUPPORTED;
+  if (d.C <= 0 || d.C % 32 || d.N <= 0 || d.N % 32) return PV_ERR_UNSUPPORTED;
+  if (d.ldx < d.C || d.ldx % 4 || d.ldy < d.N || d.ldy % 8) return PV_ERR_INVALID;
+  return PV_OK;
 }
 
 template <int KS, int NOB, int MINW> int launch(const pv_mlp_desc& d, hipStream_t s) {
@@ -296,9 +514,28 @@ extern "C" int pv_mlp_rows(const pv_mlp_desc* dp, pv_stream_t stream) {
   const pv_mlp_desc& d = *dp;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.C == 96 && d.Cout == 96) return launch<6, 3, 2>(d, s);
-  if (d.C == 96 && d.Cout == 192) return launch<6, 6, 2>(d, s);
+  if (d.C == 96 && d.Cout == 192) return launch<6, 6, 1>(d, s);
   if (d.C == 192 && d.Cout == 192) return launch<12, 6, 1>(d, s);
   if (d.C == 192 && d.Cout == 384) return launch<12, 12, 1>(d, s);
   if (d.C == 384 && d.Cout == 384) return launch<24, 12, 1>(d, s);
   return PV_ERR_UNSUPPORTED;
+}
+
+extern "C" int pv_ln_linear_rows_supported(const pv_ln_linear_desc* d) {
+  if (!d || check_ln_linear(*d) != PV_OK) return 0;
+  return d->C == 96 || d->C == 192 || d->C == 384 || d->C == 768;
+}
+
+extern "C" int pv_ln_linear_rows(const pv_ln_linear_desc* dp, pv_stream_t stream) {
+  if (!dp) return PV_ERR_INVALID;
+  const int rc = check_ln_linear(*dp);
+  if (rc != PV_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dp->C) {
+    case 96: return launch_ln_linear<6, 2>(*dp, s);
+    case 192: return launch_ln_linear<12, 2>(*dp, s);
+    case 384: return launch_ln_linear<24, 2>(*dp, s);
+    case 768: return launch_ln_linear<48, 1>(*dp, s);
+    default: return PV_ERR_UNSUPPORTED;
+  }
 }

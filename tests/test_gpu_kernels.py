@@ -939,3 +939,31 @@ def test_fused_mlp_rows(M, Cin, H, Cout, ln, res):
     # unsupported widths are declined, inconsistent descriptors rejected
     d.C = 768
     assert L.lib().pv_mlp_rows_supported(C.byref(d)) == 0
+
+
+@pytest.mark.parametrize("M,Cin,N", [(300, 96, 288), (1001, 192, 576), (6274, 384, 1152), (129, 384, 96), (785 * 2, 768, 2304),
+                                     (31, 96, 32)])
+def test_layernorm_fused_into_the_qkv_linear(M, Cin, N):
+    """pv_ln_linear_rows: norm1 -> q|k|v Linear (layers/attention.py:729-737,425-451) in one launch against fp32 torch
+    on the same bf16-rounded weights; rows with a large mean (shifted one-pass statistics), ragged last tile, a last
+    workgroup whose trailing waves hold no row at all."""
+    from pytorchvideo_amd.accelerator.mi355x.emit_mvit import pack_ln_linear_weights
+    g = torch.Generator().manual_seed(78)
+    w = (torch.randn(N, Cin, generator=g) * Cin ** -0.5).bfloat16().float()
+    b = torch.randn(N, generator=g) * 0.3
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+    x = torch.randn(M, Cin, generator=g) * 2.0 + 5.0 * torch.randn(M, 1, generator=g)
+    want = F.linear(F.layer_norm(x, (Cin,), gamma, beta, 1e-6), w, b)
+    img = pack_ln_linear_weights(w, b).cuda()
+    xd, gd, bd = x.cuda(), gamma.cuda(), beta.cuda()
+    y = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    d = L.LnLinearDesc()
+    d.x, d.wb, d.y, d.ln_gamma, d.ln_beta = xd.data_ptr(), img.data_ptr(), y.data_ptr(), gd.data_ptr(), bd.data_ptr()
+    d.M, d.C, d.N, d.ldx, d.ldy, d.act, d.dtype, d.ln_eps = M, Cin, N, Cin, N, L.ACT_NONE, L.PV_BF16, 1e-6
+    assert L.lib().pv_ln_linear_rows_supported(C.byref(d)) == 1
+    call("pv_ln_linear_rows", d)
+    assert rel_err(y, want) <= 1e-2
+    y2 = torch.zeros_like(y)
+    d.y = y2.data_ptr()
+    call("pv_ln_linear_rows", d)
+    assert torch.equal(y, y2)

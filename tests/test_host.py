@@ -293,7 +293,7 @@ def test_fused_mlp_weight_image_follows_the_documented_layout():
     img = pack_mlp_weights(w1, b1, w2)
     KS, NOB, NH = Cin // 16, Cout // 32, H // 32
     stage = KS * 1024 + NOB * 2048 + 256
-    assert img.dtype == torch.uint8 and img.numel() == NH * stage
+    assert img.dtype == torch.uint8 and img.numel() == (NH + 1) * stage and not img[NH * stage:].any()
     bf = lambda t: t.to(torch.bfloat16)
     for hb in range(NH):
         blk = img[hb * stage:(hb + 1) * stage]
@@ -311,3 +311,27 @@ def test_fused_mlp_weight_image_follows_the_documented_layout():
             for r in range(16):
                 assert c[hi * 16 + r] == b1[32 * hb + (r & 3) + 8 * (r >> 2) + 4 * hi]
         assert not c[32:].any()
+
+
+def test_ln_linear_weight_image_follows_the_documented_layout():
+    import torch
+    from pytorchvideo_amd.accelerator.mi355x.emit_mvit import _chi, pack_ln_linear_weights
+    torch.manual_seed(1)
+    N, Cin = 96, 64
+    w, b = torch.randn(N, Cin), torch.randn(N)
+    img = pack_ln_linear_weights(w, b)
+    KS, NB = Cin // 16, N // 32
+    stage = KS * 1024 + 256
+    assert img.numel() == (NB + 1) * stage and not img[NB * stage:].any()
+    for nb in range(NB):
+        blk = img[nb * stage:(nb + 1) * stage]
+        a = blk[:KS * 1024].view(torch.int16).view(torch.bfloat16).reshape(KS, 2, 32, 8)
+        c = blk[KS * 1024:].view(torch.float32)
+        for ks in range(KS):
+            for hi in range(2):
+                for rho in (0, 6, 19, 31):
+                    for j in range(8):
+                        assert a[ks, hi, rho, j] == w[32 * nb + _chi(rho), 32 * (ks >> 1) + 16 * hi + 8 * (ks & 1) + j].to(torch.bfloat16)
+        for hi in range(2):
+            for r in range(16):
+                assert c[hi * 16 + r] == b[32 * nb + 16 * hi + r]
