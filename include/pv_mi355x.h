@@ -508,6 +508,9 @@ int pv_joint_branches(const pv_joint* j);                          /* 0 until bu
  * queued un-instrumented replay (the host never paces the measurement); minimum over `iters` passes, minus the
  * null interval of an empty event pair */
 int pv_plan_profile(pv_plan* p, pv_stream_t stream, int iters, float* ms_per_op);
+/* symbol of the kernel op `i` was routed to ("gemm_glds_kernel", "pw_stream_kernel", ...; the last one when an op launches
+ * several), known after pv_plan_profile ran; "" before.  The string lives as long as the plan. */
+const char* pv_plan_op_kernel(const pv_plan* p, int i);
 
 #ifdef __cplusplus
 }

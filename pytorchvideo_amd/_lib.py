@@ -160,9 +160,10 @@ _SYMBOLS = [
     ("pv_joint_launch", C.c_int, [_p, _p]),
     ("pv_joint_branches", C.c_int, [_p]),
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
+    ("pv_plan_op_kernel", C.c_char_p, [_p, C.c_int]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _lib = None
 

@@ -259,6 +259,7 @@ class Session:
         out = (C.c_float * n)()
         with torch.cuda.device(self.device):    # the session stays pinned to the device it was finalized on
             L.check(lib.pv_plan_profile(self.plan, self._stream(), iters, out), "profile")
+        self.op_kernels = [(lib.pv_plan_op_kernel(self.plan, i) or b"").decode() for i in range(n)]   # kernel symbol per op
         return [(self.ops[i][3], self.ops[i][0], float(out[i]), self.ops[i][4], self.ops[i][5]) for i in range(n)]
 
     # ------------------------------------------------------------------ tensor views

@@ -663,12 +663,12 @@ template <typename T, int D> int launch_attn(const pv_attention_desc& d, hipStre
   if constexpr (sizeof(T) == 2 && D <= 96) {   // (D = 128 would spill: two score sets + 64 O accumulators)
     const long kv_bytes = ((long)(d.Nk + 192) * (d.ldk > d.ldv ? d.ldk : d.ldv) + D) * 2;   // 32-bit offsets, 2 tiles past the end
     if (pv_tune("attn_pipe", 1) && kv_bytes < 0x7fffffffL) {
-      hipLaunchKernelGGL((attn_pipe_kernel<D>), dim3((unsigned)total), dim3(kThreads), 0, s, d, nqb, (int)total);
+      PV_LAUNCH((attn_pipe_kernel<D>), dim3((unsigned)total), dim3(kThreads), 0, s, d, nqb, (int)total);
       PV_LAUNCH_CHECK();
       return PV_OK;
     }
   }
-  hipLaunchKernelGGL((attn_kernel<T, D>), dim3((unsigned)total), dim3(kThreads), 0, s, d, nqb, (int)total);
+  PV_LAUNCH((attn_kernel<T, D>), dim3((unsigned)total), dim3(kThreads), 0, s, d, nqb, (int)total);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

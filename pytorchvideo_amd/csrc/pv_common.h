@@ -21,6 +21,14 @@ int pv_tune(const char* key, int dflt);                // pv_plan.hip
     if (_e != hipSuccess) return pv_set_hip_error(_e, #expr); \
   } while (0)
 #define PV_LAUNCH_CHECK() PV_HIP_CHECK(hipGetLastError())
+// Every kernel launch goes through PV_LAUNCH: it notes the kernel's symbol (a pointer store) so that pv_plan_profile can
+// report which kernel an op was routed to -- bench.py's `roofline` is per kernel SYMBOL, not per op label.
+void pv_note_kernel(const char* name);                 // pv_plan.hip
+#define PV_LAUNCH(kernel, ...)              \
+  do {                                      \
+    pv_note_kernel(#kernel);                \
+    hipLaunchKernelGGL(kernel, __VA_ARGS__); \
+  } while (0)
 
 // ---- an 8-channel chunk: the unit every kernel moves (16 B of bf16, 32 B of f32) ----
 template <typename T> struct Chunk8;

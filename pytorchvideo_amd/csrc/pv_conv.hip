@@ -314,8 +314,8 @@ int launch_cfg(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   const long tiles = pv_ceil_div(M, BM) * pv_ceil_div(cout_p8, BN);
   if (tiles <= 0 || tiles > 0x7fffffffL) return PV_ERR_INVALID;
   dim3 grid((unsigned)tiles), block(kThreads);
-  if (pw) hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM_, WN_, true>), grid, block, 0, s, d);
-  else hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM_, WN_, false>), grid, block, 0, s, d);
+  if (pw) PV_LAUNCH((conv_igemm_kernel<T, BM, BN, WM_, WN_, true>), grid, block, 0, s, d);
+  else PV_LAUNCH((conv_igemm_kernel<T, BM, BN, WM_, WN_, false>), grid, block, 0, s, d);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

@@ -460,12 +460,12 @@ template <int S, int NW> int launch_plane(const pv_dwconv3d_desc& d, hipStream_t
   dim3 grid((unsigned)blocks), block(kPlaneThreads);
   if (d.n_prefix > 0) {
     const int total = d.B * d.n_prefix * (c_p / 8);
-    hipLaunchKernelGGL(dw_prefix_kernel<bf16_t>, dim3((unsigned)pv_ceil_div(total, kThreads)), dim3(kThreads), 0, s, d);
+    PV_LAUNCH(dw_prefix_kernel<bf16_t>, dim3((unsigned)pv_ceil_div(total, kThreads)), dim3(kThreads), 0, s, d);
     PV_LAUNCH_CHECK();
   }
-  if (d.act == PV_ACT_NONE) hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_NONE>), grid, block, 0, s, d, ntiles, ngroups);
-  else if (d.act == PV_ACT_RELU) hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_RELU>), grid, block, 0, s, d, ntiles, ngroups);
-  else hipLaunchKernelGGL((dw3_plane_kernel<S, NW, PV_ACT_SWISH>), grid, block, 0, s, d, ntiles, ngroups);
+  if (d.act == PV_ACT_NONE) PV_LAUNCH((dw3_plane_kernel<S, NW, PV_ACT_NONE>), grid, block, 0, s, d, ntiles, ngroups);
+  else if (d.act == PV_ACT_RELU) PV_LAUNCH((dw3_plane_kernel<S, NW, PV_ACT_RELU>), grid, block, 0, s, d, ntiles, ngroups);
+  else PV_LAUNCH((dw3_plane_kernel<S, NW, PV_ACT_SWISH>), grid, block, 0, s, d, ntiles, ngroups);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }
@@ -509,7 +509,7 @@ int launch_variant(const pv_dwconv3d_desc& d, const DwGeom& g, hipStream_t s) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
   }
   dim3 grid(g.nblk, d.B), block(kThreads);
-  hipLaunchKernelGGL(kern, grid, block, g.lds, s, d, g.gpb, g.wgroups, g.units_per_batch, g.w_global);
+  PV_LAUNCH(kern, grid, block, g.lds, s, d, g.gpb, g.wgroups, g.units_per_batch, g.w_global);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }
@@ -517,7 +517,7 @@ int launch_variant(const pv_dwconv3d_desc& d, const DwGeom& g, hipStream_t s) {
 template <typename T> int launch_dw(const pv_dwconv3d_desc& d, const DwGeom& g, hipStream_t s) {
   if (d.n_prefix > 0) {
     const int total = d.B * d.n_prefix * (pv_round_up(d.C, 8) / 8);
-    hipLaunchKernelGGL(dw_prefix_kernel<T>, dim3((unsigned)pv_ceil_div(total, kThreads)), dim3(kThreads), 0, s, d);
+    PV_LAUNCH(dw_prefix_kernel<T>, dim3((unsigned)pv_ceil_div(total, kThreads)), dim3(kThreads), 0, s, d);
     PV_LAUNCH_CHECK();
   }
   if (d.gw > 1) return launch_variant<T, 0, 1, 1>(d, g, s);   // channel-wise grouped: the runtime variant

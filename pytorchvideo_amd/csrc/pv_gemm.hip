@@ -428,21 +428,21 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads);
   const int abl = pv_tune("gemm_abl", 0);
   if (abl && vt == 2) {
-    if (abl == 1) { if (pw) hipLaunchKernelGGL((gemm_glds_kernel<true, 2, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-                    else hipLaunchKernelGGL((gemm_glds_kernel<false, 2, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin); }
-    if (abl == 2) { if (pw) hipLaunchKernelGGL((gemm_glds_kernel<true, 2, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-                    else hipLaunchKernelGGL((gemm_glds_kernel<false, 2, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin); }
-    if (abl == 3) { if (pw) hipLaunchKernelGGL((gemm_glds_kernel<true, 2, 3>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-                    else hipLaunchKernelGGL((gemm_glds_kernel<false, 2, 3>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin); }
+    if (abl == 1) { if (pw) PV_LAUNCH((gemm_glds_kernel<true, 2, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+                    else PV_LAUNCH((gemm_glds_kernel<false, 2, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin); }
+    if (abl == 2) { if (pw) PV_LAUNCH((gemm_glds_kernel<true, 2, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+                    else PV_LAUNCH((gemm_glds_kernel<false, 2, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin); }
+    if (abl == 3) { if (pw) PV_LAUNCH((gemm_glds_kernel<true, 2, 3>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+                    else PV_LAUNCH((gemm_glds_kernel<false, 2, 3>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin); }
     PV_LAUNCH_CHECK();
     return PV_OK;
   }
   if (vt == 1) {
-    if (pw) hipLaunchKernelGGL((gemm_glds_kernel<true, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-    else hipLaunchKernelGGL((gemm_glds_kernel<false, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+    if (pw) PV_LAUNCH((gemm_glds_kernel<true, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+    else PV_LAUNCH((gemm_glds_kernel<false, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
   } else {
-    if (pw) hipLaunchKernelGGL((gemm_glds_kernel<true, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-    else hipLaunchKernelGGL((gemm_glds_kernel<false, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+    if (pw) PV_LAUNCH((gemm_glds_kernel<true, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+    else PV_LAUNCH((gemm_glds_kernel<false, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
   }
   PV_LAUNCH_CHECK();
   return PV_OK;

@@ -418,7 +418,7 @@ int launch8(const pv_conv3d_desc& d, int tiles_n, long total, hipStream_t s) {
   PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long resident = 256;   // one workgroup per CU
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads8);
-  hipLaunchKernelGGL(kern, grid, block, lds, s, d, tiles_n, (int)total, 1.0f / (float)d.cin);
+  PV_LAUNCH(kern, grid, block, lds, s, d, tiles_n, (int)total, 1.0f / (float)d.cin);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

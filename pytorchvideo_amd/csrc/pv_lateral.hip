@@ -223,7 +223,7 @@ int launch_lateral(const TapConv& d, int ksteps, size_t lds, hipStream_t s) {
   long nchunks = pv_ceil_div(256 * per_cu, nsplit);
   if (nchunks > ngroups) nchunks = ngroups;
   const long blocks = pv_ceil_div(nchunks, 8) * 8 * nsplit;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kLatThreads), lds, s, d, ksteps, (int)ngroups, (int)nchunks, nsplit);
+  PV_LAUNCH(kern, dim3((unsigned)blocks), dim3(kLatThreads), lds, s, d, ksteps, (int)ngroups, (int)nchunks, nsplit);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

@@ -766,15 +766,15 @@ extern "C" int pv_se_gate(const pv_se_gate_desc* d, pv_stream_t stream) {
     const int cj = (d->C + 63) / 64;
     dim3 grid(d->B), block(kThreads);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (cj <= 1 && d->cr <= 8) hipLaunchKernelGGL((se_gate_fast_kernel<1, 8>), grid, block, lds_f, st, *d);
-    else if (cj <= 2 && d->cr <= 8) hipLaunchKernelGGL((se_gate_fast_kernel<2, 8>), grid, block, lds_f, st, *d);
-    else if (cj <= 4 && d->cr <= 16) hipLaunchKernelGGL((se_gate_fast_kernel<4, 16>), grid, block, lds_f, st, *d);
-    else hipLaunchKernelGGL((se_gate_fast_kernel<7, 32>), grid, block, lds_f, st, *d);
+    if (cj <= 1 && d->cr <= 8) PV_LAUNCH((se_gate_fast_kernel<1, 8>), grid, block, lds_f, st, *d);
+    else if (cj <= 2 && d->cr <= 8) PV_LAUNCH((se_gate_fast_kernel<2, 8>), grid, block, lds_f, st, *d);
+    else if (cj <= 4 && d->cr <= 16) PV_LAUNCH((se_gate_fast_kernel<4, 16>), grid, block, lds_f, st, *d);
+    else PV_LAUNCH((se_gate_fast_kernel<7, 32>), grid, block, lds_f, st, *d);
     PV_LAUNCH_CHECK();
     return PV_OK;
   }
   const size_t lds = sizeof(float) * ((size_t)d->c_p + d->cr + (size_t)(kThreads / cw) * d->c_p);
-  hipLaunchKernelGGL(se_gate_kernel, dim3(d->B), dim3(kThreads), lds, static_cast<hipStream_t>(stream), *d);
+  PV_LAUNCH(se_gate_kernel, dim3(d->B), dim3(kThreads), lds, static_cast<hipStream_t>(stream), *d);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }
@@ -790,15 +790,15 @@ template <typename T> static int pool_launch(const pv_pool3d_desc& d, hipStream_
     const int cgb = CG < 8 ? CG : 8;
     if (nvox > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
     dim3 grid((unsigned)nvox, (unsigned)pv_ceil_div(CG, cgb));
-    hipLaunchKernelGGL(pool_reduce_kernel<T>, grid, dim3(kThreads), 0, s, d, cgb);
+    PV_LAUNCH(pool_reduce_kernel<T>, grid, dim3(kThreads), 0, s, d, cgb);
   } else {
     const long total = nvox * CG;
-    hipLaunchKernelGGL(pool_direct_kernel<T>, dim3(blocks_for(total)), dim3(kThreads), 0, s, d, total);
+    PV_LAUNCH(pool_direct_kernel<T>, dim3(blocks_for(total)), dim3(kThreads), 0, s, d, total);
   }
   PV_LAUNCH_CHECK();
   if (d.n_prefix > 0) {
     const int total = d.B * d.n_prefix * CG;
-    hipLaunchKernelGGL(pool_prefix_kernel<T>, dim3(blocks_for(total)), dim3(kThreads), 0, s, d);
+    PV_LAUNCH(pool_prefix_kernel<T>, dim3(blocks_for(total)), dim3(kThreads), 0, s, d);
     PV_LAUNCH_CHECK();
   }
   return PV_OK;
@@ -839,16 +839,16 @@ extern "C" int pv_ingest_ncdhw(const pv_layout_desc* d, pv_stream_t stream) {
     if (HW % 8 == 0 && (HW * esz) % 16 == 0 && ((uintptr_t)d->src % 16) == 0 && ((uintptr_t)d->dst % 16) == 0 && d->bs % 8 == 0) {
       const long ngroups = nvox / 8;
       dim3 g8(blocks_for(ngroups));
-      if (d->src_dtype == PV_F32) hipLaunchKernelGGL(ingest_c4_vec8_kernel<float>, g8, block, 0, s, *d, ngroups);
-      else if (d->src_dtype == PV_BF16) hipLaunchKernelGGL(ingest_c4_vec8_kernel<bf16_t>, g8, block, 0, s, *d, ngroups);
-      else if (d->src_dtype == PV_U8) hipLaunchKernelGGL(ingest_c4_vec8_kernel<unsigned char>, g8, block, 0, s, *d, ngroups);
+      if (d->src_dtype == PV_F32) PV_LAUNCH(ingest_c4_vec8_kernel<float>, g8, block, 0, s, *d, ngroups);
+      else if (d->src_dtype == PV_BF16) PV_LAUNCH(ingest_c4_vec8_kernel<bf16_t>, g8, block, 0, s, *d, ngroups);
+      else if (d->src_dtype == PV_U8) PV_LAUNCH(ingest_c4_vec8_kernel<unsigned char>, g8, block, 0, s, *d, ngroups);
       else return PV_ERR_UNSUPPORTED;
       PV_LAUNCH_CHECK();
       return PV_OK;
     }
-    if (d->src_dtype == PV_F32) hipLaunchKernelGGL(ingest_c4_kernel<float>, grid, block, 0, s, *d, nvox);
-    else if (d->src_dtype == PV_BF16) hipLaunchKernelGGL(ingest_c4_kernel<bf16_t>, grid, block, 0, s, *d, nvox);
-    else if (d->src_dtype == PV_U8) hipLaunchKernelGGL(ingest_c4_kernel<unsigned char>, grid, block, 0, s, *d, nvox);
+    if (d->src_dtype == PV_F32) PV_LAUNCH(ingest_c4_kernel<float>, grid, block, 0, s, *d, nvox);
+    else if (d->src_dtype == PV_BF16) PV_LAUNCH(ingest_c4_kernel<bf16_t>, grid, block, 0, s, *d, nvox);
+    else if (d->src_dtype == PV_U8) PV_LAUNCH(ingest_c4_kernel<unsigned char>, grid, block, 0, s, *d, nvox);
     else return PV_ERR_UNSUPPORTED;
     PV_LAUNCH_CHECK();
     return PV_OK;
@@ -861,17 +861,17 @@ extern "C" int pv_ingest_ncdhw(const pv_layout_desc* d, pv_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d->t_index && d->src_T <= 0) return PV_ERR_INVALID;
   if (d->src_dtype == PV_U8 && d->dst_dtype == PV_F32)
-    hipLaunchKernelGGL((ingest_kernel<unsigned char, float>), grid, block, 0, s, *d, nvox);
+    PV_LAUNCH((ingest_kernel<unsigned char, float>), grid, block, 0, s, *d, nvox);
   else if (d->src_dtype == PV_U8 && d->dst_dtype == PV_BF16)
-    hipLaunchKernelGGL((ingest_kernel<unsigned char, bf16_t>), grid, block, 0, s, *d, nvox);
+    PV_LAUNCH((ingest_kernel<unsigned char, bf16_t>), grid, block, 0, s, *d, nvox);
   else if (d->src_dtype == PV_F32 && d->dst_dtype == PV_F32)
-    hipLaunchKernelGGL((ingest_kernel<float, float>), grid, block, 0, s, *d, nvox);
+    PV_LAUNCH((ingest_kernel<float, float>), grid, block, 0, s, *d, nvox);
   else if (d->src_dtype == PV_F32 && d->dst_dtype == PV_BF16)
-    hipLaunchKernelGGL((ingest_kernel<float, bf16_t>), grid, block, 0, s, *d, nvox);
+    PV_LAUNCH((ingest_kernel<float, bf16_t>), grid, block, 0, s, *d, nvox);
   else if (d->src_dtype == PV_BF16 && d->dst_dtype == PV_BF16)
-    hipLaunchKernelGGL((ingest_kernel<bf16_t, bf16_t>), grid, block, 0, s, *d, nvox);
+    PV_LAUNCH((ingest_kernel<bf16_t, bf16_t>), grid, block, 0, s, *d, nvox);
   else if (d->src_dtype == PV_BF16 && d->dst_dtype == PV_F32)
-    hipLaunchKernelGGL((ingest_kernel<bf16_t, float>), grid, block, 0, s, *d, nvox);
+    PV_LAUNCH((ingest_kernel<bf16_t, float>), grid, block, 0, s, *d, nvox);
   else
     return PV_ERR_UNSUPPORTED;
   PV_LAUNCH_CHECK();
@@ -887,13 +887,13 @@ extern "C" int pv_egress_ncdhw(const pv_layout_desc* d, pv_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   // src = NDHWC side (src_dtype), dst = NCDHW side (dst_dtype)
   if (d->src_dtype == PV_F32 && d->dst_dtype == PV_F32)
-    hipLaunchKernelGGL((egress_kernel<float, float>), grid, block, 0, s, *d, nvox);
+    PV_LAUNCH((egress_kernel<float, float>), grid, block, 0, s, *d, nvox);
   else if (d->src_dtype == PV_BF16 && d->dst_dtype == PV_F32)
-    hipLaunchKernelGGL((egress_kernel<bf16_t, float>), grid, block, 0, s, *d, nvox);
+    PV_LAUNCH((egress_kernel<bf16_t, float>), grid, block, 0, s, *d, nvox);
   else if (d->src_dtype == PV_BF16 && d->dst_dtype == PV_BF16)
-    hipLaunchKernelGGL((egress_kernel<bf16_t, bf16_t>), grid, block, 0, s, *d, nvox);
+    PV_LAUNCH((egress_kernel<bf16_t, bf16_t>), grid, block, 0, s, *d, nvox);
   else if (d->src_dtype == PV_F32 && d->dst_dtype == PV_BF16)
-    hipLaunchKernelGGL((egress_kernel<float, bf16_t>), grid, block, 0, s, *d, nvox);
+    PV_LAUNCH((egress_kernel<float, bf16_t>), grid, block, 0, s, *d, nvox);
   else
     return PV_ERR_UNSUPPORTED;
   PV_LAUNCH_CHECK();
@@ -950,9 +950,9 @@ extern "C" int pv_affine_rows(const pv_rows_desc* d, pv_stream_t stream) {
   nb = nb < 8192 ? nb : 8192;
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid((unsigned)nb), block(kThreads);
-  if (d->dtype == PV_BF16 && d->x_f32) hipLaunchKernelGGL((affine_rows_kernel<float, bf16_t>), grid, block, 0, s, *d, total, CG);
-  else if (d->dtype == PV_BF16) hipLaunchKernelGGL((affine_rows_kernel<bf16_t, bf16_t>), grid, block, 0, s, *d, total, CG);
-  else if (d->dtype == PV_F32) hipLaunchKernelGGL((affine_rows_kernel<float, float>), grid, block, 0, s, *d, total, CG);
+  if (d->dtype == PV_BF16 && d->x_f32) PV_LAUNCH((affine_rows_kernel<float, bf16_t>), grid, block, 0, s, *d, total, CG);
+  else if (d->dtype == PV_BF16) PV_LAUNCH((affine_rows_kernel<bf16_t, bf16_t>), grid, block, 0, s, *d, total, CG);
+  else if (d->dtype == PV_F32) PV_LAUNCH((affine_rows_kernel<float, float>), grid, block, 0, s, *d, total, CG);
   else return PV_ERR_UNSUPPORTED;
   PV_LAUNCH_CHECK();
   return PV_OK;
@@ -973,11 +973,11 @@ extern "C" int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream) {
     if (d->g_period > 1) nb16 = pv_ceil_div(nb16, d->g_period) * d->g_period;                                   \
     dim3 grid16((unsigned)nb16), block16(kThreads);                                                             \
     if (d->dtype == PV_BF16 && d->x_f32)                                                                        \
-      hipLaunchKernelGGL((layernorm16_kernel<float, bf16_t, G>), grid16, block16, 0, s, *d);                    \
+      PV_LAUNCH((layernorm16_kernel<float, bf16_t, G>), grid16, block16, 0, s, *d);                    \
     else if (d->dtype == PV_BF16)                                                                               \
-      hipLaunchKernelGGL((layernorm16_kernel<bf16_t, bf16_t, G>), grid16, block16, 0, s, *d);                   \
+      PV_LAUNCH((layernorm16_kernel<bf16_t, bf16_t, G>), grid16, block16, 0, s, *d);                   \
     else if (d->dtype == PV_F32)                                                                                \
-      hipLaunchKernelGGL((layernorm16_kernel<float, float, G>), grid16, block16, 0, s, *d);                     \
+      PV_LAUNCH((layernorm16_kernel<float, float, G>), grid16, block16, 0, s, *d);                     \
     else                                                                                                        \
       return PV_ERR_UNSUPPORTED;                                                                                \
     PV_LAUNCH_CHECK();                                                                                          \
@@ -988,7 +988,7 @@ extern "C" int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream) {
 #define PV_LNF(G, NL)                                                                                  \
   do {                                                                                                 \
     const long nb = pv_ceil_div(d->rows, (kThreads / 64) * (64 / G) * 2);                              \
-    hipLaunchKernelGGL((layernorm_f32in_kernel<bf16_t, G, NL>), dim3((unsigned)(nb < 4096 ? nb : 4096)), \
+    PV_LAUNCH((layernorm_f32in_kernel<bf16_t, G, NL>), dim3((unsigned)(nb < 4096 ? nb : 4096)), \
                        dim3(kThreads), 0, s, *d);                                                      \
     PV_LAUNCH_CHECK();                                                                                 \
     return PV_OK;                                                                                      \
@@ -1004,7 +1004,7 @@ extern "C" int pv_layernorm(const pv_rows_desc* d, pv_stream_t stream) {
   if (CG <= 32) PV_LN16(32);
 #undef PV_LN16
   dim3 grid((unsigned)pv_ceil_div(d->rows, kThreads / 64)), block(kThreads);
-#define PV_LN(TI, T, MAXC) hipLaunchKernelGGL((layernorm_kernel<TI, T, MAXC>), grid, block, 0, s, *d)
+#define PV_LN(TI, T, MAXC) PV_LAUNCH((layernorm_kernel<TI, T, MAXC>), grid, block, 0, s, *d)
   if (d->dtype == PV_BF16 && d->x_f32) {
     if (CG <= 64) PV_LN(float, bf16_t, 1); else if (CG <= 128) PV_LN(float, bf16_t, 2);
     else if (CG <= 256) PV_LN(float, bf16_t, 4); else return PV_ERR_UNSUPPORTED;
@@ -1025,8 +1025,8 @@ extern "C" int pv_softmax_rows(const pv_rows_desc* d, pv_stream_t stream) {
   if (v != PV_OK) return v;
   dim3 grid((unsigned)pv_ceil_div(d->rows, kThreads / 64)), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (d->dtype == PV_BF16) hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, block, 0, s, *d);
-  else if (d->dtype == PV_F32) hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, block, 0, s, *d);
+  if (d->dtype == PV_BF16) PV_LAUNCH(softmax_rows_kernel<bf16_t>, grid, block, 0, s, *d);
+  else if (d->dtype == PV_F32) PV_LAUNCH(softmax_rows_kernel<float>, grid, block, 0, s, *d);
   else return PV_ERR_UNSUPPORTED;
   PV_LAUNCH_CHECK();
   return PV_OK;
@@ -1035,7 +1035,7 @@ extern "C" int pv_softmax_rows(const pv_rows_desc* d, pv_stream_t stream) {
 extern "C" int pv_ensemble_scores(const pv_ensemble_desc* d, pv_stream_t stream) {
   if (!d || !d->logits || !d->video_index || !d->accum || !d->counts) return PV_ERR_INVALID;
   if (d->N <= 0 || d->C <= 0 || d->V <= 0 || d->ld < d->C || (d->mode != 0 && d->mode != 1)) return PV_ERR_INVALID;
-  hipLaunchKernelGGL(ensemble_kernel, dim3((unsigned)pv_ceil_div(d->N, kThreads / 64)), dim3(kThreads), 0,
+  PV_LAUNCH(ensemble_kernel, dim3((unsigned)pv_ceil_div(d->N, kThreads / 64)), dim3(kThreads), 0,
                      static_cast<hipStream_t>(stream), *d);
   PV_LAUNCH_CHECK();
   return PV_OK;
@@ -1048,8 +1048,8 @@ extern "C" int pv_mean_rows(const pv_rows_desc* d, pv_stream_t stream) {
   const int nb = (int)(d->rows / d->rows_per_batch);
   dim3 grid(blocks_for((long)nb * d->C)), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (d->dtype == PV_BF16) hipLaunchKernelGGL(mean_rows_kernel<bf16_t>, grid, block, 0, s, *d, nb);
-  else if (d->dtype == PV_F32) hipLaunchKernelGGL(mean_rows_kernel<float>, grid, block, 0, s, *d, nb);
+  if (d->dtype == PV_BF16) PV_LAUNCH(mean_rows_kernel<bf16_t>, grid, block, 0, s, *d, nb);
+  else if (d->dtype == PV_F32) PV_LAUNCH(mean_rows_kernel<float>, grid, block, 0, s, *d, nb);
   else return PV_ERR_UNSUPPORTED;
   PV_LAUNCH_CHECK();
   return PV_OK;
@@ -1063,8 +1063,8 @@ extern "C" int pv_add_posenc(const pv_posenc_desc* d, pv_stream_t stream) {
   const long total = (long)d->B * (d->cls_only ? 1 : rows) * (pv_round_up(d->C, 8) / 8);
   dim3 grid(blocks_for(total)), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (d->dtype == PV_BF16) hipLaunchKernelGGL(posenc_kernel<bf16_t>, grid, block, 0, s, *d, total);
-  else if (d->dtype == PV_F32) hipLaunchKernelGGL(posenc_kernel<float>, grid, block, 0, s, *d, total);
+  if (d->dtype == PV_BF16) PV_LAUNCH(posenc_kernel<bf16_t>, grid, block, 0, s, *d, total);
+  else if (d->dtype == PV_F32) PV_LAUNCH(posenc_kernel<float>, grid, block, 0, s, *d, total);
   else return PV_ERR_UNSUPPORTED;
   PV_LAUNCH_CHECK();
   return PV_OK;
@@ -1076,8 +1076,8 @@ extern "C" int pv_add_act(const pv_add_desc* d, pv_stream_t stream) {
   const long total = d->rows * (pv_round_up(d->C, 8) / 8);
   dim3 grid(blocks_for(total)), block(kThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (d->dtype == PV_BF16) hipLaunchKernelGGL(add_act_kernel<bf16_t>, grid, block, 0, s, *d, total);
-  else if (d->dtype == PV_F32) hipLaunchKernelGGL(add_act_kernel<float>, grid, block, 0, s, *d, total);
+  if (d->dtype == PV_BF16) PV_LAUNCH(add_act_kernel<bf16_t>, grid, block, 0, s, *d, total);
+  else if (d->dtype == PV_F32) PV_LAUNCH(add_act_kernel<float>, grid, block, 0, s, *d, total);
   else return PV_ERR_UNSUPPORTED;
   PV_LAUNCH_CHECK();
   return PV_OK;

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256, MINW) void ln_linear_rows_kernel(const pv_ln_l
 }
 
 template <int KS, int MINW> int launch_ln_linear(const pv_ln_linear_desc& d, hipStream_t s) {
-  hipLaunchKernelGGL((ln_linear_rows_kernel<KS, MINW>), dim3((unsigned)pv_ceil_div(d.M, 128)), dim3(256), 0, s, d);
+  PV_LAUNCH((ln_linear_rows_kernel<KS, MINW>), dim3((unsigned)pv_ceil_div(d.M, 128)), dim3(256), 0, s, d);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }
@@ -478,10 +478,10 @@ int check_ln_linear(const pv_ln_linear_desc& d) {
 template <int KS, int NOB, int MINW> int launch(const pv_mlp_desc& d, hipStream_t s) {
   const unsigned grid = (unsigned)pv_ceil_div(d.M, 128);
   if (d.ln_gamma != nullptr) {
-    if constexpr (KS == 2 * NOB) hipLaunchKernelGGL((mlp_rows_kernel<KS, NOB, true, MINW>), dim3(grid), dim3(256), 0, s, d);
+    if constexpr (KS == 2 * NOB) PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW>), dim3(grid), dim3(256), 0, s, d);
     else return PV_ERR_UNSUPPORTED;
   } else {
-    hipLaunchKernelGGL((mlp_rows_kernel<KS, NOB, false, MINW>), dim3(grid), dim3(256), 0, s, d);
+    PV_LAUNCH((mlp_rows_kernel<KS, NOB, false, MINW>), dim3(grid), dim3(256), 0, s, d);
   }
   PV_LAUNCH_CHECK();
   return PV_OK;

@@ -9,7 +9,7 @@
 
 namespace {
 thread_local std::string g_last_error;
-constexpr int kAbiVersion = 21;
+constexpr int kAbiVersion = 22;
 }  // namespace
 
 int pv_set_hip_error(hipError_t e, const char* what) {
@@ -18,6 +18,11 @@ int pv_set_hip_error(hipError_t e, const char* what) {
   g_last_error = buf;
   return PV_ERR_HIP;
 }
+
+namespace {
+thread_local const char* g_last_kernel = "";
+}  // namespace
+void pv_note_kernel(const char* name) { g_last_kernel = name; }
 
 namespace {
 struct TuneEntry { std::string key; int value; };
@@ -55,6 +60,7 @@ struct pv_plan {
   struct Op {
     int kind;
     std::vector<unsigned char> desc;
+    std::string kernel;      // symbol of the (last) kernel the op launched; filled by pv_plan_profile
   };
   std::vector<Op> ops;
   hipGraph_t graph = nullptr;
@@ -140,6 +146,11 @@ extern "C" int pv_plan_add(pv_plan* p, int op_kind, const void* desc, size_t des
 }
 
 extern "C" int pv_plan_size(const pv_plan* p) { return p ? (int)p->ops.size() : PV_ERR_INVALID; }
+
+extern "C" const char* pv_plan_op_kernel(const pv_plan* p, int i) {
+  if (!p || i < 0 || i >= (int)p->ops.size()) return "";
+  return p->ops[i].kernel.c_str();
+}
 
 extern "C" int pv_plan_launch_range(pv_plan* p, int first, int last, pv_stream_t stream) {
   if (!p || first < 0 || last > (int)p->ops.size() || first > last) return PV_ERR_INVALID;
@@ -294,9 +305,18 @@ extern "C" int pv_plan_profile(pv_plan* p, pv_stream_t stream, int iters, float*
       for (int i = 0; i < n; ++i) {
         const bool timed = (i % kStride) == phase;
         if (timed) PV_HIP_CHECK(hipEventRecord(e0[slot], s));
+        g_last_kernel = "";
         rc = run_op(p->ops[i], stream);
         if (rc != PV_OK) break;
-        if (timed) PV_HIP_CHECK(hipEventRecord(e1[slot++], s));
+        if (timed) {
+          PV_HIP_CHECK(hipEventRecord(e1[slot++], s));
+          // "(gemm_glds_kernel<true, 2>)" -> "gemm_glds_kernel": the symbol without parentheses / template arguments
+          std::string k = g_last_kernel;
+          while (!k.empty() && (k.front() == '(' || k.front() == ' ')) k.erase(k.begin());
+          const size_t cut = k.find_first_of("<) ");
+          if (cut != std::string::npos) k.resize(cut);
+          p->ops[i].kernel = k;
+        }
       }
       if (rc != PV_OK) break;
       PV_HIP_CHECK(hipEventRecord(e0[slot], s));       // null pair

@@ -281,9 +281,9 @@ template <int S, int NW, int KS> int launch_pwdw(const pv_dwconv3d_desc& d, hipS
   const long blocks = pv_ceil_div((long)ntiles * d.B, 8) * 8 * ngroups;
   if (blocks > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
   dim3 grid((unsigned)blocks), block(kPlaneThreads);
-  if (d.act == PV_ACT_NONE) hipLaunchKernelGGL((pwdw_plane_kernel<S, NW, KS, PV_ACT_NONE>), grid, block, 0, s, d, ntiles, ngroups);
-  else if (d.act == PV_ACT_RELU) hipLaunchKernelGGL((pwdw_plane_kernel<S, NW, KS, PV_ACT_RELU>), grid, block, 0, s, d, ntiles, ngroups);
-  else hipLaunchKernelGGL((pwdw_plane_kernel<S, NW, KS, PV_ACT_SWISH>), grid, block, 0, s, d, ntiles, ngroups);
+  if (d.act == PV_ACT_NONE) PV_LAUNCH((pwdw_plane_kernel<S, NW, KS, PV_ACT_NONE>), grid, block, 0, s, d, ntiles, ngroups);
+  else if (d.act == PV_ACT_RELU) PV_LAUNCH((pwdw_plane_kernel<S, NW, KS, PV_ACT_RELU>), grid, block, 0, s, d, ntiles, ngroups);
+  else PV_LAUNCH((pwdw_plane_kernel<S, NW, KS, PV_ACT_SWISH>), grid, block, 0, s, d, ntiles, ngroups);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

@@ -144,9 +144,9 @@ extern "C" int pv_roi_align(const pv_roi_align_desc* dp, pv_stream_t stream) {
   dim3 grid((unsigned)d.R, (unsigned)pv_ceil_div(CG, kSlab));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.dtype == PV_BF16)
-    hipLaunchKernelGGL(roi_align_kernel<bf16_t>, grid, dim3(kThreads), 0, s, d);
+    PV_LAUNCH(roi_align_kernel<bf16_t>, grid, dim3(kThreads), 0, s, d);
   else
-    hipLaunchKernelGGL(roi_align_kernel<float>, grid, dim3(kThreads), 0, s, d);
+    PV_LAUNCH(roi_align_kernel<float>, grid, dim3(kThreads), 0, s, d);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

@@ -217,7 +217,7 @@ template <int NT, int TM, int JP = 1> int launch_stem(const pv_conv3d_desc& d, i
   if (lds > 64 * 1024)
     PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long gx = ngroups < 4096 ? ngroups : 4096;
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nsplit), dim3(kThreads), lds, s, d, ksteps, (int)ngroups);
+  PV_LAUNCH(kern, dim3((unsigned)gx, (unsigned)nsplit), dim3(kThreads), lds, s, d, ksteps, (int)ngroups);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }
@@ -660,7 +660,7 @@ template <int KT, int NW> int launch_stem_pe(const pv_conv3d_desc& d, int wpitch
   const size_t lds = (size_t)KT * ((TH - 1) * 4 + 7) * ((TW - 1) * 4 + 8) * 8;
   const long blocks = (long)d.B * d.To * tiles_h * tiles_w;
   if (blocks > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((stem_pe_kernel<KT, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, d, tiles_h, tiles_w, wpitch);
+  PV_LAUNCH((stem_pe_kernel<KT, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, d, tiles_h, tiles_w, wpitch);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }
@@ -689,7 +689,7 @@ template <int RP, int NT, int TM, int KT = 0> int launch_stem7(const pv_conv3d_d
     PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long blocks = (long)d.B * tiles_h * tiles_w;
   if (blocks > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), lds, s, d, tiles_h, tiles_w, wpitch);
+  PV_LAUNCH(kern, dim3((unsigned)blocks), dim3(kThreads), lds, s, d, tiles_h, tiles_w, wpitch);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }
@@ -885,8 +885,8 @@ template <int NT, int TM, int KS, int DK> int launch_stem_dwt(const pv_conv3d_de
   if (gpc * d.B > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
   const size_t lds = (size_t)NT * 16 * (KS * 32 + 8) * 2 + (size_t)KS * 4 * 4;
   dim3 grid((unsigned)(gpc * d.B)), block(kThreads);
-  if (d.act == PV_ACT_RELU) hipLaunchKernelGGL((stem_c4_dwt_kernel<NT, TM, KS, DK, PV_ACT_RELU>), grid, block, lds, s, d, (int)gpc);
-  else hipLaunchKernelGGL((stem_c4_dwt_kernel<NT, TM, KS, DK, PV_ACT_NONE>), grid, block, lds, s, d, (int)gpc);
+  if (d.act == PV_ACT_RELU) PV_LAUNCH((stem_c4_dwt_kernel<NT, TM, KS, DK, PV_ACT_RELU>), grid, block, lds, s, d, (int)gpc);
+  else PV_LAUNCH((stem_c4_dwt_kernel<NT, TM, KS, DK, PV_ACT_NONE>), grid, block, lds, s, d, (int)gpc);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

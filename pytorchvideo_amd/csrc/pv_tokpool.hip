@@ -176,10 +176,10 @@ extern "C" int pv_token_pool(const pv_token_pool_desc* dp, pv_stream_t stream) {
   const size_t lds = sizeof(float) * (size_t)d.kt * d.kh * d.kw * pv_round_up(d.head_dim, 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool k333 = d.kt == 3 && d.kh == 3 && d.kw == 3;
-  if (d.dtype == PV_BF16 && k333) hipLaunchKernelGGL((token_pool_kernel<bf16_t, true>), grid, block, lds, s, d);
-  else if (d.dtype == PV_BF16) hipLaunchKernelGGL((token_pool_kernel<bf16_t, false>), grid, block, lds, s, d);
-  else if (d.dtype == PV_F32 && k333) hipLaunchKernelGGL((token_pool_kernel<float, true>), grid, block, lds, s, d);
-  else if (d.dtype == PV_F32) hipLaunchKernelGGL((token_pool_kernel<float, false>), grid, block, lds, s, d);
+  if (d.dtype == PV_BF16 && k333) PV_LAUNCH((token_pool_kernel<bf16_t, true>), grid, block, lds, s, d);
+  else if (d.dtype == PV_BF16) PV_LAUNCH((token_pool_kernel<bf16_t, false>), grid, block, lds, s, d);
+  else if (d.dtype == PV_F32 && k333) PV_LAUNCH((token_pool_kernel<float, true>), grid, block, lds, s, d);
+  else if (d.dtype == PV_F32) PV_LAUNCH((token_pool_kernel<float, false>), grid, block, lds, s, d);
   else return PV_ERR_UNSUPPORTED;
   PV_LAUNCH_CHECK();
   return PV_OK;
