@@ -419,7 +419,7 @@ int pv_roi_align(const pv_roi_align_desc* d, pv_stream_t stream);
  *   ln_gamma == NULL:  x is a bf16 operand tensor [M][ldx] (the LayerNorm output); R = residual (fp32 [M][ldr]) or 0.
  * y is fp32 [M][ldy].  dtype must be PV_BF16 (weights bf16, fp32 accumulation / bias / activation / LayerNorm).
  * `w12` is the host-packed per-hidden-block LDS image, H/32 blocks of  C/16*1024 + Cout/32*2048 + 256  bytes
- * FOLLOWED BY ONE MORE BLOCK OF PADDING (any finite values; the kernel prefetches one block ahead without a branch):
+ * FOLLOWED BY TWO MORE BLOCKS OF PADDING (any finite values; the kernel prefetches two blocks ahead without a branch):
  *   [ks < C/16][hi < 2][rho < 32][j < 8]  bf16  W1[32 hb + rho][32 (ks>>1) + 16 hi + 8 (ks&1) + j]
  *   [ob < Cout/32][i < 2][hi < 2][rho < 32][j < 8]  bf16  W2[32 ob + chi(rho)][32 hb + (j&3) + 8 (2 i + (j>>2)) + 4 hi],
  *        chi(rho) = 16 ((rho>>2)&1) + 4 ((rho>>3)&3) + (rho&3)
@@ -451,7 +451,7 @@ int pv_mlp_rows_supported(const pv_mlp_desc* d);
  *     y[m][:] = act( W . LayerNorm(x[m][:]; ln_gamma, ln_beta, ln_eps) + b )
  * x is the fp32 token stream [M][ldx], y is bf16 [M][ldy]; the bf16 operand tensor between LayerNorm and the GEMM is
  * never written.  `wb` is the host-packed per-output-block LDS image, N/32 blocks of  C/16*1024 + 256  bytes followed
- * by one more block of padding (prefetched, never used):
+ * by two more blocks of padding (prefetched, never used):
  *   [ks < C/16][hi < 2][rho < 32][j < 8]  bf16  W[32 nb + chi(rho)][32 (ks>>1) + 16 hi + 8 (ks&1) + j]   (chi as above)
  *   [hi < 2][r < 16]  fp32  b[32 nb + 16 hi + r]  (zeros without bias), then 128 bytes of padding
  * (pytorchvideo_amd/accelerator/mi355x/emit_mvit.py::pack_ln_linear_weights).  C in {96, 192, 384, 768}, N % 32 == 0. */

@@ -232,7 +232,7 @@ def _streams_well(ap, x):
     if st[0] != 1 or st[1] != st[2] or st[1] not in (1, 2):
         return False
     T, H, W = x.thw
-    return x.B * T * H * W * x.C >= (1 << 23)
+    return x.B * T * H * W * x.C >= tuning.get("pool_stream_min_elems")
 
 
 def emit_attention_pool_kv(sess, ap_k, ap_v, xkv, heads, label):
@@ -394,7 +394,7 @@ def pack_mlp_weights(w1, b1, w2):
                      w2p.to(torch.bfloat16).view(torch.int16).view(torch.uint8).reshape(NH, -1),
                      b1p.view(torch.uint8).reshape(NH, -1)], dim=1)
     assert img.shape[1] == KS * 1024 + NOB * 2048 + 256
-    img = torch.cat([img, torch.zeros(1, img.shape[1], dtype=torch.uint8)])      # one block of padding (prefetched, never used)
+    img = torch.cat([img, torch.zeros(2, img.shape[1], dtype=torch.uint8)])      # two blocks of padding (prefetched, never used)
     return img.reshape(-1).contiguous()
 
 
@@ -414,7 +414,7 @@ def pack_ln_linear_weights(w, b):
     img = torch.cat([wp.to(torch.bfloat16).view(torch.int16).view(torch.uint8).reshape(NB, -1),
                      bp.view(torch.uint8).reshape(NB, -1)], dim=1)
     assert img.shape[1] == KS * 1024 + 256
-    img = torch.cat([img, torch.zeros(1, img.shape[1], dtype=torch.uint8)])      # one block of padding (prefetched, never used)
+    img = torch.cat([img, torch.zeros(2, img.shape[1], dtype=torch.uint8)])      # two blocks of padding (prefetched, never used)
     return img.reshape(-1).contiguous()
 
 

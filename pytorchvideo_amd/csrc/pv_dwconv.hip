@@ -510,6 +510,7 @@ int launch_variant(const pv_dwconv3d_desc& d, const DwGeom& g, hipStream_t s) {
   }
   dim3 grid(g.nblk, d.B), block(kThreads);
   PV_LAUNCH(kern, grid, block, g.lds, s, d, g.gpb, g.wgroups, g.units_per_batch, g.w_global);
+  pv_note_kernel("dwconv_kernel");   // (launched through a function pointer: PV_LAUNCH saw only the variable)
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

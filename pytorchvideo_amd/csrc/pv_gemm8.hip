@@ -419,6 +419,7 @@ int launch8(const pv_conv3d_desc& d, int tiles_n, long total, hipStream_t s) {
   const long resident = 256;   // one workgroup per CU
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads8);
   PV_LAUNCH(kern, grid, block, lds, s, d, tiles_n, (int)total, 1.0f / (float)d.cin);
+  pv_note_kernel("gemm8_kernel");   // (launched through a function pointer: PV_LAUNCH saw only the variable)
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

@@ -224,6 +224,7 @@ int launch_lateral(const TapConv& d, int ksteps, size_t lds, hipStream_t s) {
   if (nchunks > ngroups) nchunks = ngroups;
   const long blocks = pv_ceil_div(nchunks, 8) * 8 * nsplit;
   PV_LAUNCH(kern, dim3((unsigned)blocks), dim3(kLatThreads), lds, s, d, ksteps, (int)ngroups, (int)nchunks, nsplit);
+  pv_note_kernel("tap_stream_kernel");   // (launched through a function pointer: PV_LAUNCH saw only the variable)
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

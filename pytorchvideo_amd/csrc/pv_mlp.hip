@@ -60,7 +60,10 @@ template <int KS, int NOB> struct MlpGeom {
 template <int KS, int NOB, bool LN, int MINW>
 __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d) {
   using G = MlpGeom<KS, NOB>;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G::STAGE];
+  // THREE stage buffers: the LDS-DMA of block hb + 2 is issued while block hb is multiplied.  With two (prefetch distance
+  // one block) the last pieces of a block are issued ~100 cycles before the wait at the top of the next iteration and their
+  // whole L2 latency (~1.1 us) is exposed: measured 2.6 us per hidden block for 1.1 us of MFMA + GELU work.
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * G::STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,14 +83,14 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
     constexpr int P = KS + 2 * NOB;
 #pragma unroll
     for (int p0 = 0; p0 < P; p0 += 4) {
-      const int p = p0 + wave;
-      if (p < P)
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + p * 1024 + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
+      const int p = p0 + wave < P ? p0 + wave : P - 1;     // every wave issues the same number of pieces (counted waits)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + p * 1024 + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
     }
     if (wave == 0)   // b1 block: 64 lanes x 4 bytes
       __builtin_amdgcn_global_load_lds((gptr_t)(src + P * 1024 + lane * 4), (lptr_t)(dst + P * 1024), 4, 0, 0);
   };
   stage(0, 0);
+  stage(1, 1);      // (H = 32: block 1 is the padding block)
 
   // ---- prologue: operand fragments and accumulator initialisation --------------------------------------------
   bf16x8 bx[KS];
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
         for (int e = 0; e < 4; ++e) xn[4 * g + e] = (v[e] - mean) * rstd * gg[e] + bb[e];
       }
       {
-        // The fragments take a detour through LDS (this wave's own 2 KB per 32-channel group, inside stage buffer 1,
+        // The fragments take a detour through LDS (this wave's own 2 KB per 32-channel group, inside stage buffer 2,
         // which the weight stream does not touch before the first barrier of the main loop).  Values that vector
         // arithmetic produces start life in the ArchVGPR half of the register file; 96 long-lived fragment registers
         // made that way plus the 192 accumulators made hipcc carry 270-540 registers through scratch, whereas
@@ -142,14 +145,14 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
         bf16x8 t0, t1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { t0[j] = (bf16_t)xn[j]; t1[j] = (bf16_t)xn[8 + j]; }
-        unsigned char* lp = smem + G::STAGE + wave * (GQ * 2048) + (q % GQ) * 2048 + lane * 32;
+        unsigned char* lp = smem + 2 * G::STAGE + wave * (GQ * 2048) + (q % GQ) * 2048 + lane * 32;
         *reinterpret_cast<bf16x8*>(lp) = t0;
         *reinterpret_cast<bf16x8*>(lp + 16) = t1;
         if (q % GQ == GQ - 1) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (also keeps the compiler from forwarding the stores)
 #pragma unroll
           for (int qq = q - (GQ - 1); qq <= q; ++qq) {
-            const unsigned char* rp = smem + G::STAGE + wave * (GQ * 2048) + (qq % GQ) * 2048 + lane * 32;
+            const unsigned char* rp = smem + 2 * G::STAGE + wave * (GQ * 2048) + (qq % GQ) * 2048 + lane * 32;
             bx[2 * qq] = *reinterpret_cast<const bf16x8*>(rp);
             bx[2 * qq + 1] = *reinterpret_cast<const bf16x8*>(rp + 16);
           }
@@ -221,15 +224,20 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
   constexpr int P = KS + 2 * NOB;                     // 1 KB pieces per block (the b1 piece is extra)
   constexpr int NPW = (P + 3) / 4;                    // pieces per wave
   auto frag_off = [](int f) { return f < KS ? f * 1024 : G::W1B + (((f - KS) % NOB) * 2 + (f - KS) / NOB) * 1024; };
+  int cur = 0;                                // stage buffer of block hb (hb % 3, kept without a division)
   for (int hb = 0; hb < NH; ++hb) {
-    __builtin_amdgcn_s_waitcnt(vm(0));      // this wave's pieces of block hb have landed ...
-    __builtin_amdgcn_s_barrier();           // ... everybody's have, and everybody is done reading the other buffer
-    // (the image carries one block of padding behind the last hidden block: the prefetch of block hb + 1 needs no branch --
+    // this wave's pieces of block hb have landed (in-order return: exactly the pieces of block hb + 1 may stay in flight) ...
+    if (wave == 0) __builtin_amdgcn_s_waitcnt(vm(NPW + 1));
+    else __builtin_amdgcn_s_waitcnt(vm(NPW));
+    __builtin_amdgcn_s_barrier();           // ... everybody's have, and everybody is done reading the buffer refilled next
+    // (the image carries TWO blocks of padding behind the last hidden block: the prefetch of block hb + 2 needs no branch --
     //  a branch per piece splits the loop body into basic blocks and costs a full lgkmcnt(0) drain at every join)
-    const unsigned char* nsrc = wsrc + (long)(hb + 1) * G::STAGE;
-    const unsigned ndst_lds = smem_lds + ((hb + 1) & 1) * G::STAGE;
-    const unsigned char* ws = smem + (hb & 1) * G::STAGE + lane * 16;
-    const float* b1s = reinterpret_cast<const float*>(smem + (hb & 1) * G::STAGE + G::W1B + G::W2B) + 16 * hi;
+    const int nxt = cur == 0 ? 2 : cur - 1;   // (hb + 2) % 3
+    const unsigned char* nsrc = wsrc + (long)(hb + 2) * G::STAGE;
+    const unsigned ndst_lds = smem_lds + nxt * G::STAGE;
+    const unsigned char* ws = smem + cur * G::STAGE + lane * 16;
+    const float* b1s = reinterpret_cast<const float*>(smem + cur * G::STAGE + G::W1B + G::W2B) + 16 * hi;
+    cur = cur == 2 ? 0 : cur + 1;
     bf16x8 ring[PF];
 #pragma unroll
     for (int f = 0; f < PF; ++f) ring[f] = *reinterpret_cast<const bf16x8*>(ws + frag_off(f));
@@ -245,7 +253,8 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
     auto dma = [&](int f) {
       if (f % STEP == 0 && f / STEP < NPW) {
         const int pc = 4 * (f / STEP) + wave;
-        if (P % 4 == 0 || pc < P) dma16_asm(nsrc + pc * 1024 + lane * 16, ndst_lds + pc * 1024);
+        const int pq = (P % 4 == 0 || pc < P) ? pc : P - 1;      // every wave issues NPW pieces (the counted wait above relies on it)
+        dma16_asm(nsrc + pq * 1024 + lane * 16, ndst_lds + pq * 1024);
       }
       if (f == NF - 1 && wave == 0) dma4_asm(nsrc + P * 1024 + lane * 4, ndst_lds + P * 1024);   // b1 block: 64 lanes x 4 bytes
     };
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
 template <int KS, int MINW>
 __global__ __launch_bounds__(256, MINW) void ln_linear_rows_kernel(const pv_ln_linear_desc d) {
   constexpr int STAGE = KS * 1024 + kB1Bytes;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE];      // three stage buffers: see mlp_rows_kernel
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -334,9 +343,8 @@ __global__ __launch_bounds__(256, MINW) void ln_linear_rows_kernel(const pv_ln_l
     unsigned char* dst = smem + buf * STAGE;
 #pragma unroll
     for (int p0 = 0; p0 < KS; p0 += 4) {
-      const int p = p0 + wave;
-      if (p < KS)
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + p * 1024 + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
+      const int p = p0 + wave < KS ? p0 + wave : KS - 1;   // every wave issues the same number of pieces (counted waits)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + p * 1024 + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
     }
     if (wave == (KS & 3))   // bias block: 64 lanes x 4 bytes, issued by the wave with the fewest fragments
       __builtin_amdgcn_global_load_lds((gptr_t)(src + KS * 1024 + lane * 4), (lptr_t)(dst + KS * 1024), 4, 0, 0);
@@ -403,23 +411,37 @@ __global__ __launch_bounds__(256, MINW) void ln_linear_rows_kernel(const pv_ln_l
 
   __builtin_amdgcn_s_barrier();     // every wave is done with its LayerNorm staging area: the weight stream may use the buffers
   stage(0, 0);
+  stage(1, 1);
   bf16_t* yr = static_cast<bf16_t*>(d.y) + m * d.ldy + 16 * hi;
   // a wave with at least one row in range issues both store instructions of a block (partially masked or not); a wave
   // entirely past the last row issues none (the compiler branches around them on exec == 0) and must not count them
   const bool wave_stores = __builtin_amdgcn_ballot_w64(ok) != 0ul;
-  bool stores_in_flight = false;
   const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_offset(smem));
   constexpr int PF = KS < 8 ? KS : 8;             // fragment ring (see mlp_rows_kernel)
   constexpr int NPW = (KS + 3) / 4;
+  int cur = 0;
   for (int nb = 0; nb < NB; ++nb) {
-    // the LDS-DMA of this block was issued BEFORE the previous block's two stores (in-order return): leave them in flight
-    if (stores_in_flight) __builtin_amdgcn_s_waitcnt(vm(2));
-    else __builtin_amdgcn_s_waitcnt(vm(0));
+    // Issue order of this wave's vector-memory operations: ... DMA(nb), stores(nb - 2), DMA(nb + 1), stores(nb - 1).
+    // Block nb has landed once at most the operations issued after its pieces are still in flight (in-order return).
+    {
+      const int dma_next = (wave == (KS & 3)) ? NPW + 1 : NPW;
+      const int st = wave_stores ? 2 : 0;
+      const int allow = dma_next + (nb >= 1 ? st : 0) + (nb >= 2 ? st : 0);
+      // (s_waitcnt takes an immediate: the handful of possible counts are separate instructions)
+      if (allow >= NPW + 5) __builtin_amdgcn_s_waitcnt(vm(NPW + 5));
+      else if (allow == NPW + 4) __builtin_amdgcn_s_waitcnt(vm(NPW + 4));
+      else if (allow == NPW + 3) __builtin_amdgcn_s_waitcnt(vm(NPW + 3));
+      else if (allow == NPW + 2) __builtin_amdgcn_s_waitcnt(vm(NPW + 2));
+      else if (allow == NPW + 1) __builtin_amdgcn_s_waitcnt(vm(NPW + 1));
+      else __builtin_amdgcn_s_waitcnt(vm(NPW));
+    }
     __builtin_amdgcn_s_barrier();
-    const unsigned char* nsrc = wsrc + (long)(nb + 1) * STAGE;      // (one block of padding behind the last: no branch)
-    const unsigned ndst_lds = smem_lds + ((nb + 1) & 1) * STAGE;
-    const unsigned char* ws = smem + (nb & 1) * STAGE + lane * 16;
-    const float* bs = reinterpret_cast<const float*>(smem + (nb & 1) * STAGE + KS * 1024) + 16 * hi;
+    const int nxt = cur == 0 ? 2 : cur - 1;                          // (nb + 2) % 3
+    const unsigned char* nsrc = wsrc + (long)(nb + 2) * STAGE;      // (two blocks of padding behind the last: no branch)
+    const unsigned ndst_lds = smem_lds + nxt * STAGE;
+    const unsigned char* ws = smem + cur * STAGE + lane * 16;
+    const float* bs = reinterpret_cast<const float*>(smem + cur * STAGE + KS * 1024) + 16 * hi;
+    cur = cur == 2 ? 0 : cur + 1;
     bf16x8 ring[PF];
 #pragma unroll
     for (int f = 0; f < PF; ++f) ring[f] = *reinterpret_cast<const bf16x8*>(ws + f * 1024);
@@ -438,7 +460,8 @@ __global__ __launch_bounds__(256, MINW) void ln_linear_rows_kernel(const pv_ln_l
       else D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[f], D0, 0, 0, 0);
       if (f % (KS / NPW) == 0 && f / (KS / NPW) < NPW) {
         const int pc = 4 * (f / (KS / NPW)) + wave;
-        if (KS % 4 == 0 || pc < KS) dma16_asm(nsrc + pc * 1024 + lane * 16, ndst_lds + pc * 1024);
+        const int pq = (KS % 4 == 0 || pc < KS) ? pc : KS - 1;      // every wave issues NPW pieces (counted waits)
+        dma16_asm(nsrc + pq * 1024 + lane * 16, ndst_lds + pq * 1024);
       }
       if (f == KS - 1 && wave == (KS & 3)) dma4_asm(nsrc + KS * 1024 + lane * 4, ndst_lds + KS * 1024);
       __builtin_amdgcn_sched_barrier(0);
@@ -456,7 +479,6 @@ __global__ __launch_bounds__(256, MINW) void ln_linear_rows_kernel(const pv_ln_l
       *reinterpret_cast<bf16x8*>(yr + 32 * nb) = o0;
       *reinterpret_cast<bf16x8*>(yr + 32 * nb + 8) = o1;
     }
-    stores_in_flight = wave_stores;
   }
   __builtin_amdgcn_s_waitcnt(vm(0));        // the padding block's LDS-DMA must not outlive the workgroup
 }

@@ -344,6 +344,7 @@ int launch_pw_f(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) 
       if (nchunks2 > ngroups2) nchunks2 = ngroups2;
       const long blocks2 = pv_ceil_div(nchunks2, 8) * 8 * nsplit2;
       PV_LAUNCH(kern2, dim3((unsigned)blocks2), dim3(kThreads), lds, s, d, ksteps, (int)ngroups2, (int)nchunks2, nsplit2);
+      pv_note_kernel("pw_stream_kernel");   // (launched through a function pointer: PV_LAUNCH saw only the variable)
       PV_LAUNCH_CHECK();
       return PV_OK;
     } else {
@@ -362,6 +363,7 @@ int launch_pw_f(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) 
   if (nchunks > ngroups) nchunks = ngroups;
   const long blocks = pv_ceil_div(nchunks, 8) * 8 * nsplit;
   PV_LAUNCH(kern, dim3((unsigned)blocks), dim3(kThreads), lds, s, d, ksteps, (int)ngroups, (int)nchunks, nsplit);
+  pv_note_kernel("pw_stream_kernel");   // (launched through a function pointer: PV_LAUNCH saw only the variable)
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

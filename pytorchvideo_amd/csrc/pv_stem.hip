@@ -218,6 +218,7 @@ template <int NT, int TM, int JP = 1> int launch_stem(const pv_conv3d_desc& d, i
     PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long gx = ngroups < 4096 ? ngroups : 4096;
   PV_LAUNCH(kern, dim3((unsigned)gx, (unsigned)nsplit), dim3(kThreads), lds, s, d, ksteps, (int)ngroups);
+  pv_note_kernel("stem_c4_kernel");   // (launched through a function pointer: PV_LAUNCH saw only the variable)
   PV_LAUNCH_CHECK();
   return PV_OK;
 }
@@ -690,6 +691,7 @@ template <int RP, int NT, int TM, int KT = 0> int launch_stem7(const pv_conv3d_d
   const long blocks = (long)d.B * tiles_h * tiles_w;
   if (blocks > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
   PV_LAUNCH(kern, dim3((unsigned)blocks), dim3(kThreads), lds, s, d, tiles_h, tiles_w, wpitch);
+  pv_note_kernel("stem7_kernel");   // (launched through a function pointer: PV_LAUNCH saw only the variable)
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

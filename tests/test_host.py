@@ -293,7 +293,7 @@ def test_fused_mlp_weight_image_follows_the_documented_layout():
     img = pack_mlp_weights(w1, b1, w2)
     KS, NOB, NH = Cin // 16, Cout // 32, H // 32
     stage = KS * 1024 + NOB * 2048 + 256
-    assert img.dtype == torch.uint8 and img.numel() == (NH + 1) * stage and not img[NH * stage:].any()
+    assert img.dtype == torch.uint8 and img.numel() == (NH + 2) * stage and not img[NH * stage:].any()
     bf = lambda t: t.to(torch.bfloat16)
     for hb in range(NH):
         blk = img[hb * stage:(hb + 1) * stage]
@@ -322,7 +322,7 @@ def test_ln_linear_weight_image_follows_the_documented_layout():
     img = pack_ln_linear_weights(w, b)
     KS, NB = Cin // 16, N // 32
     stage = KS * 1024 + 256
-    assert img.numel() == (NB + 1) * stage and not img[NB * stage:].any()
+    assert img.numel() == (NB + 2) * stage and not img[NB * stage:].any()
     for nb in range(NB):
         blk = img[nb * stage:(nb + 1) * stage]
         a = blk[:KS * 1024].view(torch.int16).view(torch.bfloat16).reshape(KS, 2, 32, 8)
