@@ -57,7 +57,9 @@ template <int KS, int NOB> struct MlpGeom {
 };
 
 // KS = C / 16 (even), NOB = Cout / 32, LN: x is the fp32 stream (LayerNorm here, residual = x, needs C == Cout)
-template <int KS, int NOB, bool LN, int MINW>
+// ABL: ablation builds for tools/bench_mlp.py (timing only, wrong results): 1 no activation, 2 no weight streaming, 3 no phase B,
+// 4 no phase A, 5 no barrier, 6 no LDS fragment reads
+template <int KS, int NOB, bool LN, int MINW, int ABL = 0>
 __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d) {
   using G = MlpGeom<KS, NOB>;
   // THREE stage buffers: the LDS-DMA of block hb + 2 is issued while block hb is multiplied.  With two (prefetch distance
@@ -227,9 +229,11 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
   int cur = 0;                                // stage buffer of block hb (hb % 3, kept without a division)
   for (int hb = 0; hb < NH; ++hb) {
     // this wave's pieces of block hb have landed (in-order return: exactly the pieces of block hb + 1 may stay in flight) ...
-    if (wave == 0) __builtin_amdgcn_s_waitcnt(vm(NPW + 1));
-    else __builtin_amdgcn_s_waitcnt(vm(NPW));
-    __builtin_amdgcn_s_barrier();           // ... everybody's have, and everybody is done reading the buffer refilled next
+    if constexpr (ABL != 2) {
+      if (wave == 0) __builtin_amdgcn_s_waitcnt(vm(NPW + 1));
+      else __builtin_amdgcn_s_waitcnt(vm(NPW));
+    }
+    if constexpr (ABL != 5) __builtin_amdgcn_s_barrier();   // ... everybody's have, and everybody is done reading the buffer refilled next
     // (the image carries TWO blocks of padding behind the last hidden block: the prefetch of block hb + 2 needs no branch --
     //  a branch per piece splits the loop body into basic blocks and costs a full lgkmcnt(0) drain at every join)
     const int nxt = cur == 0 ? 2 : cur - 1;   // (hb + 2) % 3
@@ -251,6 +255,7 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
     __builtin_amdgcn_sched_barrier(0);
     constexpr int STEP = NF / NPW;          // a DMA piece of the next block every STEP fragments
     auto dma = [&](int f) {
+      if constexpr (ABL == 2) return;
       if (f % STEP == 0 && f / STEP < NPW) {
         const int pc = 4 * (f / STEP) + wave;
         const int pq = (P % 4 == 0 || pc < P) ? pc : P - 1;      // every wave issues NPW pieces (the counted wait above relies on it)
@@ -262,9 +267,11 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const bf16x8 afrag = ring[ks % PF];
-      if (ks + PF < NF) ring[ks % PF] = *reinterpret_cast<const bf16x8*>(ws + frag_off(ks + PF));
-      if (ks & 1) D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[ks], D1, 0, 0, 0);
-      else D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[ks], D0, 0, 0, 0);
+      if (ABL != 6 && ks + PF < NF) ring[ks % PF] = *reinterpret_cast<const bf16x8*>(ws + frag_off(ks + PF));
+      if constexpr (ABL != 4) {
+        if (ks & 1) D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[ks], D1, 0, 0, 0);
+        else D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[ks], D0, 0, 0, 0);
+      }
       dma(ks);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) h[4 * g + e] = D0[4 * g + e] + D1[4 * g + e] + bb[g][e];
-      pv_apply_act_n<true, 16>(h, d.act);
+      if constexpr (ABL != 1) pv_apply_act_n<true, 16>(h, d.act);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { hf0[j] = (bf16_t)h[j]; hf1[j] = (bf16_t)h[8 + j]; }
     }
@@ -286,8 +293,9 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
       for (int ob = 0; ob < NOB; ++ob) {
         const int f = KS + i * NOB + ob;
         const bf16x8 afrag = ring[f % PF];
-        if (f + PF < NF) ring[f % PF] = *reinterpret_cast<const bf16x8*>(ws + frag_off(f + PF));
-        Y[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, i == 0 ? hf0 : hf1, Y[ob], 0, 0, 0);
+        if (ABL != 6 && f + PF < NF) ring[f % PF] = *reinterpret_cast<const bf16x8*>(ws + frag_off(f + PF));
+        if constexpr (ABL != 3) Y[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, i == 0 ? hf0 : hf1, Y[ob], 0, 0, 0);
+        else asm volatile("" :: "v"(afrag), "v"(hf0), "v"(hf1));
         dma(f);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -499,6 +507,21 @@ int check_ln_linear(const pv_ln_linear_desc& d) {
 
 template <int KS, int NOB, int MINW> int launch(const pv_mlp_desc& d, hipStream_t s) {
   const unsigned grid = (unsigned)pv_ceil_div(d.M, 128);
+  if constexpr (KS == 24 && NOB == 12) {
+    const int abl = pv_tune("mlp_abl", 0);      // tools/bench_mlp.py only: timing builds with wrong results
+    if (abl && d.ln_gamma != nullptr) {
+      switch (abl) {
+        case 1: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, 1>), dim3(grid), dim3(256), 0, s, d); break;
+        case 2: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, 2>), dim3(grid), dim3(256), 0, s, d); break;
+        case 3: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, 3>), dim3(grid), dim3(256), 0, s, d); break;
+        case 4: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, 4>), dim3(grid), dim3(256), 0, s, d); break;
+        case 5: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, 5>), dim3(grid), dim3(256), 0, s, d); break;
+        default: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, 6>), dim3(grid), dim3(256), 0, s, d); break;
+      }
+      PV_LAUNCH_CHECK();
+      return PV_OK;
+    }
+  }
   if (d.ln_gamma != nullptr) {
     if constexpr (KS == 2 * NOB) PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW>), dim3(grid), dim3(256), 0, s, d);
     else return PV_ERR_UNSUPPORTED;
