@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
   // THREE stage buffers: the LDS-DMA of block hb + 2 is issued while block hb is multiplied.  With two (prefetch distance
   // one block) the last pieces of a block are issued ~100 cycles before the wait at the top of the next iteration and their
   // whole L2 latency (~1.1 us) is exposed: measured 2.6 us per hidden block for 1.1 us of MFMA + GELU work.
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * G::STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * G::STAGE + NOB * 128];   // + b2 (LayerNorm mode: read in the epilogue)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,6 +99,9 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
   f32x16 Y[NOB];
   if constexpr (LN) {
     static_assert(KS == 2 * NOB, "LayerNorm mode needs C == Cout");
+    // b2 -> LDS: the epilogue adds it while storing, and a GLOBAL load between global stores is serialised by the compiler
+    // (it cannot prove y and b2 do not alias: one L2 round trip per 64 bytes stored -- 48 of them, measured ~25 us per launch)
+    if (tid < NOB * 8) reinterpret_cast<f32x4*>(smem + 3 * G::STAGE)[tid] = reinterpret_cast<const f32x4*>(d.b2)[tid];
     const float* xr = static_cast<const float*>(d.x) + mm * d.ldx + 16 * hi;
     // Pass 1: row statistics, one shifted pass (shift = the row's first element, the same for both lane halves: the
     // sums of (x - shift) and (x - shift)^2 do not cancel catastrophically however far the row's mean is from 0).
@@ -220,6 +223,10 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
   // a full LDS round trip -- measured 4.4x the MFMA time), and the LDS-DMA pieces of the NEXT block are issued a few
   // MFMAs apart instead of as one burst at the top.  sched_barrier(0) after every step pins that order; the waitcnt
   // pass still emits counted lgkmcnt waits.
+  // Every load the COMPILER knows of is complete before the loop: the accumulator blocks come straight from global loads,
+  // and hipcc would otherwise place its waits for them (vmcnt(36) ... vmcnt(0)) inside the loop body, where they also drain
+  // the LDS-DMA prefetches it cannot see (inline asm) -- every iteration (measured: 41 % of the wave cycles parked).
+  __builtin_amdgcn_s_waitcnt(vm(0));
   const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_offset(smem));
   constexpr int NF = KS + 2 * NOB;
   constexpr int PF = NF < 8 ? NF : 8;
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
     for (int ob = 0; ob < NOB; ++ob) {
       f32x4* p4 = reinterpret_cast<f32x4*>(yr + 32 * ob);
       if constexpr (LN) {
-        const f32x4* c4 = reinterpret_cast<const f32x4*>(d.b2 + 32 * ob + 16 * hi);
+        const f32x4* c4 = reinterpret_cast<const f32x4*>(smem + 3 * G::STAGE) + 8 * ob + 4 * hi;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 cc = c4[g];
