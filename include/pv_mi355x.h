@@ -418,12 +418,14 @@ int pv_roi_align(const pv_roi_align_desc* d, pv_stream_t stream);
  *                      in the kernel and R = x (the row is read once); needs C == Cout, residual == NULL.
  *   ln_gamma == NULL:  x is a bf16 operand tensor [M][ldx] (the LayerNorm output); R = residual (fp32 [M][ldr]) or 0.
  * y is fp32 [M][ldy].  dtype must be PV_BF16 (weights bf16, fp32 accumulation / bias / activation / LayerNorm).
- * `w12` is the host-packed per-hidden-block LDS image, H/32 blocks of  C/16*1024 + Cout/32*2048 + 256  bytes
- * FOLLOWED BY TWO MORE BLOCKS OF PADDING (any finite values; the kernel prefetches two blocks ahead without a branch):
- *   [ks < C/16][hi < 2][rho < 32][j < 8]  bf16  W1[32 hb + rho][32 (ks>>1) + 16 hi + 8 (ks&1) + j]
- *   [ob < Cout/32][i < 2][hi < 2][rho < 32][j < 8]  bf16  W2[32 ob + chi(rho)][32 hb + (j&3) + 8 (2 i + (j>>2)) + 4 hi],
+ * `w12` is the host-packed LDS image the kernel streams: H/32 + 1 blocks of  C/16*1024 + Cout/32*2048 + 256  bytes, block j
+ * holding W1 of hidden block j and W2 of hidden block j - 1 (the kernel multiplies phase B one block behind phase A so that the
+ * activation issues in the shadow of MFMAs; W2 of block -1, W1 and b1 of block H/32 are zeros), FOLLOWED BY TWO MORE BLOCKS OF
+ * PADDING (any finite values; the kernel prefetches two blocks ahead without a branch).  Block j:
+ *   [ks < C/16][hi < 2][rho < 32][j8 < 8]  bf16  W1[32 j + rho][32 (ks>>1) + 16 hi + 8 (ks&1) + j8]
+ *   [ob < Cout/32][i < 2][hi < 2][rho < 32][j8 < 8]  bf16  W2[32 ob + chi(rho)][32 (j-1) + (j8&3) + 8 (2 i + (j8>>2)) + 4 hi],
  *        chi(rho) = 16 ((rho>>2)&1) + 4 ((rho>>3)&3) + (rho&3)
- *   [hi < 2][r < 16] fp32  b1[32 hb + (r&3) + 8 (r>>2) + 4 hi]  (zeros when the layer has no bias), then 128 bytes of padding
+ *   [hi < 2][r < 16] fp32  b1[32 j + (r&3) + 8 (r>>2) + 4 hi]  (zeros when the layer has no bias), then 128 bytes of padding
  * (pytorchvideo_amd/accelerator/mi355x/emit_mvit.py::pack_mlp_weights builds it).  b2 is [Cout] fp32 or NULL.
  * pv_mlp_rows_supported(d) == 1 for the (C, Cout) pairs the kernel is instantiated for (MViT-B: 96/192, 192/192,
  * 192/384, 384/384; H any multiple of 32). */

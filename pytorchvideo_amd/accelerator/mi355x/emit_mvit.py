@@ -369,7 +369,7 @@ def _chi(rho):
 
 def pack_mlp_weights(w1, b1, w2):
     """The per-hidden-block LDS image pv_mlp_rows streams (layout: include/pv_mi355x.h, pv_mlp_desc).
-    w1 [H, C], b1 [H] or None, w2 [Cout, H] (fp32, host) -> uint8 [H/32 * (C/16*1024 + Cout/32*2048 + 256)]."""
+    w1 [H, C], b1 [H] or None, w2 [Cout, H] (fp32, host) -> uint8 [(H/32 + 3) * (C/16*1024 + Cout/32*2048 + 256)]."""
     H, Cin = w1.shape
     Cout = w2.shape[0]
     NH, KS, NOB = H // 32, Cin // 16, Cout // 32
@@ -390,11 +390,15 @@ def pack_mlp_weights(w1, b1, w2):
     b1p = torch.zeros(NH, 64, dtype=torch.float32)                                                            # 128 B + 128 B padding
     if b1 is not None:
         b1p[:, :32] = b1.detach().float().cpu()[unit].reshape(NH, 32)
-    img = torch.cat([w1p.to(torch.bfloat16).view(torch.int16).view(torch.uint8).reshape(NH, -1),
-                     w2p.to(torch.bfloat16).view(torch.int16).view(torch.uint8).reshape(NH, -1),
-                     b1p.view(torch.uint8).reshape(NH, -1)], dim=1)
+    # the kernel's software pipeline multiplies phase B of hidden block j - 1 in iteration j: image block j = [W1(j) | W2(j-1) | b1(j)],
+    # j = 0 .. NH with W2(-1) = W1(NH) = b1(NH) = 0, followed by two blocks of padding (prefetched, never used)
+    z = lambda t: torch.zeros(1, t.shape[1], dtype=t.dtype)
+    w1b = torch.cat([w1p, z(w1p)]).to(torch.bfloat16).view(torch.int16).view(torch.uint8).reshape(NH + 1, -1)
+    w2b = torch.cat([z(w2p), w2p]).to(torch.bfloat16).view(torch.int16).view(torch.uint8).reshape(NH + 1, -1)
+    b1b = torch.cat([b1p, z(b1p)]).view(torch.uint8).reshape(NH + 1, -1)
+    img = torch.cat([w1b, w2b, b1b], dim=1)
     assert img.shape[1] == KS * 1024 + NOB * 2048 + 256
-    img = torch.cat([img, torch.zeros(2, img.shape[1], dtype=torch.uint8)])      # two blocks of padding (prefetched, never used)
+    img = torch.cat([img, torch.zeros(2, img.shape[1], dtype=torch.uint8)])
     return img.reshape(-1).contiguous()
 
 

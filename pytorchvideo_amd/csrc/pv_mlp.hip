@@ -59,7 +59,9 @@ template <int KS, int NOB> struct MlpGeom {
 // KS = C / 16 (even), NOB = Cout / 32, LN: x is the fp32 stream (LayerNorm here, residual = x, needs C == Cout)
 // ABL: ablation builds for tools/bench_mlp.py (timing only, wrong results): 1 no activation, 2 no weight streaming, 3 no phase B,
 // 4 no phase A, 5 no barrier, 6 no LDS fragment reads
-template <int KS, int NOB, bool LN, int MINW, int ABL = 0>
+// ACT: the activation between the two Linears as a compile-time constant (PV_ACT_GELU for MViT), or -1 = read d.act at
+// run time (any pv_act; a branch tree per element inside the MFMA stream, slower).
+template <int KS, int NOB, bool LN, int MINW, int ACT, int ABL = 0>
 __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d) {
   using G = MlpGeom<KS, NOB>;
   // THREE stage buffers: the LDS-DMA of block hb + 2 is issued while block hb is multiplied.  With two (prefetch distance
@@ -233,16 +235,24 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
   constexpr int P = KS + 2 * NOB;                     // 1 KB pieces per block (the b1 piece is extra)
   constexpr int NPW = (P + 3) / 4;                    // pieces per wave
   auto frag_off = [](int f) { return f < KS ? f * 1024 : G::W1B + (((f - KS) % NOB) * 2 + (f - KS) / NOB) * 1024; };
-  int cur = 0;                                // stage buffer of block hb (hb % 3, kept without a division)
-  for (int hb = 0; hb < NH; ++hb) {
+  // Software pipeline over the hidden blocks (the host image is packed for it: block j = [W1(j) | W2(j-1) | b1(j)], j = 0..NH,
+  // W2(-1) = W1(NH) = 0): iteration j multiplies phase A of block j, then phase B of block j-1 -- whose B operand, the
+  // activations of block j-1, was finished in iteration j-1 -- and slices the bias + activation + bf16 conversion of block j
+  // between those phase-B MFMAs.  The activation's ~200 VALU instructions then issue in the shadow of MFMAs that do not
+  // depend on them instead of stalling the matrix pipe between phase A and phase B (ablation: 29 of 127 us per launch).
+  int cur = 0;                                // stage buffer of block j (j % 3, kept without a division)
+  bf16x8 hp0, hp1;                            // activations of the previous hidden block (phase B operand)
+#pragma unroll
+  for (int j8 = 0; j8 < 8; ++j8) { hp0[j8] = (bf16_t)0.f; hp1[j8] = (bf16_t)0.f; }
+  for (int hb = 0; hb <= NH; ++hb) {
     // this wave's pieces of block hb have landed (in-order return: exactly the pieces of block hb + 1 may stay in flight) ...
     if constexpr (ABL != 2) {
       if (wave == 0) __builtin_amdgcn_s_waitcnt(vm(NPW + 1));
       else __builtin_amdgcn_s_waitcnt(vm(NPW));
     }
     if constexpr (ABL != 5) __builtin_amdgcn_s_barrier();   // ... everybody's have, and everybody is done reading the buffer refilled next
-    // (the image carries TWO blocks of padding behind the last hidden block: the prefetch of block hb + 2 needs no branch --
-    //  a branch per piece splits the loop body into basic blocks and costs a full lgkmcnt(0) drain at every join)
+    // (the image carries TWO blocks of padding behind block NH: the prefetch of block hb + 2 needs no branch -- a branch
+    //  per piece splits the loop body into basic blocks and costs a full lgkmcnt(0) drain at every join)
     const int nxt = cur == 0 ? 2 : cur - 1;   // (hb + 2) % 3
     const unsigned char* nsrc = wsrc + (long)(hb + 2) * G::STAGE;
     const unsigned ndst_lds = smem_lds + nxt * G::STAGE;
@@ -258,9 +268,8 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
     f32x16 D0, D1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { D0[r] = 0.f; D1[r] = 0.f; }
-    bf16x8 hf0, hf1;
     __builtin_amdgcn_sched_barrier(0);
-    constexpr int STEP = NF / NPW;          // a DMA piece of the next block every STEP fragments
+    constexpr int STEP = NF / NPW;          // a DMA piece of block hb + 2 every STEP fragments
     auto dma = [&](int f) {
       if constexpr (ABL == 2) return;
       if (f % STEP == 0 && f / STEP < NPW) {
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
       }
       if (f == NF - 1 && wave == 0) dma4_asm(nsrc + P * 1024 + lane * 4, ndst_lds + P * 1024);   // b1 block: 64 lanes x 4 bytes
     };
-    // phase A: D[32 hidden units][32 rows]
+    // phase A of block hb: D[32 hidden units][32 rows]
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const bf16x8 afrag = ring[ks % PF];
@@ -282,31 +291,35 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
       dma(ks);
       __builtin_amdgcn_sched_barrier(0);
     }
-    {   // hidden activations of this block: D + b1 -> act -> bf16 = the B operand of phase B
-      float h[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[4 * g + e] = D0[4 * g + e] + D1[4 * g + e] + bb[g][e];
-      if constexpr (ABL != 1) pv_apply_act_n<true, 16>(h, d.act);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { hf0[j] = (bf16_t)h[j]; hf1[j] = (bf16_t)h[8 + j]; }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // phase B: Y[ob] += W2blk[ob] . H
+    // phase B of block hb - 1 (Y[ob] += W2blk[ob] . H(hb-1)), the activation of block hb in its shadow
+    constexpr int EPS = (16 + 2 * NOB - 1) / (2 * NOB);       // activation elements finished per phase-B MFMA
+    float h[16];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int ob = 0; ob < NOB; ++ob) {
-        const int f = KS + i * NOB + ob;
+        const int t = i * NOB + ob;
+        const int f = KS + t;
         const bf16x8 afrag = ring[f % PF];
         if (ABL != 6 && f + PF < NF) ring[f % PF] = *reinterpret_cast<const bf16x8*>(ws + frag_off(f + PF));
-        if constexpr (ABL != 3) Y[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, i == 0 ? hf0 : hf1, Y[ob], 0, 0, 0);
-        else asm volatile("" :: "v"(afrag), "v"(hf0), "v"(hf1));
+        if constexpr (ABL != 3) Y[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, i == 0 ? hp0 : hp1, Y[ob], 0, 0, 0);
+        else asm volatile("" :: "v"(afrag), "v"(hp0), "v"(hp1));
+#pragma unroll
+        for (int e = t * EPS; e < (t + 1) * EPS && e < 16; ++e) {
+          const float v = D0[e] + D1[e] + bb[e >> 2][e & 3];
+          if constexpr (ABL == 1) h[e] = v;
+          else if constexpr (ACT == PV_ACT_GELU) h[e] = pv_gelu_fast(v);
+          else if constexpr (ACT == PV_ACT_RELU) h[e] = fmaxf(v, 0.f);
+          else if constexpr (ACT == PV_ACT_NONE) h[e] = v;
+          else h[e] = pv_apply_act(v, d.act);
+        }
         dma(f);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#pragma unroll
+    for (int j8 = 0; j8 < 8; ++j8) { hp0[j8] = (bf16_t)h[j8]; hp1[j8] = (bf16_t)h[8 + j8]; }
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---- epilogue: 16 consecutive channels per lane and output block ---------------------------------------------
@@ -512,31 +525,36 @@ int check_ln_linear(const pv_ln_linear_desc& d) {
   return PV_OK;
 }
 
-template <int KS, int NOB, int MINW> int launch(const pv_mlp_desc& d, hipStream_t s) {
+template <int KS, int NOB, int MINW, int ACT> int launch_act(const pv_mlp_desc& d, hipStream_t s) {
   const unsigned grid = (unsigned)pv_ceil_div(d.M, 128);
-  if constexpr (KS == 24 && NOB == 12) {
+  if constexpr (KS == 24 && NOB == 12 && ACT == PV_ACT_GELU) {
     const int abl = pv_tune("mlp_abl", 0);      // tools/bench_mlp.py only: timing builds with wrong results
     if (abl && d.ln_gamma != nullptr) {
       switch (abl) {
-        case 1: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, 1>), dim3(grid), dim3(256), 0, s, d); break;
-        case 2: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, 2>), dim3(grid), dim3(256), 0, s, d); break;
-        case 3: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, 3>), dim3(grid), dim3(256), 0, s, d); break;
-        case 4: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, 4>), dim3(grid), dim3(256), 0, s, d); break;
-        case 5: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, 5>), dim3(grid), dim3(256), 0, s, d); break;
-        default: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, 6>), dim3(grid), dim3(256), 0, s, d); break;
+        case 1: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT, 1>), dim3(grid), dim3(256), 0, s, d); break;
+        case 2: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT, 2>), dim3(grid), dim3(256), 0, s, d); break;
+        case 3: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT, 3>), dim3(grid), dim3(256), 0, s, d); break;
+        case 4: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT, 4>), dim3(grid), dim3(256), 0, s, d); break;
+        case 5: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT, 5>), dim3(grid), dim3(256), 0, s, d); break;
+        default: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT, 6>), dim3(grid), dim3(256), 0, s, d); break;
       }
       PV_LAUNCH_CHECK();
       return PV_OK;
     }
   }
   if (d.ln_gamma != nullptr) {
-    if constexpr (KS == 2 * NOB) PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW>), dim3(grid), dim3(256), 0, s, d);
+    if constexpr (KS == 2 * NOB) PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT>), dim3(grid), dim3(256), 0, s, d);
     else return PV_ERR_UNSUPPORTED;
   } else {
-    PV_LAUNCH((mlp_rows_kernel<KS, NOB, false, MINW>), dim3(grid), dim3(256), 0, s, d);
+    PV_LAUNCH((mlp_rows_kernel<KS, NOB, false, MINW, ACT>), dim3(grid), dim3(256), 0, s, d);
   }
   PV_LAUNCH_CHECK();
   return PV_OK;
+}
+
+template <int KS, int NOB, int MINW> int launch(const pv_mlp_desc& d, hipStream_t s) {
+  if (d.act == PV_ACT_GELU) return launch_act<KS, NOB, MINW, PV_ACT_GELU>(d, s);
+  return launch_act<KS, NOB, MINW, -1>(d, s);
 }
 
 int check(const pv_mlp_desc& d) {

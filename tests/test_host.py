@@ -284,7 +284,8 @@ def test_slowfast_with_a_declined_head_converts_block_by_block():
 
 
 def test_fused_mlp_weight_image_follows_the_documented_layout():
-    """pack_mlp_weights builds exactly the per-hidden-block LDS image include/pv_mi355x.h documents for pv_mlp_rows."""
+    """pack_mlp_weights builds exactly the LDS image include/pv_mi355x.h documents for pv_mlp_rows: block j carries W1 / b1 of
+    hidden block j and W2 of hidden block j - 1 (software pipeline), zeros at both ends, two blocks of padding."""
     import torch
     from pytorchvideo_amd.accelerator.mi355x.emit_mvit import _chi, pack_mlp_weights
     torch.manual_seed(0)
@@ -293,23 +294,30 @@ def test_fused_mlp_weight_image_follows_the_documented_layout():
     img = pack_mlp_weights(w1, b1, w2)
     KS, NOB, NH = Cin // 16, Cout // 32, H // 32
     stage = KS * 1024 + NOB * 2048 + 256
-    assert img.dtype == torch.uint8 and img.numel() == (NH + 2) * stage and not img[NH * stage:].any()
+    assert img.dtype == torch.uint8 and img.numel() == (NH + 3) * stage and not img[(NH + 1) * stage:].any()
     bf = lambda t: t.to(torch.bfloat16)
-    for hb in range(NH):
-        blk = img[hb * stage:(hb + 1) * stage]
+    for j in range(NH + 1):
+        blk = img[j * stage:(j + 1) * stage]
         a = blk[:KS * 1024].view(torch.int16).view(torch.bfloat16).reshape(KS, 2, 32, 8)
         b = blk[KS * 1024:KS * 1024 + NOB * 2048].view(torch.int16).view(torch.bfloat16).reshape(NOB, 2, 2, 32, 8)
         c = blk[KS * 1024 + NOB * 2048:].view(torch.float32)
+        if j == NH:
+            assert not a.float().any() and not c.any()
+        if j == 0:
+            assert not b.float().any()
         for hi in range(2):
             for rho in (0, 5, 18, 31):
-                for j in range(8):
+                for j8 in range(8):
                     for ks in range(KS):
-                        assert a[ks, hi, rho, j] == bf(w1[32 * hb + rho, 32 * (ks >> 1) + 16 * hi + 8 * (ks & 1) + j])
+                        if j < NH:
+                            assert a[ks, hi, rho, j8] == bf(w1[32 * j + rho, 32 * (ks >> 1) + 16 * hi + 8 * (ks & 1) + j8])
                     for ob in range(NOB):
                         for i in range(2):
-                            assert b[ob, i, hi, rho, j] == bf(w2[32 * ob + _chi(rho), 32 * hb + (j & 3) + 8 * (2 * i + (j >> 2)) + 4 * hi])
+                            if j >= 1:
+                                assert b[ob, i, hi, rho, j8] == bf(w2[32 * ob + _chi(rho), 32 * (j - 1) + (j8 & 3) + 8 * (2 * i + (j8 >> 2)) + 4 * hi])
             for r in range(16):
-                assert c[hi * 16 + r] == b1[32 * hb + (r & 3) + 8 * (r >> 2) + 4 * hi]
+                if j < NH:
+                    assert c[hi * 16 + r] == b1[32 * j + (r & 3) + 8 * (r >> 2) + 4 * hi]
         assert not c[32:].any()
 
 
