@@ -430,6 +430,11 @@ def can_fuse_ln_linear(sess, norm, lin, x):
         return False
     if tuple(norm.normalized_shape) != (x.C,) or lin.in_features != x.C or x.bs != x.voxels * x.ld:
         return False
+    # Measured per layer on MViT-B (b = 8, same box, norm1 + qkv GEMM vs the fused launch): 96 ch 150 -> 119 us, 192 ch
+    # 335 -> 271 us (401 k rows) and 75 -> 72 us (100 k rows); 384 ch 48 -> 55 us, 768 ch 42 -> 140 us (25 k / 6 k rows: a
+    # row-resident workgroup per 128 rows leaves the chip half empty and the 128 x 128-tile GEMM wins).
+    if x.C > tuning.get("fuse_ln_qkv_max_c"):
+        return False
     d = L.LnLinearDesc()
     d.x = d.wb = d.y = d.ln_gamma = d.ln_beta = 1
     d.M, d.C, d.N, d.ldx, d.ldy, d.dtype = x.B * x.voxels, x.C, lin.out_features, x.ld, pad8(lin.out_features), L.PV_BF16
