@@ -318,8 +318,18 @@ def run_workload(name, args, world, rank, device, steps, warmup, sustained_s=0.0
         for part in getattr(model, "parts", [model]):
             part.__dict__["_pv_use_graph"] = False
 
-    def step():
-        return gather_logits(model(list(x) if isinstance(x, list) else x), global_batch=batch * world)
+    comm = None if args.no_graph else HEAD["comm"]      # pv_forward_gather replays a graph
+    if comm is not None:
+        # the step is ONE C call behind the input ingest: graph replay, logits rows of the sub-plans, ncclAllGather
+        # enqueued by the library itself on the launch stream (pv_forward_gather, include/pv_mi355x.h)
+        from pytorchvideo_amd.parallel import ShardedForward
+        sharded = ShardedForward(model, comm)
+
+        def step():
+            return sharded(list(x) if isinstance(x, list) else x)
+    else:
+        def step():
+            return gather_logits(model(list(x) if isinstance(x, list) else x), global_batch=batch * world)
 
     for _ in range(warmup):
         out = step()
@@ -335,6 +345,27 @@ def run_workload(name, args, world, rank, device, steps, warmup, sustained_s=0.0
         res["sustained"] = {"seconds": round(e2, 3), "steps": n, "value": round(batch * world * n / e2, 2),
                             "ms_per_step": round(e2 / n * 1e3, 4)}
     return res, model, x, step
+
+
+# the head collective of this process: a pv_comm communicator (RCCL driven from C) at N > 1 or with --head-comm
+HEAD = {"comm": None, "how": "none (one rank: the logits stay where they are)"}
+
+
+def setup_head_collective(args, world):
+    """N > 1 (or --head-comm at N = 1): bind RCCL inside the C library and create the communicator; every step then
+    calls pv_forward_gather.  If no rank-wide binding is possible the step falls back to torch.distributed's
+    all_gather_into_tensor (the same RCCL, called from Python) and the line says so."""
+    if world == 1 and not args.head_comm:
+        return
+    try:
+        from pytorchvideo_amd.parallel import HeadComm
+        HEAD["comm"] = HeadComm()
+        HEAD["how"] = ("pv_forward_gather: graph launch + ncclAllGather enqueued from C on the launch stream (pv_comm over %s)"
+                       % HEAD["comm"].library)
+    except Exception as e:      # noqa: BLE001 -- any failure to bind: report it, keep the torch.distributed route
+        if args.head_comm == "require":
+            raise
+        HEAD["how"] = "torch.distributed all_gather_into_tensor from Python (pv_comm unavailable: %s)" % str(e)[:200]
 
 
 def pcie_leg(model, x, step, batch, steps, device):
@@ -393,6 +424,15 @@ def dry_host(args, world, rank):
     model.eval()
     batch = args.batch or 2
     x = synth_input(shape, batch, 1234 + rank)
+    how = "torch.distributed (gloo)"
+    if os.environ.get("PV_RCCL_LIB"):     # the C communicator with a host-memory librccl double (tests/helpers/rccl_stub.c)
+        from pytorchvideo_amd.parallel import HeadComm
+        comm = HeadComm()
+        recv = torch.empty(batch * world, 400)
+        how = "pv_comm over %s" % os.path.basename(comm.library)
+
+        def gather_logits(local, global_batch=None):     # noqa: F811 -- same contract, through pv_comm_all_gather
+            return comm.all_gather(local.contiguous(), recv)
     with torch.no_grad():
         for _ in range(args.warmup):
             out = gather_logits(model(x), global_batch=batch * world)
@@ -416,6 +456,7 @@ def dry_host(args, world, rank):
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32",
                           "data": "synthetic", "config": {"workload": "x3d_xs_dry: original-form model on the host, gloo",
                                                            "per_gpu_batch": batch, "global_batch": batch * world,
+                                                           "head_collective": how,
                                                            "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}}))
     if world > 1:
         dist.destroy_process_group()
@@ -439,6 +480,8 @@ def main():
                     help="skip the per-op profiling passes (rocprofv3 --pmc runs: only the replays are wanted)")
     ap.add_argument("--with-h2d", action="store_true",
                     help="also time steps that upload the (pinned) host input first; reported as pcie_inclusive, never as value")
+    ap.add_argument("--head-comm", nargs="?", const="on", default="", choices=["", "on", "require"],
+                    help="use the C-driven head collective at N = 1 too (one-rank RCCL communicator); 'require': no fallback")
     ap.add_argument("--dry-host", action="store_true", help="launcher check on the host (gloo, original-form model); no GPU")
     ap.add_argument("--tune", default="", help="development knobs k=v,... (pytorchvideo_amd.accelerator.mi355x.tuning / pv_tune_set)")
     args = ap.parse_args()
@@ -463,6 +506,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
+    setup_head_collective(args, world)
     wl = WORKLOADS[args.workload]
     res, model, x, step = run_workload(args.workload, args, world, rank, device, args.steps, args.warmup,
                                        sustained_s=0.0 if args.no_sustained else 2.0)
@@ -510,6 +554,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "per_gpu_batch": batch,
                        "global_batch": batch * world, "parallelism": "dp%d (batch-sharded, logits all_gather)" % world,
+                       "head_collective": HEAD["how"],
                        "weights": "random-init, randomised BN stats", "hip_graph": not args.no_graph,
                        "streams": res["streams"]},
             "roofline": roof,

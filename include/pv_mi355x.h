@@ -514,6 +514,42 @@ int pv_plan_profile(pv_plan* p, pv_stream_t stream, int iters, float* ms_per_op)
  * several), known after pv_plan_profile ran; "" before.  The string lives as long as the plan. */
 const char* pv_plan_op_kernel(const pv_plan* p, int i);
 
+/* ---- head collective ----------------------------------------------------------------------
+ * The one exchange of the batch-sharded forward: every rank contributes its [B_local, classes] logits and obtains
+ * the [B_global, classes] rows (the reference's forward has no collective, models/net.py:41-44; BASELINE.json
+ * prescribes this one on the classification head, models/head.py:376-382).  The library binds RCCL itself
+ * (dlopen of librccl: ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy / ncclGetErrorString)
+ * and ENQUEUES the all-gather from C on the stream the forward was launched on, directly behind the graph
+ * launch -- no Python, no torch.distributed call per step.  Bootstrap: rank 0 makes the 128-byte id
+ * (pv_comm_unique_id), the host side hands it to every rank (any out-of-band channel; pytorchvideo_amd.parallel
+ * uses the process group's store), every rank calls pv_comm_create.
+ *   lib_paths: ':'-separated candidates for librccl, tried in order (a copy already mapped into the process --
+ *   torch's -- is preferred so that one RCCL instance serves both); NULL = "librccl.so:librccl.so.1".
+ * pv_comm_all_gather(send, recv, bytes_per_rank): recv[r*bytes .. (r+1)*bytes) = rank r's send; byte-typed (ncclUint8),
+ * asynchronous on `stream`, safe behind pv_plan_graph_launch / pv_joint_launch on the same stream.
+ * pv_forward_gather: ONE C call per step of the batch-sharded forward (what a step of `bench.py --gpus N` is):
+ *   graph launch (plan `p`, or joint graph `j` -- exactly one non-NULL) -> the rank's logits rows collected from up to
+ *   16 strided sources (the result buffers of the sub-batch plans) into `staging` -> all-gather into `recv`
+ *   ([world][bytes_per_rank], i.e. the [B_global, classes] rows), all enqueued on `stream`.
+ *   c == NULL or world 1: the rows are collected straight into `recv` (no RCCL call). */
+typedef struct pv_comm pv_comm;
+typedef struct pv_gather_src {
+  const void* ptr;     /* first row                         */
+  size_t row_bytes;    /* bytes copied per row              */
+  size_t row_pitch;    /* bytes between rows (>= row_bytes)  */
+  int64_t rows;
+} pv_gather_src;
+int pv_comm_probe(const char* lib_paths);          /* PV_OK when a librccl with the five entry points can be bound */
+int pv_comm_unique_id(void* id128, const char* lib_paths);
+int pv_comm_create(pv_comm** out, const void* id128, int rank, int world, const char* lib_paths);
+void pv_comm_destroy(pv_comm* c);
+int pv_comm_rank(const pv_comm* c);
+int pv_comm_world(const pv_comm* c);
+const char* pv_comm_library(const pv_comm* c);     /* path of the RCCL copy the communicator bound */
+int pv_comm_all_gather(pv_comm* c, const void* send, void* recv, size_t bytes_per_rank, pv_stream_t stream);
+int pv_forward_gather(pv_plan* p, pv_joint* j, pv_comm* c, const pv_gather_src* srcs, int n_srcs, void* staging,
+                      void* recv, pv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

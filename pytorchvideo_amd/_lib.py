@@ -106,6 +106,8 @@ LnLinearDesc = _struct("LnLinearDesc", [
     ("x", _p), ("wb", _p), ("y", _p), ("ln_gamma", _p), ("ln_beta", _p), ("M", _i64)]
     + _ints("C", "N", "ldx", "ldy", "act", "dtype") + [("ln_eps", _f32)])
 
+GatherSrc = _struct("GatherSrc", [("ptr", _p), ("row_bytes", C.c_size_t), ("row_pitch", C.c_size_t), ("rows", _i64)])
+
 DESC_FOR_OP = {
     OP_CONV3D: Conv3dDesc, OP_DWCONV3D: DwConv3dDesc, OP_SE_GATE: SeGateDesc, OP_POOL3D: Pool3dDesc,
     OP_LAYERNORM: RowsDesc, OP_SOFTMAX_ROWS: RowsDesc, OP_MEAN_ROWS: RowsDesc, OP_POSENC: PosencDesc,
@@ -161,9 +163,18 @@ _SYMBOLS = [
     ("pv_joint_branches", C.c_int, [_p]),
     ("pv_plan_profile", C.c_int, [_p, _p, C.c_int, C.POINTER(C.c_float)]),
     ("pv_plan_op_kernel", C.c_char_p, [_p, C.c_int]),
+    ("pv_comm_probe", C.c_int, [C.c_char_p]),
+    ("pv_comm_unique_id", C.c_int, [_p, C.c_char_p]),
+    ("pv_comm_create", C.c_int, [C.POINTER(_p), _p, C.c_int, C.c_int, C.c_char_p]),
+    ("pv_comm_destroy", None, [_p]),
+    ("pv_comm_rank", C.c_int, [_p]),
+    ("pv_comm_world", C.c_int, [_p]),
+    ("pv_comm_library", C.c_char_p, [_p]),
+    ("pv_comm_all_gather", C.c_int, [_p, _p, _p, C.c_size_t, _p]),
+    ("pv_forward_gather", C.c_int, [_p, _p, _p, C.POINTER(GatherSrc), C.c_int, _p, _p, _p]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _lib = None
 

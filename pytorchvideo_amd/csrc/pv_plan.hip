@@ -3,13 +3,14 @@
 // once and replays them from C++ -- eagerly, or as one captured hipGraph.
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "pv_common.h"
 
 namespace {
 thread_local std::string g_last_error;
-constexpr int kAbiVersion = 22;
+constexpr int kAbiVersion = 23;
 }  // namespace
 
 int pv_set_hip_error(hipError_t e, const char* what) {
@@ -19,17 +20,27 @@ int pv_set_hip_error(hipError_t e, const char* what) {
   return PV_ERR_HIP;
 }
 
+int pv_set_text_error(const char* text) {
+  g_last_error = text ? text : "";
+  return PV_ERR_HIP;
+}
+
 namespace {
 thread_local const char* g_last_kernel = "";
 }  // namespace
 void pv_note_kernel(const char* name) { g_last_kernel = name; }
 
+// Development knobs.  The table is process-global and may be written through the public ABI while another thread
+// launches ops, so every access takes the mutex (a launch reads a handful of knobs: nanoseconds against a
+// microsecond-scale hipLaunchKernel).  Knob values are baked into a graph at capture time: set them BEFORE building.
 namespace {
 struct TuneEntry { std::string key; int value; };
 std::vector<TuneEntry>& tune_table() { static std::vector<TuneEntry> t; return t; }
+std::mutex& tune_mutex() { static std::mutex m; return m; }
 }  // namespace
 
 int pv_tune(const char* key, int dflt) {
+  std::lock_guard<std::mutex> lock(tune_mutex());
   for (const auto& e : tune_table())
     if (e.key == key) return e.value;
   return dflt;
@@ -37,6 +48,7 @@ int pv_tune(const char* key, int dflt) {
 
 extern "C" int pv_tune_set(const char* key, int value) {
   if (!key || !*key || strlen(key) > 48) return PV_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(tune_mutex());
   for (auto& e : tune_table())
     if (e.key == key) { e.value = value; return PV_OK; }
   tune_table().push_back({key, value});
@@ -44,6 +56,7 @@ extern "C" int pv_tune_set(const char* key, int value) {
 }
 
 extern "C" int pv_tune_clear(void) {
+  std::lock_guard<std::mutex> lock(tune_mutex());
   tune_table().clear();
   return PV_OK;
 }

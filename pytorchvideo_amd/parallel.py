@@ -92,3 +92,137 @@ def reduce_box_scores(local_scores, rows, total_boxes, group=None):
     if world_size > 1:
         dist.all_reduce(out, group=group)
     return out
+
+
+# --------------------------------------------------------------------------- head collective driven from C
+def rccl_candidates():
+    """librccl candidates for pv_comm_create, in order: torch's own copy (already mapped into the process when torch
+    is imported on ROCm, so ONE RCCL instance serves torch.distributed and the library), then the system one.
+    PV_RCCL_LIB overrides (the CPU tests point it at a stub that exchanges host buffers through shared memory)."""
+    import os
+    if os.environ.get("PV_RCCL_LIB"):
+        return os.environ["PV_RCCL_LIB"]
+    cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so", "librccl.so.1",
+             "/opt/rocm/lib/librccl.so"]
+    return ":".join(cands)
+
+
+class HeadComm:
+    """An RCCL communicator owned by the C library (include/pv_mi355x.h, pv_comm_*): rank 0 draws the unique id, the
+    process group carries its 128 bytes to the other ranks once, and from then on no torch.distributed call is made
+    on the data path."""
+
+    def __init__(self, group=None, lib_paths=None):
+        import ctypes as C
+        from . import _lib as L
+        self._L, self._C = L, C
+        rank, world_size = world()
+        paths = (lib_paths or rccl_candidates()).encode()
+        # every rank first checks that it can bind an RCCL copy and the group agrees on the outcome: a rank that failed
+        # here would otherwise leave the others waiting inside ncclCommInitRank
+        ok = torch.tensor([1 if L.lib().pv_comm_probe(paths) == L.PV_OK else 0], dtype=torch.int32)
+        why = "" if ok.item() else (L.lib().pv_last_error() or b"").decode()
+        if world_size > 1:
+            if dist.get_backend(group) == "nccl":
+                ok = ok.cuda()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            raise L.PvError("pv_comm: librccl could not be bound on every rank (%s)" % (why or "another rank failed"))
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            L.check(L.lib().pv_comm_unique_id(buf, paths), "pv_comm_unique_id")
+            ident = [bytes(buf.raw)]
+        if world_size > 1:
+            dist.broadcast_object_list(ident, src=0, group=group)
+        h = C.c_void_p()
+        L.check(L.lib().pv_comm_create(C.byref(h), ident[0], rank, world_size, paths), "pv_comm_create")
+        self.handle, self.rank, self.world_size = h, rank, world_size
+        self.library = (L.lib().pv_comm_library(h) or b"").decode()
+
+    def all_gather(self, send, recv, stream=None):
+        """recv[r] = rank r's `send` (contiguous tensors; device tensors on `stream`, default the current one)."""
+        assert send.is_contiguous() and recv.is_contiguous() and recv.numel() == send.numel() * self.world_size
+        if stream is None:
+            stream = torch.cuda.current_stream(send.device).cuda_stream if send.is_cuda else 0
+        self._L.check(self._L.lib().pv_comm_all_gather(self.handle, send.data_ptr(), recv.data_ptr(),
+                                                       send.numel() * send.element_size(), self._C.c_void_p(stream)),
+                      "pv_comm_all_gather")
+        return recv
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._L.lib().pv_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedForward:
+    """One step of the batch-sharded forward as ONE C call behind the input ingest: replay of the rank's graph (a single
+    plan, or the joint graph of its sub-batch plans), collection of the logits rows of every sub-plan, ncclAllGather
+    into the [B_global, classes] buffer -- pv_forward_gather (include/pv_mi355x.h).  `deployed` is what
+    `convert_to_deployable_form` returned (whole-model plan, streams >= 1).  The returned tensor is the library's
+    receive buffer: valid until the next call."""
+
+    def __init__(self, deployed, comm=None):
+        import ctypes as C
+        from . import _lib as L
+        from .accelerator.mi355x.conversion import _ingest_inputs
+        self._L, self._C, self._ingest = L, C, _ingest_inputs
+        self.deployed, self.comm = deployed, comm
+        self.parts = list(getattr(deployed, "parts", [deployed]))
+        if any(getattr(p, "_pv_inputs", None) is None or not hasattr(p, "_pv_result") for p in self.parts):
+            raise L.PvError("ShardedForward needs a whole-model deploy form (one launch plan per sub-batch)")
+        self.splits = list(getattr(deployed, "_splits", [None]))
+        views = [p._pv_result() for p in self.parts]
+        if any(v.dim() != 2 or v.stride(1) != 1 for v in views):
+            raise L.PvError("ShardedForward gathers [B, classes] logits rows")
+        self.n_local, self.classes, self.dtype = sum(v.shape[0] for v in views), views[0].shape[1], views[0].dtype
+        dev = views[0].device
+        world_size = comm.world_size if comm is not None else 1
+        isz = views[0].element_size()
+        self._srcs = (L.GatherSrc * len(views))(*[
+            L.GatherSrc(v.data_ptr(), v.shape[1] * isz, v.stride(0) * isz if v.shape[0] > 1 else v.shape[1] * isz, v.shape[0])
+            for v in views])
+        self._staging = torch.empty((self.n_local, self.classes), dtype=self.dtype, device=dev)
+        self._recv = torch.empty((world_size * self.n_local, self.classes), dtype=self.dtype, device=dev)
+        self._device = dev
+        self._joint = len(self.parts) > 1
+        self._ready = False
+
+    def _handles(self):
+        """(plan, joint) for pv_forward_gather; graphs are built by one ordinary forward-less launch on first use."""
+        if not self._ready:
+            if self._joint:
+                if not self.deployed._use_joint():
+                    raise self._L.PvError("ShardedForward needs the joint graph of the split-batch form")
+                self.deployed._launch_joint()
+            else:
+                self.parts[0]._pv_session.launch(use_graph=True)
+            self._ready = True
+        if self._joint:
+            return None, self.deployed._joint_handle
+        return self.parts[0]._pv_session.plan, None
+
+    def __call__(self, x):
+        multi = isinstance(x, (list, tuple))
+        lo = 0
+        for part, b in zip(self.parts, self.splits):
+            if b is None:
+                xc = x
+            else:
+                xc = [t[lo:lo + b] for t in x] if multi else x[lo:lo + b]
+                lo += b
+            self._ingest(part._pv_session, list(xc) if multi else xc, part._pv_inputs, multi)
+        plan, joint = self._handles()
+        with torch.cuda.device(self._device):
+            stream = self._C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+            self._L.check(self._L.lib().pv_forward_gather(
+                plan, joint, self.comm.handle if self.comm is not None else None, self._srcs, len(self.parts),
+                self._staging.data_ptr(), self._recv.data_ptr(), stream), "pv_forward_gather")
+        return self._recv

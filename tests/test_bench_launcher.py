@@ -35,3 +35,11 @@ def test_inside_a_torchrun_environment_the_world_size_wins():
     # the driver's N>1 invocation passes --gpus N AND sets WORLD_SIZE: no second spawn
     line = _run(["--gpus", "1"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert line["n_gpus"] == 1
+
+
+def test_two_ranks_gather_through_the_c_communicator(tmp_path):
+    # the head collective of `bench.py --gpus N`: pv_comm_* with a host-memory double of librccl behind the dlopen
+    so = os.path.join(str(tmp_path), "librccl_stub.so")
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "helpers", "rccl_stub.c"), "-lrt"])
+    line = _run(["--gpus", "2"], {"PV_RCCL_LIB": so})
+    assert line["n_gpus"] == 2 and line["config"]["head_collective"] == "pv_comm over librccl_stub.so"
