@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libpv_mi355x.so")
+# PV_MI355X_LIB: a debug variant of the SAME library (csrc/build.py VARIANTS: the AddressSanitizer build of the host shim)
+# for the sanitizer job -- not a way to select another implementation: the ABI version and every symbol are checked below.
+LIB_PATH = os.environ.get("PV_MI355X_LIB") or os.path.join(_HERE, "_lib", "libpv_mi355x.so")
 
 PV_OK, PV_ERR_UNSUPPORTED, PV_ERR_INVALID, PV_ERR_HIP = 0, -1, -2, -3
 PV_F32, PV_BF16, PV_U8 = 0, 1, 2

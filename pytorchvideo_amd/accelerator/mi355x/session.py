@@ -22,6 +22,7 @@ import torch
 from ... import _lib as L
 
 _ALIGN = 256
+_CANARY = 0xA5
 
 
 def _round_up(v, m):
@@ -85,13 +86,24 @@ class TRef:
 class _Arena:
     """First-fit offset allocator with coalescing free list; tracks the peak."""
 
-    def __init__(self):
+    def __init__(self, guard=0):
         self.free = []  # sorted (off, size)
         self.top = 0
         self.peak = 0
         self.live = {}
+        self.guard = guard      # bytes of canary behind every allocation (debug plans)
+        self.bands = []         # (allocation offset, requested bytes, band offset, band bytes)
 
     def alloc(self, nbytes):
+        if self.guard:
+            band = _round_up(max(nbytes, 1), 16)        # right behind the last 16-byte chunk a kernel may store
+            total = _round_up(band + self.guard, _ALIGN)
+            off = self.top
+            self.top += total
+            self.peak = max(self.peak, self.top)
+            self.live[off] = total
+            self.bands.append((off, nbytes, off + band, total - band))
+            return off
         nbytes = _round_up(max(nbytes, 1), _ALIGN)
         for i, (off, size) in enumerate(self.free):
             if size >= nbytes:
@@ -112,6 +124,8 @@ class _Arena:
         return off
 
     def release(self, off):
+        if self.guard:
+            return              # debug plans never re-use memory: a late write shows up in a canary, not in another tensor
         size = self.live.pop(off)
         self.free.append((off, size))
         self.free.sort()
@@ -132,7 +146,8 @@ class Session:
         self.itemsize = 2 if dtype == torch.bfloat16 else 4
         self.device = device
         self.reuse = reuse_buffers
-        self._arena = _Arena()
+        from . import tuning
+        self._arena = _Arena(guard=int(tuning.get("arena_guards")))
         self._weights = []      # (byte_off, cpu tensor)
         self._wtop = 0
         self.ops = []           # (kind, desc_cls, fields dict, label, alg_bytes, flops)
@@ -210,6 +225,8 @@ class Session:
         dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
         self.device = dev
         self.arena_t = torch.zeros(max(self._arena.peak, _ALIGN), dtype=torch.uint8, device=dev)
+        for _, _, boff, blen in self._arena.bands:      # debug plans: canaries behind every buffer
+            self.arena_t[boff:boff + blen] = _CANARY
         blob = torch.zeros(max(self._wtop, _ALIGN), dtype=torch.uint8)
         for off, t in self._weights:
             raw = t.view(torch.uint8).reshape(-1) if t.dtype != torch.bfloat16 else t.view(torch.int16).view(torch.uint8).reshape(-1)
@@ -233,6 +250,20 @@ class Session:
             self._desc_keep.append(d)
             L.check(lib.pv_plan_add(self.plan, kind, C.byref(d), C.sizeof(d)), "pv_plan_add(%s)" % label)
         self.finalized = True
+
+    def check_guards(self):
+        """Debug plans (tuning "arena_guards" > 0): the arena buffers whose canary a kernel overwrote, as
+        (buffer offset, buffer bytes, first bad byte behind the buffer, bad bytes).  Empty list = every write stayed
+        inside the buffer it was addressed to.  Synchronises."""
+        if not self._arena.guard:
+            raise L.PvError("this plan was not converted with tuning.OPTIONS['arena_guards'] > 0")
+        torch.cuda.synchronize(self.device)
+        bad = []
+        for off, nbytes, boff, blen in self._arena.bands:
+            hit = (self.arena_t[boff:boff + blen] != _CANARY).nonzero()
+            if hit.numel():
+                bad.append((off, nbytes, int(hit[0].item()), int(hit.numel())))
+        return bad
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

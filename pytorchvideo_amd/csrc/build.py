@@ -29,11 +29,29 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, force):
-    obj = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+# Debug variants (sanitizer / bounds-check builds of the native code), built on demand next to the product library:
+#   "asan": the HOST side of every translation unit (descriptor validation, kernel routing, the launch plan, the
+#           communicator) instrumented by AddressSanitizer (device code is left alone: -fno-gpu-sanitize); loaded by a
+#           python started with LD_PRELOAD=<ASAN_RUNTIME> and PV_MI355X_LIB=<variant library> (tests/test_sanitizers.py).
+VARIANTS = {
+    "asan": ["-fsanitize=address", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-O1"],
+}
+
+
+def asan_runtime():
+    """libclang_rt.asan of the ROCm clang that built the variant (LD_PRELOAD for the python that loads it)."""
+    import glob
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    return hits[-1] if hits else None
+
+
+def _compile(src, force, out_dir=None, extra=()):
+    out_dir = out_dir or OUT_DIR
+    obj = os.path.join(out_dir, src.replace(".hip", ".o"))
     path = os.path.join(HERE, src)
     if force or _stale(obj, [path] + HEADERS):
-        cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+        flags = [f for f in FLAGS if not (extra and f == "-O3")] + list(extra)
+        cmd = [HIPCC] + flags + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -58,5 +76,27 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_variant(name, force=False, verbose=True):
+    """Build libpv_mi355x.so with the flags of VARIANTS[name] under _lib/<name>/ (objects cached like the product build)."""
+    extra = VARIANTS[name]
+    out_dir = os.path.join(OUT_DIR, name)
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(out_dir, "libpv_mi355x.so")
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force, out_dir, extra), SOURCES))
+    if force or any(changed for _, changed in results) or not os.path.exists(lib):
+        link = [f for f in extra if f.startswith("-fsanitize") or f == "-fno-gpu-sanitize"]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [o for o, _ in results] + link + ["-ldl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("built", lib)
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--variant" in sys.argv:
+        build_variant(sys.argv[sys.argv.index("--variant") + 1], force="--force" in sys.argv)
+    else:
+        build(force="--force" in sys.argv)
