@@ -97,6 +97,28 @@ __device__ __forceinline__ float pv_gelu_fast(float x) {
   return h + fabsf(h) * (1.0f - poly * e);
 }
 
+// Two elements at once on the packed fp32 pipe (v_pk_mul / v_pk_fma_f32: one issue slot per PAIR; the reciprocal and the
+// exponential stay per element): 17 issue slots per pair against 24 -- the fused MLP kernel is issue-bound, not
+// MFMA-bound (pv_mlp.hip).  Same operations in the same order as pv_gelu_fast (0.5 (x + |x| (1 - poly e)) = h + |h| (...)
+// exactly: the scaling by 0.5 is exact), so both give the same bits.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pv_gelu_fast2(f32x2 x) {
+  f32x2 ax;
+  ax[0] = fabsf(x[0]);
+  ax[1] = fabsf(x[1]);
+  const f32x2 z = ax * 0.70710678118654752440f;
+  const f32x2 dn = z * 0.47047f + 1.0f;
+  f32x2 t;
+  t[0] = __builtin_amdgcn_rcpf(dn[0]);
+  t[1] = __builtin_amdgcn_rcpf(dn[1]);
+  const f32x2 poly = t * (0.3480242f + t * (-0.0958798f + t * 0.7478556f));
+  const f32x2 a = (x * x) * -0.72134752044448170368f;
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(a[0]);
+  e[1] = __builtin_amdgcn_exp2f(a[1]);
+  return (x + ax * (1.0f - poly * e)) * 0.5f;
+}
+
 // Activation of a small register array with ONE wave-uniform branch around straight-line loops (a
 // per-element switch on a runtime act code makes the compiler emit a branch tree per element).
 // FAST: bf16 kernels may use the cheap GELU; fp32 kernels keep erff.

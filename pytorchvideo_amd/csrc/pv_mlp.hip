@@ -58,7 +58,8 @@ template <int KS, int NOB> struct MlpGeom {
 
 // KS = C / 16 (even), NOB = Cout / 32, LN: x is the fp32 stream (LayerNorm here, residual = x, needs C == Cout)
 // ABL: ablation builds for tools/bench_mlp.py (timing only, wrong results): 1 no activation, 2 no weight streaming, 3 no phase B,
-// 4 no phase A, 5 no barrier, 6 no LDS fragment reads
+// 4 no phase A, 5 no barrier, 6 no LDS fragment reads; 7 / 8 are correct variants kept for A/B: one phase-A accumulator chain,
+// activation stages pinned into the MFMA gaps
 // ACT: the activation between the two Linears as a compile-time constant (PV_ACT_GELU for MViT), or -1 = read d.act at
 // run time (any pv_act; a branch tree per element inside the MFMA stream, slower).
 template <int KS, int NOB, bool LN, int MINW, int ACT, int ABL = 0>
@@ -77,8 +78,10 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
   const long mm = ok ? m : 0;
   const int NH = d.H >> 5;
   constexpr auto vm = [](int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); };
-  // the widest LayerNorm variant sits at the edge of the 512-register file: one phase-A accumulator chain instead of two
-  constexpr bool ONE_D = false;
+  // Two phase-A accumulator chains.  (With two, hipcc parks two of the Y blocks in ArchVGPRs during phase A and moves them
+  // back -- 64 v_accvgpr moves per hidden block -- yet ONE chain measured 2 % slower: 114.6 vs 112.3 us at 384 -> 1536 -> 384.)
+  constexpr bool ONE_D = (ABL == 7);
+  constexpr bool PIN = (ABL == 8);      // activation stages tied into the phase-B MFMA gaps (measured 117.0 us against 112.3 with the stages left where hipcc sinks them, below the last MFMA: a gap hides ~5 instructions, a stage plus the fragment read, the wait and the DMA piece are 10-12)
 
   const unsigned char* wsrc = static_cast<const unsigned char*>(d.w12);
   auto stage = [&](int hb, int buf) {
@@ -262,12 +265,16 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
     bf16x8 ring[PF];
 #pragma unroll
     for (int f = 0; f < PF; ++f) ring[f] = *reinterpret_cast<const bf16x8*>(ws + frag_off(f));
-    f32x4 bb[4];
+    // b1 of this block is the C operand of the first phase-A MFMA (the four 16-byte reads land in the tuple the matrix
+    // instruction reads: no accumulator initialisation, no bias add); the second chain starts from the zero literal
+    f32x16 Bv;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bb[g] = *reinterpret_cast<const f32x4*>(b1s + 4 * g);
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 q4 = *reinterpret_cast<const f32x4*>(b1s + 4 * g);
+      Bv[4 * g] = q4[0]; Bv[4 * g + 1] = q4[1]; Bv[4 * g + 2] = q4[2]; Bv[4 * g + 3] = q4[3];
+    }
+    const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 D0, D1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { D0[r] = 0.f; D1[r] = 0.f; }
     __builtin_amdgcn_sched_barrier(0);
     constexpr int STEP = NF / NPW;          // a DMA piece of block hb + 2 every STEP fragments
     auto dma = [&](int f) {
@@ -285,15 +292,69 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
       const bf16x8 afrag = ring[ks % PF];
       if (ABL != 6 && ks + PF < NF) ring[ks % PF] = *reinterpret_cast<const bf16x8*>(ws + frag_off(ks + PF));
       if constexpr (ABL != 4) {
-        if (ks & 1) D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[ks], D1, 0, 0, 0);
-        else D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[ks], D0, 0, 0, 0);
+        if (!ONE_D && (ks & 1)) D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[ks], ks == 1 ? kZero16 : D1, 0, 0, 0);
+        else D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[ks], ks == 0 ? Bv : D0, 0, 0, 0);
+      } else if (ks < 2) {
+        if (ks & 1) D1 = kZero16; else D0 = Bv;
       }
       dma(ks);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // phase B of block hb - 1 (Y[ob] += W2blk[ob] . H(hb-1)), the activation of block hb in its shadow
-    constexpr int EPS = (16 + 2 * NOB - 1) / (2 * NOB);       // activation elements finished per phase-B MFMA
-    float h[16];
+    // (the phase-A accumulator is read by vector arithmetic only: named as an ArchVGPR operand here, hipcc allocates it there
+    //  for its whole life instead of borrowing the AGPR range of a Y block and moving that block out and back every iteration)
+    if constexpr (PIN) asm volatile("" : "+v"(D0));
+    // phase B of block hb - 1 (Y[ob] += W2blk[ob] . H(hb-1)), the activation of block hb in its shadow.
+    // The activation is PINNED into the phase-B slots: its results are only consumed at the bottom of the loop, so without a
+    // tie hipcc sinks the whole computation below the last MFMA (round-3 ISA: 200 VALU instructions per block in the loop
+    // latch, none in the MFMA shadow).  GELU of the 16 hidden units of a lane = 8 pairs (packed fp32 math) x 3 stages of
+    // 5-7 issue slots; one stage per MFMA gap at NOB = 12 (a gap hides about 5 single-issue instructions,
+    // MI355X_MICROARCH.md), each stage ending in an empty asm that names its outputs.
+    constexpr int UNITS = 24 / (2 * NOB);      // stage units per phase-B MFMA (NOB = 12 / 6 / 3 -> 1 / 2 / 4)
+    static_assert(UNITS * 2 * NOB == 24, "8 pairs x 3 stages over the phase-B slots");
+    f32x2 gx[8], gax[8], gdn[8], gxx[8], gt[8], ge[8];
+    unsigned hn[8];                            // activations of block hb as packed bf16 pairs: pair q = hidden units 2q, 2q + 1 of the lane
+    auto act_unit = [&](int u) {
+      const int q = u / 3, st = u % 3;
+      if constexpr (ACT == PV_ACT_GELU && ABL != 1) {
+        if (st == 0) {
+          gx[q] = f32x2{D0[2 * q], D0[2 * q + 1]};
+          if constexpr (!ONE_D) gx[q] += f32x2{D1[2 * q], D1[2 * q + 1]};
+          gax[q][0] = fabsf(gx[q][0]);
+          gax[q][1] = fabsf(gx[q][1]);
+          gdn[q] = (gax[q] * 0.70710678118654752440f) * 0.47047f + 1.0f;
+          gxx[q] = gx[q] * gx[q];
+          if constexpr (PIN) asm volatile("" : "+v"(gx[q]), "+v"(gax[q]), "+v"(gdn[q]), "+v"(gxx[q]));
+        } else if (st == 1) {
+          gt[q][0] = __builtin_amdgcn_rcpf(gdn[q][0]);
+          gt[q][1] = __builtin_amdgcn_rcpf(gdn[q][1]);
+          const f32x2 a = gxx[q] * -0.72134752044448170368f;
+          ge[q][0] = __builtin_amdgcn_exp2f(a[0]);
+          ge[q][1] = __builtin_amdgcn_exp2f(a[1]);
+          if constexpr (PIN) asm volatile("" : "+v"(gt[q]), "+v"(ge[q]));
+        } else {
+          const f32x2 t = gt[q];
+          const f32x2 poly = t * (0.3480242f + t * (-0.0958798f + t * 0.7478556f));
+          const f32x2 gq = (gx[q] + gax[q] * (1.0f - poly * ge[q])) * 0.5f;
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          const bf16x2_t pk = {(bf16_t)gq[0], (bf16_t)gq[1]};
+          hn[q] = __builtin_bit_cast(unsigned, pk);
+          if constexpr (PIN) asm volatile("" : "+v"(hn[q]));
+        }
+      } else {
+        if (st == 0) {
+          f32x2 v = f32x2{D0[2 * q], D0[2 * q + 1]};
+          if constexpr (!ONE_D) v += f32x2{D1[2 * q], D1[2 * q + 1]};
+          float r0 = v[0], r1 = v[1];
+          if constexpr (ABL == 1 || ACT == PV_ACT_NONE) {}
+          else if constexpr (ACT == PV_ACT_RELU) { r0 = fmaxf(r0, 0.f); r1 = fmaxf(r1, 0.f); }
+          else { r0 = pv_apply_act(r0, d.act); r1 = pv_apply_act(r1, d.act); }
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          const bf16x2_t pk = {(bf16_t)r0, (bf16_t)r1};
+          hn[q] = __builtin_bit_cast(unsigned, pk);
+          asm volatile("" : "+v"(hn[q]));
+        }
+      }
+    };
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -305,20 +366,16 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
         if constexpr (ABL != 3) Y[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, i == 0 ? hp0 : hp1, Y[ob], 0, 0, 0);
         else asm volatile("" :: "v"(afrag), "v"(hp0), "v"(hp1));
 #pragma unroll
-        for (int e = t * EPS; e < (t + 1) * EPS && e < 16; ++e) {
-          const float v = D0[e] + D1[e] + bb[e >> 2][e & 3];
-          if constexpr (ABL == 1) h[e] = v;
-          else if constexpr (ACT == PV_ACT_GELU) h[e] = pv_gelu_fast(v);
-          else if constexpr (ACT == PV_ACT_RELU) h[e] = fmaxf(v, 0.f);
-          else if constexpr (ACT == PV_ACT_NONE) h[e] = v;
-          else h[e] = pv_apply_act(v, d.act);
-        }
+        for (int u = t * UNITS; u < (t + 1) * UNITS; ++u) act_unit(u);
         dma(f);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-#pragma unroll
-    for (int j8 = 0; j8 < 8; ++j8) { hp0[j8] = (bf16_t)h[j8]; hp1[j8] = (bf16_t)h[8 + j8]; }
+    {
+      typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+      hp0 = __builtin_bit_cast(bf16x8, u32x4_t{hn[0], hn[1], hn[2], hn[3]});
+      hp1 = __builtin_bit_cast(bf16x8, u32x4_t{hn[4], hn[5], hn[6], hn[7]});
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -536,6 +593,8 @@ template <int KS, int NOB, int MINW, int ACT> int launch_act(const pv_mlp_desc& 
         case 3: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT, 3>), dim3(grid), dim3(256), 0, s, d); break;
         case 4: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT, 4>), dim3(grid), dim3(256), 0, s, d); break;
         case 5: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT, 5>), dim3(grid), dim3(256), 0, s, d); break;
+        case 7: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT, 7>), dim3(grid), dim3(256), 0, s, d); break;
+        case 8: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT, 8>), dim3(grid), dim3(256), 0, s, d); break;
         default: PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT, 6>), dim3(grid), dim3(256), 0, s, d); break;
       }
       PV_LAUNCH_CHECK();

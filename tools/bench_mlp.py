@@ -52,7 +52,7 @@ def main():
         d.ln_gamma, d.ln_beta, d.ln_eps = (gam.data_ptr(), bet.data_ptr(), 1e-6) if ln else (None, None, 0.0)
         d.M, d.C, d.H, d.Cout, d.ldx, d.ldr, d.ldy, d.act, d.dtype = M, Cin, H, Cout, Cin, Cout, Cout, L.ACT_GELU, L.PV_BF16
         flops = 2.0 * M * H * (Cin + Cout)
-        for abl in ((0, 1, 2, 3, 4, 5, 6) if (Cin, Cout) == (384, 384) else (0,)):
+        for abl in ((0, 7, 8, 1, 2, 3, 4, 5, 6) if (Cin, Cout) == (384, 384) else (0,)):
             L.tune(mlp_abl=abl)
             us = timed(lambda: L.check(lib.pv_mlp_rows(C.byref(d), st)), a.iters)
             print("mlp_rows M=%d %d->%d->%d ln=%d abl=%d: %8.1f us  %7.1f TF/s" % (M, Cin, H, Cout, ln, abl, us, flops / us / 1e6), flush=True)

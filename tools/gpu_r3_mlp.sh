@@ -1,0 +1,4 @@
+#!/bin/bash
+R=$PWD; OUT=$R/gpurun_out/r3f; mkdir -p $OUT
+python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "fused_mlp or layernorm_fused" > $OUT/pytest_mlp.log 2>&1; tail -4 $OUT/pytest_mlp.log
+python tools/bench_mlp.py --iters 30 > $OUT/bench_mlp.txt 2>&1; grep -v amdgpu $OUT/bench_mlp.txt
