@@ -643,8 +643,10 @@ extern "C" int pv_mlp_rows(const pv_mlp_desc* dp, pv_stream_t stream) {
   const pv_mlp_desc& d = *dp;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.C == 96 && d.Cout == 96) return launch<6, 3, 2>(d, s);
-  if (d.C == 96 && d.Cout == 192) return launch<6, 6, 1>(d, s);
-  if (d.C == 192 && d.Cout == 192) return launch<12, 6, 1>(d, s);
+  // two workgroups per CU where registers (<= 256 per wave) and LDS (3 stages each) allow: the narrow variants spend as long
+  // loading the residual rows and storing the result as multiplying, and a lone workgroup overlaps neither with anything
+  if (d.C == 96 && d.Cout == 192) return pv_tune("mlp_minw", 2) >= 2 ? launch<6, 6, 2>(d, s) : launch<6, 6, 1>(d, s);
+  if (d.C == 192 && d.Cout == 192) return pv_tune("mlp_minw", 2) >= 2 ? launch<12, 6, 2>(d, s) : launch<12, 6, 1>(d, s);
   if (d.C == 192 && d.Cout == 384) return launch<12, 12, 1>(d, s);
   if (d.C == 384 && d.Cout == 384) return launch<24, 12, 1>(d, s);
   return PV_ERR_UNSUPPORTED;
