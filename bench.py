@@ -327,6 +327,13 @@ def run_workload(name, args, world, rank, device, steps, warmup, sustained_s=0.0
 
         def step():
             return sharded(list(x) if isinstance(x, list) else x)
+
+        if world > 1:     # once per workload: the C-driven collective against torch.distributed's on the same logits
+            ref = gather_logits(model(list(x) if isinstance(x, list) else x), global_batch=batch * world)
+            got = step()
+            torch.cuda.synchronize()
+            if not torch.equal(got, ref):
+                raise SystemExit("pv_forward_gather disagrees with torch.distributed's all_gather on rank %d" % rank)
     else:
         def step():
             return gather_logits(model(list(x) if isinstance(x, list) else x), global_batch=batch * world)

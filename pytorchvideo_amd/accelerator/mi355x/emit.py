@@ -348,6 +348,8 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
     if producer is not None:
         if not check_conv3d(conv) or w_mod or grid is not None:
             raise Unsupported("fused producer on a token pooling conv")
+        if group_width(conv) != 1:
+            raise Unsupported("fused producer on a channel-wise grouped conv")
     elif not w_mod:
         if not check_conv3d(conv):
             raise Unsupported("not depthwise")
@@ -635,6 +637,8 @@ def can_fuse_temporal_dw(sess, first, second, mid_norm, mid_act, x, act):
         if check_conv3d(first) or not check_conv3d(second):
             return False
     except Unsupported:
+        return False
+    if group_width(second) != 1:      # a channel-wise GROUPED temporal conv passes check_conv3d too: not this fusion
         return False
     k = second.kernel_size
     if first.bias is not None or first.out_channels != second.in_channels or second.in_channels != second.out_channels:

@@ -343,3 +343,22 @@ def test_ln_linear_weight_image_follows_the_documented_layout():
         for hi in range(2):
             for r in range(16):
                 assert c[hi * 16 + r] == b[32 * nb + 16 * hi + r]
+
+
+def test_grouped_temporal_conv_declines_the_stem_fusion_and_the_fused_producer():
+    """check_conv3d accepts channel-wise grouped convs (2 / 4 / 8 channels per group) as well as depthwise ones; the two
+    fusions that need a TRUE depthwise conv must decline them instead of reshaping a [cout, gw, k, 1, 1] weight."""
+    import torch.nn as nn
+    from pytorchvideo_amd.accelerator.mi355x import emit as E
+    sess = Session(dtype=torch.bfloat16)
+    x = sess.alloc_input(1, 4, 16, 16, 3)
+    first = nn.Conv3d(3, 24, (1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1), bias=False)
+    dw = nn.Conv3d(24, 24, (5, 1, 1), padding=(2, 0, 0), groups=24, bias=False)
+    grouped = nn.Conv3d(24, 24, (5, 1, 1), padding=(2, 0, 0), groups=6, bias=False)       # 4 channels per group
+    assert E.group_width(dw) == 1 and E.group_width(grouped) == 4
+    assert E.can_fuse_temporal_dw(sess, first, grouped, None, L.ACT_NONE, x, L.ACT_RELU) is False
+    y = sess.alloc_act(1, 4, 8, 8, 24)
+    conv_b = nn.Conv3d(48, 48, 3, padding=1, groups=12, bias=False)                      # 4 channels per group
+    conv_a = nn.Conv3d(24, 48, 1, bias=False)
+    with pytest.raises(E.Unsupported):
+        E.emit_dwconv(sess, conv_b, y, producer=(conv_a, None, L.ACT_RELU))
