@@ -39,6 +39,16 @@ KERNEL_BF16 = {"x3d_m": 3e-2, "x3d_l": 9e-2, "slowfast_r50": 2.5e-2, "mvit_b_32x
 NORTH_STAR_BF16 = {"x3d_m": 6.5e-2, "x3d_l": 1.1e-1, "slowfast_r50": 4.7e-2, "mvit_b_32x3": 1e-2}
 
 
+def _dump(r, what):
+    """PV_PARITY_DUMP=<file>: every case's numbers as one JSON line (the evidence kept under profiles/)."""
+    path = os.environ.get("PV_PARITY_DUMP")
+    if path:
+        import json
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(r, case=what, bounds={"fp32": FP32_TOL, "bf16_kernel": KERNEL_BF16[r["workload"]],
+                                                          "bf16_north_star": NORTH_STAR_BF16[r["workload"]]}), default=str) + "\n")
+
+
 def _check(r, bf16_only=False):
     w = r["workload"]
     assert 0.1 < r["logit_absmax"] < 100.0 and r["logit_std"] > 1e-2      # a well-scaled, non-degenerate instance
@@ -57,6 +67,7 @@ def test_full_geometry_parity(workload):
     print("\n%s: fp32 %.2e | bf16 vs bf16-storage oracle %.2e | bf16 vs fp32 oracle %.2e (storage floor %.2e, weights "
           "alone %.2e)" % (workload, r["fp32_vs_oracle"], r["bf16_vs_emulated_oracle"], r["bf16_vs_fp32_oracle"],
                            r["storage_floor"], r["weights_floor"]))
+    _dump(r, "one clip, single plan")
     _check(r)
 
 
@@ -71,5 +82,6 @@ def test_bench_batch_with_bench_streams_every_row(workload):
     print("\n%s b=%d streams=%d: bf16 vs bf16-storage oracle %.2e (worst row %.2e) | vs fp32 oracle %.2e | top-1 %d/%d" % (
         workload, r["batch"], r["streams"], r["bf16_vs_emulated_oracle"], r["bf16_rows_worst"], r["bf16_vs_fp32_oracle"],
         r["top1_agree_emulated"], r["batch"]))
+    _dump(r, "bench batch, bench streams, every row")
     _check(r, bf16_only=True)
     assert r["top1_agree_emulated"] >= r["batch"] - 1
