@@ -19,6 +19,7 @@
 #include <stdlib.h>
 int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s);      // pv_pwconv.hip
 int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);  // pv_gemm.hip
+int pv_head_rows_try(const pv_conv3d_desc& d, hipStream_t s);              // pv_headgemm.hip
 int pv_gemm8_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);      // pv_gemm8.hip
 int pv_tapstream_try(const pv_conv3d_desc& d, hipStream_t s);           // pv_lateral.hip
 int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s);                 // pv_stem.hip
@@ -382,6 +383,10 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
     const int small_cin = pv_tune("conv_small_cin", 128);
     const bool small = d.cin <= small_cin;
     if (route != 3) {
+      if (pw && route == 0 && pv_tune("head_rows", 1)) {     // a handful of rows (classification heads): K-parallel kernel
+        const int r = pv_head_rows_try(d, s);
+        if (r != PV_ERR_UNSUPPORTED) return r;
+      }
       if (pw && (route == 1 || (route == 0 && small))) {
         const int r = pv_pwconv_stream_try(d, s);
         if (r != PV_ERR_UNSUPPORTED) return r;

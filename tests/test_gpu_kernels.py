@@ -551,6 +551,47 @@ def test_depthwise_3x3x3_plane_kernel_with_se_partial_sums(B, T, H, W, Cc, strid
     assert rel_err(got_mean, pre.mean(dim=[2, 3, 4])) <= 1e-3   # sums are fp32, before the bf16 rounding
 
 
+@pytest.mark.parametrize("B,S,K,N,act,y_f32,pad", [
+    (32, 1, 432, 2048, L.ACT_RELU, 0, 0),     # X3D-M head.post_conv: 27 K-steps over 4 waves
+    (32, 1, 2048, 400, L.ACT_NONE, 1, 0),     # X3D-M head.proj: fp32 logits, 13 channel tiles (the last one ragged)
+    (16, 4, 2304, 400, L.ACT_NONE, 1, 0),     # SlowFast-R50 head.proj on a 2x2 map: 64 rows, two row tiles
+    (8, 1, 768, 400, L.ACT_NONE, 1, 16),      # MViT-B head on the cls rows, output wider than cout
+    (5, 1, 200, 50, L.ACT_SIGMOID, 0, 0),     # ragged rows, K % 16 == 8, cout % 8 != 0 (padding channels written as 0)
+    (3, 11, 256, 96, L.ACT_SWISH, 0, 8),      # 33 rows: second row tile almost empty
+])
+def test_pointwise_conv_on_a_handful_of_rows_head_kernel(B, S, K, N, act, y_f32, pad):
+    """csrc/pv_headgemm.hip (K-parallel, operands straight from global memory into MFMA layout) against fp32 torch, and
+    bit-comparable with the tiled kernels it replaces on these shapes (same products, different summation order)."""
+    kp, n8 = (K + 7) // 8 * 8, (N + 7) // 8 * 8
+    x = torch.zeros(B, S, kp, dtype=torch.bfloat16, device="cuda")
+    x[..., :K] = _rand((B, S, K), 301, torch.bfloat16)
+    w = torch.zeros(N, kp, dtype=torch.bfloat16, device="cuda")
+    w[:, :K] = _rand((N, K), 302, torch.bfloat16, K ** -0.5)
+    scale, shift = _rand((N,), 303, torch.float32) * 0.2 + 1.0, _rand((N,), 304, torch.float32)
+    pre = torch.einsum("bsk,nk->bsn", x[..., :K].float(), w[:, :K].float()) * scale + shift
+    want = {L.ACT_NONE: pre, L.ACT_RELU: F.relu(pre), L.ACT_SIGMOID: torch.sigmoid(pre), L.ACT_SWISH: pre * torch.sigmoid(pre)}[act]
+    ldy = n8 + pad
+    outs = []
+    try:
+        for head_rows in (1, 0):
+            L.tune(head_rows=head_rows)
+            y = torch.full((B, S, ldy), 7.0, dtype=torch.float32 if y_f32 else torch.bfloat16, device="cuda")
+            d = L.Conv3dDesc()
+            d.x, d.w, d.y, d.scale, d.shift = x.data_ptr(), w.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr()
+            d.x_bs, d.y_bs, d.ldx, d.ldy = S * kp, S * ldy, kp, ldy
+            d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, 1, 1, S, kp, 1, 1, S, N
+            d.kt = d.kh = d.kw = d.st = d.sh = d.sw = 1
+            d.act, d.a_act, d.dtype, d.y_f32 = act, L.ACT_NONE, L.PV_BF16, y_f32
+            call("pv_conv3d", d)
+            outs.append(y)
+            if head_rows:
+                assert rel_err(y[..., :N], want) <= (1e-4 if y_f32 else 1e-2)
+                assert torch.all(y[..., N:n8] == 0) and torch.all(y[..., n8:] == 7.0)     # padding channels 0, nothing beyond
+    finally:
+        L.tune(head_rows=1)
+    assert rel_err(outs[0][..., :N], outs[1][..., :N]) <= (1e-5 if y_f32 else 8e-3)
+
+
 # ------------------------------------------------------------------ projection shortcut as a second K operand
 @pytest.mark.parametrize("B,T,H,W,cin,cout,cin2,stride,gate", [
     (2, 4, 12, 10, 54, 24, 24, (1, 2, 2), True),      # X3D res2 block 0: SE gate + swish on the first operand only
