@@ -1,25 +1,26 @@
-// Pointwise conv / Linear on a HANDFUL of rows (at most 64 voxels in the whole batch): the classification heads --
+// Pointwise conv / Linear on a HANDFUL of rows (at most 4 voxels per clip): the classification heads --
 // X3D's post_conv 432 -> 2048 and proj 2048 -> 400 on one pooled voxel per clip (models/x3d.py:480-494, models/head.py:376-382),
 // SlowFast's proj 2304 -> 400 (models/slowfast.py:345-361), MViT's head Linear on the cls rows (models/head.py:538-559).
 //
 // On the tiled GEMM such a layer is one or two row tiles and a long serial K loop on a few workgroups (X3D-M's proj: 4 tiles,
 // 32 K-steps, 29 us).  Here the reduction is what is parallel:
-//   * a workgroup owns 32 output channels, its 4 waves split K (wave w takes the 16-channel K-steps w, w+4, ...);
+//   * a workgroup owns 32 output channels, its 8 waves split K (wave w takes the 16-channel K-steps w, w+8, ...);
 //   * both MFMA operands come STRAIGHT from global memory in operand layout (v_mfma_f32_32x32x16_bf16: A = 32 filter rows x 16 k,
 //     B = 32 activation rows x 16 k; a lane's 8 k-values are 16 contiguous bytes of a filter / activation row), through buffer
 //     resources whose range check supplies the zeros of ragged rows, channels and K tails: no LDS staging, no bounds branches;
 //   * 8 K-steps of loads are issued before their MFMAs (the kernel is one memory round trip deep, not 32);
-//   * the four partial accumulators are joined through LDS by wave 0, which applies folded BN / bias, the activation and stores.
+//   * the eight partial accumulators are joined through LDS by wave 0, which applies folded BN / bias, the activation and stores.
 #include "pv_common.h"
 
 namespace {
 
-constexpr int kHeadThreads = 256;
+constexpr int kHeadThreads = 512;
+constexpr int kHeadWaves = kHeadThreads / 64;
 constexpr int kHeadU = 8;   // K-steps in flight per wave
 
 template <int NB>   // 32-row tiles of activation rows (1: <= 32 rows, 2: <= 64)
 __global__ __launch_bounds__(kHeadThreads) void head_rows_kernel(const pv_conv3d_desc d, int M, int S_out) {
-  __shared__ float s_red[3][NB][16][64];
+  __shared__ float s_red[kHeadWaves - 1][NB][16][64];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_rows_kernel(const pv_conv3d
   unsigned x_base[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int m = nb * 32 + l31;
+    const int m = blockIdx.y * 64 + nb * 32 + l31;
     const int b = m / S_out, sp = m - b * S_out;
     x_base[nb] = m < M ? (unsigned)(((long)b * d.x_bs + (long)sp * d.ldx) * 2) : kOOB;
   }
@@ -49,11 +50,11 @@ __global__ __launch_bounds__(kHeadThreads) void head_rows_kernel(const pv_conv3d
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
-  for (int ks0 = wave; ks0 < nks; ks0 += 4 * kHeadU) {
+  for (int ks0 = wave; ks0 < nks; ks0 += kHeadWaves * kHeadU) {
     u32x4 af[kHeadU], bf[kHeadU][NB];
 #pragma unroll
     for (int u = 0; u < kHeadU; ++u) {
-      const int k = (ks0 + 4 * u) * 16 + hi * 8;
+      const int k = (ks0 + kHeadWaves * u) * 16 + hi * 8;
       const bool k_ok = k < K;                    // (covers K-steps past the end and the upper half of a K % 16 == 8 tail)
       const unsigned ko = (unsigned)k * 2u;
       af[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)((k_ok && w_base != kOOB) ? w_base + ko : kOOB), 0, 0);
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_rows_kernel(const pv_conv3d
                                                            acc[nb], 0, 0, 0);
   }
 
-  // join the four K slices: lane-linear through LDS (bank-conflict free), wave 0 finishes
+  // join the K slices: lane-linear through LDS (bank-conflict free), wave 0 finishes
   if (wave > 0) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_rows_kernel(const pv_conv3d
   const int cout_p8 = pv_round_up(d.cout, 8);
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int m = nb * 32 + l31;
+    const int m = blockIdx.y * 64 + nb * 32 + l31;
     if (m >= M) continue;
     const int b = m / S_out, sp = m - b * S_out;
     const long yo = (long)b * d.y_bs + (long)sp * d.ldy;
@@ -89,7 +90,9 @@ __global__ __launch_bounds__(kHeadThreads) void head_rows_kernel(const pv_conv3d
     for (int r = 0; r < 16; ++r) {
       const int c = co0 + 8 * (r >> 2) + 4 * hi + (r & 3);      // C/D layout of the 32x32 MFMA: row = 8 (r/4) + 4 (lane/32) + r%4
       if (c >= cout_p8) continue;
-      float v = acc[nb][r] + s_red[0][nb][r][lane] + s_red[1][nb][r][lane] + s_red[2][nb][r][lane];
+      float v = acc[nb][r];
+#pragma unroll
+      for (int w = 0; w < kHeadWaves - 1; ++w) v += s_red[w][nb][r][lane];
       if (c < d.cout) {
         v = v * (d.scale ? d.scale[c] : 1.f) + (d.shift ? d.shift[c] : 0.f);
         v = pv_apply_act(v, d.act);
@@ -108,12 +111,14 @@ __global__ __launch_bounds__(kHeadThreads) void head_rows_kernel(const pv_conv3d
 int pv_head_rows_try(const pv_conv3d_desc& d, hipStream_t s) {
   if (d.dtype != PV_BF16 || d.a_gate != nullptr || d.a_act != PV_ACT_NONE || d.residual != nullptr || d.x2 != nullptr)
     return PV_ERR_UNSUPPORTED;
+  // Routed by what ONE clip looks like (<= 4 output voxels, a long reduction), never by the batch: a batch split into sub-batches
+  // (SplitBatchDeployed) must run the same kernels, in the same summation order, as the one-plan form -- row for row identical.
   const long M = (long)d.B * d.To * d.Ho * d.Wo;
-  if (M > 64 || d.cin < pv_tune("head_rows_min_cin", 192)) return PV_ERR_UNSUPPORTED;
+  if ((long)d.To * d.Ho * d.Wo > 4 || M > 0x7fffffffL / 64 || d.cin < pv_tune("head_rows_min_cin", 512)) return PV_ERR_UNSUPPORTED;
   if ((long)d.cout * d.cin * 2 > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
   if (((long)(d.B - 1) * d.x_bs + (long)d.To * d.Ho * d.Wo * d.ldx) * 2 > 0x7fffffe0L) return PV_ERR_UNSUPPORTED;   // 31-bit byte offsets
   const int S_out = d.To * d.Ho * d.Wo;
-  dim3 grid((unsigned)pv_ceil_div(pv_round_up(d.cout, 8), 32)), block(kHeadThreads);
+  dim3 grid((unsigned)pv_ceil_div(pv_round_up(d.cout, 8), 32), (unsigned)pv_ceil_div(M, 64)), block(kHeadThreads);   // 64-row tiles in y
   if (M <= 32) PV_LAUNCH((head_rows_kernel<1>), grid, block, 0, s, d, (int)M, S_out);
   else PV_LAUNCH((head_rows_kernel<2>), grid, block, 0, s, d, (int)M, S_out);
   PV_LAUNCH_CHECK();

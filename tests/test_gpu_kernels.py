@@ -552,12 +552,13 @@ def test_depthwise_3x3x3_plane_kernel_with_se_partial_sums(B, T, H, W, Cc, strid
 
 
 @pytest.mark.parametrize("B,S,K,N,act,y_f32,pad", [
-    (32, 1, 432, 2048, L.ACT_RELU, 0, 0),     # X3D-M head.post_conv: 27 K-steps over 4 waves
+    (32, 1, 560, 2048, L.ACT_RELU, 0, 0),     # 35 K-steps over 8 waves, wide output
     (32, 1, 2048, 400, L.ACT_NONE, 1, 0),     # X3D-M head.proj: fp32 logits, 13 channel tiles (the last one ragged)
     (16, 4, 2304, 400, L.ACT_NONE, 1, 0),     # SlowFast-R50 head.proj on a 2x2 map: 64 rows, two row tiles
     (8, 1, 768, 400, L.ACT_NONE, 1, 16),      # MViT-B head on the cls rows, output wider than cout
-    (5, 1, 200, 50, L.ACT_SIGMOID, 0, 0),     # ragged rows, K % 16 == 8, cout % 8 != 0 (padding channels written as 0)
-    (3, 11, 256, 96, L.ACT_SWISH, 0, 8),      # 33 rows: second row tile almost empty
+    (5, 1, 520, 50, L.ACT_SIGMOID, 0, 0),     # ragged rows, K % 16 == 8, cout % 8 != 0 (padding channels written as 0)
+    (11, 3, 768, 96, L.ACT_SWISH, 0, 8),      # 33 rows: second row tile almost empty
+    (50, 4, 512, 40, L.ACT_NONE, 1, 0),       # 200 rows: four 64-row tiles (the batch never decides the routing)
 ])
 def test_pointwise_conv_on_a_handful_of_rows_head_kernel(B, S, K, N, act, y_f32, pad):
     """csrc/pv_headgemm.hip (K-parallel, operands straight from global memory into MFMA layout) against fp32 torch, and
