@@ -94,6 +94,41 @@ def by_plan_order(d, per_op):
     return res
 
 
+def per_op_traffic(d, per_op):
+    """Markdown rows, one per plan op: algorithmic bytes (bench.py's per-op table: GB/s x ms) beside the PMC bytes of the same
+    dispatch (plan order), sorted by the bytes moved above the algorithmic count.  [] if the passes do not line up."""
+    ops = []
+    for line in open(per_op):
+        m = re.match(r"\s+op (.+?)\s+([0-9.]+) ms\s+([0-9.]+) GB/s", line)
+        if m:
+            ops.append((m.group(1), float(m.group(2)), float(m.group(2)) * float(m.group(3)) * 1e6))
+    per = [dict(label=l, ms=ms, alg=a, fetch=0.0, write=0.0) for l, ms, a in ops]
+    for key, pat, ctr in (("fetch", "fetch_counter_collection.csv", "FETCH_SIZE"), ("write", "write_counter_collection.csv", "WRITE_SIZE")):
+        disp = {}
+        for row in csv.DictReader(open(find(d, pat))):
+            if row["Counter_Name"] == ctr:
+                e = disp.setdefault(int(row["Dispatch_Id"]), [row["Kernel_Name"], 0.0])
+                e[1] += float(row["Counter_Value"])
+        seq = [disp[i] for i in sorted(disp) if "_prefix_kernel" not in disp[i][0]]
+        starts = [i for i, (name, _) in enumerate(seq) if "stem" in name]
+        reps, last = [], -len(ops)
+        for i in starts:
+            if i - last >= len(ops) and i + len(ops) <= len(seq):
+                reps.append(i)
+                last = i
+        if not reps:
+            return []
+        for i in reps:
+            for o, (_, v) in zip(per, seq[i:i + len(ops)]):
+                o[key] += v * 1024 / len(reps)
+    rows = []
+    for o in per:
+        hbm = 2 * o["fetch"] + o["write"]
+        rows.append((hbm - o["alg"], "| `%s` | %.4f | %.1f | %.1f | %.1f | %.1f | %.2f |" % (
+            o["label"][:64], o["ms"], o["alg"] / 1e6, 2 * o["fetch"] / 1e6, o["write"] / 1e6, hbm / 1e6, hbm / max(o["alg"], 1.0))))
+    return [r for _, r in sorted(rows, key=lambda t: -t[0])]
+
+
 def main():
     wl, d = sys.argv[1], sys.argv[2]
     fetch, nf = counters(find(d, "fetch_counter_collection.csv"))
@@ -117,6 +152,13 @@ def main():
             k, len(dur[k]), tot[k] / len(dur[k]), hb, 100 * mf, 100 * c.get("SQ_ACTIVE_INST_VALU", 0) / wc,
             100 * c.get("SQ_WAIT_ANY", 0) / wc, 100 * c.get("SQ_WAIT_INST_ANY", 0) / wc))
     traffic = by_plan_order(d, sys.argv[3]) if len(sys.argv) > 3 else {}
+    rows = per_op_traffic(d, sys.argv[3]) if len(sys.argv) > 3 else []
+    if rows:
+        print("\nPer op (plan order), sorted by the bytes moved above the algorithmic count -- top 24 of %d:\n" % len(rows))
+        print("| op | ms (HIP events) | algorithmic MB | fetch MB (2 x FETCH_SIZE) | write MB | HBM MB | HBM / algorithmic |")
+        print("|---|---|---|---|---|---|---|")
+        print("\n".join(rows[:24]))
+        print()
     for label, rx in FAMILIES.get(wl, {}).items():
         if traffic:
             break     # exact attribution available: dispatch i of a replay is op i of the launch plan
