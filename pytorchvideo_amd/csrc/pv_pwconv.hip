@@ -171,7 +171,27 @@ __global__ __launch_bounds__(kThreads, (KS >= 14 || X2V) ? 2 : ((NT >= 4 || KS >
 #pragma unroll
           for (int j = 0; j < 4; ++j) { f[j] *= g0[j]; f[4 + j] *= g1[j]; }
         }
-        pv_apply_act_n<true>(f, d.a_act);
+        if (d.a_act == PV_ACT_SWISH) {
+          // X3D's conv_c: swish(x g) on the packed fp32 pipe, two channels per instruction (the exponential and the reciprocal
+          // stay per element); same operations as pv_sigmoid, so the same bits as the generic path below
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            const f32x2 sv = {f[j], f[j + 1]};
+            const f32x2 ea = sv * -1.44269504088896340736f;
+            f32x2 den;
+            den[0] = __builtin_amdgcn_exp2f(ea[0]);
+            den[1] = __builtin_amdgcn_exp2f(ea[1]);
+            den = den + 1.0f;
+            f32x2 rc;
+            rc[0] = __builtin_amdgcn_rcpf(den[0]);
+            rc[1] = __builtin_amdgcn_rcpf(den[1]);
+            const f32x2 o = sv * rc;
+            f[j] = o[0];
+            f[j + 1] = o[1];
+          }
+        } else {
+          pv_apply_act_n<true>(f, d.a_act & 15);      // (bit 4: the A/B knob "pw_pk_swish" = 0 sends Swish down the generic path)
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) src[kk][t][j] = (bf16_t)f[j];
       }
@@ -393,7 +413,14 @@ int launch_pw_x(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) 
 
 template <int NT, int TM>
 int launch_pw(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) {
-  if (d.a_gate != nullptr || d.a_act != PV_ACT_NONE) return launch_pw_x<NT, TM, true>(d, ksteps, lds, s);
+  if (d.a_gate != nullptr || d.a_act != PV_ACT_NONE) {
+    if (d.a_act == PV_ACT_SWISH && !pv_tune("pw_pk_swish", 1)) {
+      pv_conv3d_desc d2 = d;
+      d2.a_act = PV_ACT_SWISH | 16;
+      return launch_pw_x<NT, TM, true>(d2, ksteps, lds, s);
+    }
+    return launch_pw_x<NT, TM, true>(d, ksteps, lds, s);
+  }
   return launch_pw_x<NT, TM, false>(d, ksteps, lds, s);
 }
 
