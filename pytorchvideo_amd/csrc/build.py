@@ -33,8 +33,12 @@ def _stale(target, deps):
 #   "asan": the HOST side of every translation unit (descriptor validation, kernel routing, the launch plan, the
 #           communicator) instrumented by AddressSanitizer (device code is left alone: -fno-gpu-sanitize); loaded by a
 #           python started with LD_PRELOAD=<ASAN_RUNTIME> and PV_MI355X_LIB=<variant library> (tests/test_sanitizers.py).
+#   "dev":  -DPV_DEV_ABLATION: the ablation builds of the GEMM / fused-MLP kernels (timing only, they skip loads, MFMAs or the
+#           epilogue and give WRONG results) and their A/B variants, selectable through pv_tune_set("gemm_abl" | "mlp_abl").  The
+#           PRODUCT library does not contain them: no knob of the public ABI can make it compute a wrong answer.
 VARIANTS = {
     "asan": ["-fsanitize=address", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-O1"],
+    "dev": ["-DPV_DEV_ABLATION", "-O3"],
 }
 
 

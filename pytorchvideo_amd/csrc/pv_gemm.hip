@@ -426,6 +426,7 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return PV_ERR_UNSUPPORTED;   // 31-bit buffer offsets
   const float inv_cin = 1.0f / (float)d.cin;
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads);
+#ifdef PV_DEV_ABLATION   // timing builds that skip loads / MFMAs / the epilogue (WRONG results): development variant of the library only
   const int abl = pv_tune("gemm_abl", 0);
   if (abl && vt == 2) {
     if (abl == 1) { if (pw) PV_LAUNCH((gemm_glds_kernel<true, 2, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
@@ -437,6 +438,7 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
     PV_LAUNCH_CHECK();
     return PV_OK;
   }
+#endif
   if (vt == 1) {
     if (pw) PV_LAUNCH((gemm_glds_kernel<true, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
     else PV_LAUNCH((gemm_glds_kernel<false, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);

@@ -584,6 +584,7 @@ int check_ln_linear(const pv_ln_linear_desc& d) {
 
 template <int KS, int NOB, int MINW, int ACT> int launch_act(const pv_mlp_desc& d, hipStream_t s) {
   const unsigned grid = (unsigned)pv_ceil_div(d.M, 128);
+#ifdef PV_DEV_ABLATION   // ablation / A-B builds (1-6 give WRONG results): development variant of the library only (csrc/build.py --variant dev)
   if constexpr (KS == 24 && NOB == 12 && ACT == PV_ACT_GELU) {
     const int abl = pv_tune("mlp_abl", 0);      // tools/bench_mlp.py only: timing builds with wrong results
     if (abl && d.ln_gamma != nullptr) {
@@ -601,6 +602,7 @@ template <int KS, int NOB, int MINW, int ACT> int launch_act(const pv_mlp_desc& 
       return PV_OK;
     }
   }
+#endif
   if (d.ln_gamma != nullptr) {
     if constexpr (KS == 2 * NOB) PV_LAUNCH((mlp_rows_kernel<KS, NOB, true, MINW, ACT>), dim3(grid), dim3(256), 0, s, d);
     else return PV_ERR_UNSUPPORTED;

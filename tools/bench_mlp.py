@@ -2,6 +2,10 @@
 builds of csrc/pv_mlp.hip (pv_tune "mlp_abl": timing only, wrong results) -- run on the GPU box.
 
     python tools/bench_mlp.py [--iters 50]
+
+The ablation / A-B builds exist only in the development variant of the library:
+    python -m pytorchvideo_amd.csrc.build --variant dev && PV_MI355X_LIB=pytorchvideo_amd/_lib/dev/libpv_mi355x.so python tools/bench_mlp.py
+(with the product library every `abl` line times the same, shipped kernel).
 """
 import argparse
 import ctypes as C
