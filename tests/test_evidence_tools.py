@@ -49,6 +49,18 @@ def test_pmc_traffic_is_attributed_by_plan_order(tmp_path):
     assert got["attn.pool_q"]["hbm_bytes_per_launch"] == round((2 * 10.0 * 4 + 1.0 * 4) * 1024)
     assert got["conv_c"]["hbm_bytes_per_launch"] == round((2 * 10.0 * 5 + 1.0 * 5) * 1024)
     assert got["conv_c"]["dispatches_profiled"] == 3
+    # ... and per op: algorithmic bytes (GB/s x ms of the per-op table) beside the PMC bytes of the same dispatch, worst excess first
+    rows = SE.per_op_traffic(str(tmp_path), str(per_op))
+    assert len(rows) == 4
+    alg = {"stem.conv": 10.0, "conv_b": 20.0, "attn.pool_q": 5.0, "conv_c": 30.0}       # MB: 100 GB/s x ms
+    hbm = {"stem.conv": 21 * 1024 * 1, "conv_b": 21 * 1024 * 2, "attn.pool_q": 21 * 1024 * 4, "conv_c": 21 * 1024 * 5}   # bytes
+    first = rows[0]
+    assert first.startswith("| `attn.pool_q|")           # 0.086 MB against 5 MB: the smallest deficit sorts first
+    for name in alg:
+        row = [r for r in rows if r.startswith("| `" + name)][0]
+        cells = [c.strip() for c in row.strip().strip("|").rsplit("|", 6)]       # (the op label itself contains a '|')
+        assert abs(float(cells[2]) - alg[name]) < 0.06 and abs(float(cells[5]) - hbm[name] / 1e6) < 0.06
+        assert abs(float(cells[6]) - hbm[name] / 1e6 / alg[name]) < 0.01
 
 
 def test_kernel_trace_is_aligned_with_the_plan(tmp_path):
