@@ -416,7 +416,7 @@ def pcie_leg(model, x, step, batch, steps, device):
     return pcie
 
 
-def dry_host(args, world, rank):
+def dry_host(args, world, rank, stdout_guard):
     """Launcher check without a GPU (tests/test_bench_launcher.py): the ORIGINAL-form model on the host, gloo.
     Exercises exactly the spawn / rank binding / barrier / max-over-ranks / n_gpus reporting of the real run;
     its number is not a measurement of the product path and the line says so."""
@@ -457,6 +457,7 @@ def dry_host(args, world, rank):
         elapsed = t.item()
     assert out.shape == (batch * world, 400)
     if rank == 0:
+        stdout_guard.restore()
         print(json.dumps({"metric": "dry-host launcher check (NOT a measurement of the HIP path)",
                           "value": round(batch * world * args.steps / elapsed, 3), "unit": "clips/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -469,7 +470,38 @@ def dry_host(args, world, rank):
         dist.destroy_process_group()
 
 
+class _StdoutToStderr:
+    """File descriptor 1 points at stderr while the job runs and comes back for the ONE JSON line: native libraries write
+    to the C stdout (RCCL prints a version banner when its first communicator is created; it sits in libc's buffer until exit
+    and would land BEHIND the JSON line), and the contract is one JSON line on stdout."""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self._libc = ctypes.CDLL(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def restore(self):
+        if self._saved is not None:
+            sys.stdout.flush()
+            self._libc.fflush(None)          # whatever C code buffered goes to stderr, not behind the JSON line
+            os.dup2(self._saved, 1)
+            os.close(self._saved)
+            self._saved = None
+
+    def __exit__(self, *exc):
+        self.restore()
+        return False
+
+
 def main():
+    with _StdoutToStderr() as out:
+        return _main(out)
+
+
+def _main(out):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -494,6 +526,7 @@ def main():
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        out.restore()                      # the ranks inherit this process's stdout
         sys.exit(self_spawn(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -501,7 +534,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if args.dry_host:
-        return dry_host(args, world, rank)
+        return dry_host(args, world, rank, out)
 
     import torch
     import torch.distributed as dist
@@ -582,7 +615,9 @@ def main():
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print("  %-16s n=%3d %8.3f ms  %8.1f GB/s  %7.2f TF/s" % (
                     k, v[0], v[1], v[2] / max(v[1], 1e-9) / 1e6, v[3] / max(v[1], 1e-9) / 1e9), file=sys.stderr)
-        print(json.dumps(line))
+        out.restore()
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)        # anything native code still prints at teardown (communicator destruction) goes to stderr
     if world > 1:
         dist.destroy_process_group()
 

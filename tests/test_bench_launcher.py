@@ -15,8 +15,9 @@ def _run(extra, env_extra=None):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-host", "--steps", "2", "--warmup", "1"] + extra,
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout          # rank 0 prints ONE JSON line
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout      # rank 0 prints ONE JSON line and NOTHING else reaches stdout
+    _run.last_stderr = r.stderr
     return json.loads(lines[0])
 
 
@@ -43,3 +44,5 @@ def test_two_ranks_gather_through_the_c_communicator(tmp_path):
     subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "helpers", "rccl_stub.c"), "-lrt"])
     line = _run(["--gpus", "2"], {"PV_RCCL_LIB": so})
     assert line["n_gpus"] == 2 and line["config"]["head_collective"] == "pv_comm over librccl_stub.so"
+    # the library's banner (RCCL prints one to the C stdout at communicator creation) went to stderr, not behind the JSON line
+    assert "RCCL version : stub" in _run.last_stderr
