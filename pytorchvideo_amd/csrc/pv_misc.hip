@@ -114,6 +114,76 @@ __global__ __launch_bounds__(kThreads) void pool_direct_kernel(const pv_pool3d_d
           ((long)(to * d.Ho + ho) * d.Wo + wo) * d.ldy + cg * 8);
 }
 
+// The windows the models use between layers -- 3x3x3 (MViT's skip-path max pool, layers/attention.py:677-679,720-727) and
+// 1x3x3 (SlowFast / ResNet stem pools, models/stem.py:98-104) -- with the taps unrolled: every load of a temporal slice is issued
+// unconditionally from a clamped address (no branch per tap: the runtime loops above wait for each load behind its own bounds
+// test), validity is applied as a select.  One output voxel x 8-channel chunk per thread, as above.
+template <typename T, int KT, int KH, int KW>
+__global__ __launch_bounds__(kThreads) void pool_window_kernel(const pv_pool3d_desc d, long total) {
+  const int CG = pv_round_up(d.C, 8) / 8;
+  const long id = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (id >= total) return;
+  const int cg = (int)(id % CG);
+  long v = id / CG;
+  const int wo = (int)(v % d.Wo); v /= d.Wo;
+  const int ho = (int)(v % d.Ho); v /= d.Ho;
+  const int to = (int)(v % d.To);
+  const int b = (int)(v / d.To);
+  const T* X = static_cast<const T*>(d.x) + (long)b * d.x_bs + (long)d.n_prefix * d.ldx + cg * 8;
+  const bool is_max = d.mode == PV_POOL_MAX;
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = is_max ? -FLT_MAX : 0.f;
+  const int h0 = ho * d.sh - d.ph, w0 = wo * d.sw - d.pw;
+  int hoff[KH], woff[KW];
+  bool hok[KH], wok[KW];
+#pragma unroll
+  for (int dh = 0; dh < KH; ++dh) {
+    const int hi = h0 + dh;
+    hok[dh] = (unsigned)hi < (unsigned)d.Hi;
+    hoff[dh] = (hok[dh] ? hi : 0) * d.Wi;
+  }
+#pragma unroll
+  for (int dw = 0; dw < KW; ++dw) {
+    const int wi = w0 + dw;
+    wok[dw] = (unsigned)wi < (unsigned)d.Wi;
+    woff[dw] = wok[dw] ? wi : 0;
+  }
+#pragma unroll
+  for (int dt = 0; dt < KT; ++dt) {
+    const int ti = to * d.st - d.pt + dt;
+    const bool tok = (unsigned)ti < (unsigned)d.Ti;
+    const T* P = X + (long)(tok ? ti : 0) * d.Hi * d.Wi * d.ldx;
+    Chunk8<T> c[KH][KW];
+#pragma unroll
+    for (int dh = 0; dh < KH; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < KW; ++dw) c[dh][dw].load(P + (long)(hoff[dh] + woff[dw]) * d.ldx);
+#pragma unroll
+    for (int dh = 0; dh < KH; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < KW; ++dw) {
+        const bool ok = tok && hok[dh] && wok[dw];
+        float f[8];
+        c[dh][dw].to_f32(f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = is_max ? fmaxf(a[j], ok ? f[j] : -FLT_MAX) : a[j] + (ok ? f[j] : 0.f);
+      }
+  }
+  if (!is_max) {
+    const float inv = 1.f / (float)(KT * KH * KW);  // count_include_pad=True
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] *= inv;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (cg * 8 + j >= d.C) a[j] = 0.f;
+  Chunk8<T> o;
+  o.from_f32(a);
+  o.store(static_cast<T*>(d.y) + (long)b * d.y_bs + (long)d.n_prefix * d.ldy +
+          ((long)(to * d.Ho + ho) * d.Wo + wo) * d.ldy + cg * 8);
+}
+
 // large windows: one block per output voxel (and chunk slab), taps split over threads
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pool_reduce_kernel(const pv_pool3d_desc d, int cgb) {
@@ -793,7 +863,10 @@ template <typename T> static int pool_launch(const pv_pool3d_desc& d, hipStream_
     PV_LAUNCH(pool_reduce_kernel<T>, grid, dim3(kThreads), 0, s, d, cgb);
   } else {
     const long total = nvox * CG;
-    PV_LAUNCH(pool_direct_kernel<T>, dim3(blocks_for(total)), dim3(kThreads), 0, s, d, total);
+    const bool win = pv_tune("pool_window", 1) != 0;
+    if (win && d.kt == 3 && d.kh == 3 && d.kw == 3) PV_LAUNCH((pool_window_kernel<T, 3, 3, 3>), dim3(blocks_for(total)), dim3(kThreads), 0, s, d, total);
+    else if (win && d.kt == 1 && d.kh == 3 && d.kw == 3) PV_LAUNCH((pool_window_kernel<T, 1, 3, 3>), dim3(blocks_for(total)), dim3(kThreads), 0, s, d, total);
+    else PV_LAUNCH(pool_direct_kernel<T>, dim3(blocks_for(total)), dim3(kThreads), 0, s, d, total);
   }
   PV_LAUNCH_CHECK();
   if (d.n_prefix > 0) {

@@ -593,6 +593,40 @@ def test_pointwise_conv_on_a_handful_of_rows_head_kernel(B, S, K, N, act, y_f32,
     assert rel_err(outs[0][..., :N], outs[1][..., :N]) <= (1e-5 if y_f32 else 8e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,H,W,Cc,k,stride,pad,mode", [
+    (2, 4, 14, 14, 96, (3, 3, 3), (1, 2, 2), (1, 1, 1), L.POOL_MAX),     # MViT skip-path pool
+    (2, 3, 17, 13, 64, (1, 3, 3), (1, 2, 2), (0, 1, 1), L.POOL_MAX),     # stem pool, ragged edges
+    (1, 5, 9, 9, 40, (3, 3, 3), (2, 1, 1), (1, 1, 1), L.POOL_AVG),       # average, temporal stride, padded count
+    (2, 4, 8, 8, 24, (2, 2, 2), (2, 2, 2), (0, 0, 0), L.POOL_MAX),       # a window the unrolled kernel does not take
+])
+def test_pool3d_windows(dtype, B, T, H, W, Cc, k, stride, pad, mode):
+    """pv_pool3d (MaxPool3d / AvgPool3d of models/stem.py:98-104, layers/attention.py:677-679): the unrolled 3x3x3 / 1x3x3 kernel
+    against torch and bit-identical to the runtime-loop kernel."""
+    cp = (Cc + 7) // 8 * 8
+    x = torch.zeros(B, T, H, W, cp, dtype=dtype, device="cuda")
+    x[..., :Cc] = _rand((B, T, H, W, Cc), 501, dtype)
+    xin = x[..., :Cc].float().permute(0, 4, 1, 2, 3)
+    want = F.max_pool3d(xin, k, stride, pad) if mode == L.POOL_MAX else F.avg_pool3d(xin, k, stride, pad, count_include_pad=True)
+    To, Ho, Wo = want.shape[2:]
+    outs = []
+    try:
+        for win in (1, 0):
+            L.tune(pool_window=win)
+            y = torch.full((B, To, Ho, Wo, cp), 3.0, dtype=dtype, device="cuda")
+            d = L.Pool3dDesc()
+            d.x, d.y, d.x_bs, d.y_bs, d.ldx, d.ldy = x.data_ptr(), y.data_ptr(), T * H * W * cp, To * Ho * Wo * cp, cp, cp
+            d.B, d.Ti, d.Hi, d.Wi, d.C, d.To, d.Ho, d.Wo = B, T, H, W, Cc, To, Ho, Wo
+            d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *stride, *pad)
+            d.mode, d.n_prefix, d.dtype = mode, 0, pv_dtype(x)
+            call("pv_pool3d", d)
+            outs.append(y)
+    finally:
+        L.tune(pool_window=1)
+    assert rel_err(outs[0][..., :Cc].permute(0, 4, 1, 2, 3), want) <= (1e-6 if dtype == torch.float32 else 4e-3)
+    assert torch.all(outs[0][..., Cc:] == 0) and torch.equal(outs[0], outs[1])
+
+
 # ------------------------------------------------------------------ projection shortcut as a second K operand
 @pytest.mark.parametrize("B,T,H,W,cin,cout,cin2,stride,gate", [
     (2, 4, 12, 10, 54, 24, 24, (1, 2, 2), True),      # X3D res2 block 0: SE gate + swish on the first operand only
