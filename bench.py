@@ -15,8 +15,8 @@ job as the explicit launcher line above.
 
 Default workload = BASELINE.json configs[1]: X3D-M, bf16, [32,3,16,224,224] per GPU; the same line carries, under
 "secondary", MViT-B 32x3 (configs[3], the other model BASELINE.json's metric names), SlowFast-R50 8x8 (configs[2]) and
-X3D-L (configs[4]) -- each with its own step percentiles, sustained run and roofline object.  At N > 1 the secondary is
-X3D-L alone (configs[4]: global batch 32 N sharded over the N GPUs).
+X3D-L (configs[4]) -- each with its own step percentiles, sustained run and roofline object.  At N > 1 the secondary
+legs are MViT-B (the metric names it at 1/2/4/8 GPUs) and X3D-L (configs[4]: global batch 32 N sharded over the N GPUs).
 """
 import argparse
 import json
@@ -92,14 +92,23 @@ def synth_input(shape, batch, seed):
     return torch.randn((batch,) + tuple(shape), generator=g)
 
 
+_WEIGHTS = {}
+
+
 def build_model(name, batch, device, dtype, streams=1):
     import torch
     from pytorchvideo_amd.accelerator import convert_to_deployable_form, transmute_model
-    from pytorchvideo_amd.utils import randomize_norm_stats
+    from pytorchvideo_amd.utils import synthetic_trained_like_weights
     torch.manual_seed(0)
     model, shape = make_model(name)
-    randomize_norm_stats(model, 0)
-    model.eval()
+    # the instance tests/test_gpu_full_geometry.py checks against the fp32 oracle at this batch and stream count
+    # (oracle.weights.trained_like_fill draws the same values: tests/test_host.py pins the two fills to each other)
+    if name in _WEIGHTS:       # (the roofline pass rebuilds the single-plan form: calibrate on the host once per workload)
+        model.load_state_dict(_WEIGHTS[name])
+        model.eval()
+    else:
+        synthetic_trained_like_weights(model, synth_input(shape, 2, 7), 0)
+        _WEIGHTS[name] = {k: v.clone() for k, v in model.state_dict().items()}
     x = synth_input(shape, batch, 1234 + int(os.environ.get("RANK", "0")))
     x = [t.to(dtype).to(device) for t in x] if isinstance(x, list) else x.to(dtype).to(device)
     transmute_model(model, "mi355x")
@@ -249,22 +258,40 @@ def roofline_of(sess, workload, clips_s_per_gpu, ms_per_step):
     mfma_bound = dom[2] > 0 and dom[3] / dom[2] > MFMA_PEAK_TFS * 1e12 / (HBM_PEAK_GBS * 1e9)
     # HBM traffic of that kernel from the rocprofv3 PMC passes of the SAME code (tools/gpu_evidence.sh +
     # tools/summarize_pmc.py -> profiles/traffic.json, stamped with the commit it was measured on), else null
-    traffic = traffic_commit = None
+    # Looked up by KERNEL SYMBOL (the "_by_kernel" table: every dispatch of that symbol in the PMC passes, i.e. the
+    # same population `alg_bytes_per_launch` averages over); where only per-op-label figures exist, each of the
+    # symbol's ops takes its label's figure and `traffic_population` says so.
+    traffic = traffic_commit = traffic_pop = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         ent = tj.get(workload, {})
-        top_label = max(dom[4].items(), key=lambda kv: kv[1])[0]
-        traffic = (ent.get(dom_sym) or ent.get(top_label) or {}).get("hbm_bytes_per_launch")
+        sym_ent = (ent.get("_by_kernel") or {}).get(dom_sym)
+        if sym_ent:
+            traffic = sym_ent.get("hbm_bytes_per_launch")
+            traffic_pop = "every dispatch of the symbol in the PMC passes (%d profiled)" % sym_ent.get("dispatches_profiled", 0)
+        else:
+            n_by_label = {}
+            for (label, kind, ms, alg_bytes, flops), sym in zip(prof, kernels):
+                if (sym or "") == dom_sym:
+                    lab = label.split("|")[0]
+                    lab = lab.split(".")[0] if lab.startswith(("conv_b", "conv_ab")) else lab
+                    n_by_label[lab] = n_by_label.get(lab, 0) + 1
+            known = {k: ent[k]["hbm_bytes_per_launch"] for k in n_by_label if k in ent}
+            if known and len(known) == len(n_by_label):
+                traffic = int(sum(known[k] * n_by_label[k] for k in known) / sum(n_by_label.values()))
+                traffic_pop = "per-op-label PMC figures weighted by this symbol's ops: " + ", ".join(
+                    "%s x%d" % kv for kv in sorted(n_by_label.items()))
         traffic_commit = tj.get("_measured_on", {}).get(workload)
-    except (OSError, ValueError):
+    except (OSError, ValueError, KeyError):
         pass
+    plan_bytes = sum(p[3] for p in prof)          # the plan's OWN algorithmic bytes per step (after its fusions)
     r = {
         "bound": "mfma" if mfma_bound else "hbm", "kernel": dom_sym, "launches_per_step": dom[0],
         "op_labels": {k: round(v, 4) for k, v in sorted(dom[4].items(), key=lambda kv: -kv[1])},
         "achieved": round(dom_tfs if mfma_bound else dom_gbs, 1),
         "peak": MFMA_PEAK_TFS if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
         "frac": round(dom_tfs / MFMA_PEAK_TFS if mfma_bound else dom_gbs / HBM_PEAK_GBS, 4),
-        "traffic": traffic, "traffic_measured_on": traffic_commit,
+        "traffic": traffic, "traffic_measured_on": traffic_commit, "traffic_population": traffic_pop,
         "alg_bytes_per_launch": int(dom[2] / max(dom[0], 1)), "alg_flops_per_launch": int(dom[3] / max(dom[0], 1)),
         "avg_launch_ms": round(dom[1] / max(dom[0], 1), 5),
         "kernel_ms_per_step": round(dom[1], 4), "all_kernels_ms_per_step": round(total_kernel_ms, 4),
@@ -273,7 +300,12 @@ def roofline_of(sess, workload, clips_s_per_gpu, ms_per_step):
         "timing": "pv_plan_profile on the single-plan form of the per-GPU batch (every kernel alone on the chip, = "
                   "bench.py --streams 1): each op timed in situ between its own HIP event pair behind a queued replay, "
                   "min of 3, null event interval subtracted; ops folded by the kernel symbol they were routed to",
+        # whole model against the HBM roofline, two byte models: SURVEY 8d's per-op model of the REFERENCE op graph
+        # (each Conv/Linear reads its input and writes its output once; wl['mb'] MB per clip) and this plan's own
+        # algorithmic bytes (what its fused kernels have to move: fewer bytes, so a lower -- stricter -- fraction)
         "model_hbm_frac": round(clips_s_per_gpu * wl["mb"] * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
+        "model_hbm_frac_plan": round(plan_bytes / max(ms_per_step, 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+        "plan_alg_mb_per_step": round(plan_bytes / 1e6, 1),
         "model_mfma_frac": round(clips_s_per_gpu * wl["gflop"] * 1e9 / (MFMA_PEAK_TFS * 1e12), 4),
     }
     return r, prof, agg
@@ -568,7 +600,7 @@ def _main(out):
         del model, x, step
         torch.cuda.empty_cache()
         secondary = {}
-        for w2 in (("mvit_b_32x3", "slowfast_r50", "x3d_l") if world == 1 else ("x3d_l",)):
+        for w2 in (("mvit_b_32x3", "slowfast_r50", "x3d_l") if world == 1 else ("mvit_b_32x3", "x3d_l")):
             r2, m2, x2, _ = run_workload(w2, args, world, rank, device, max(10, args.steps // 2), 3,
                                          sustained_s=0.0 if args.no_sustained else 1.0)
             roof2 = None
@@ -595,7 +627,7 @@ def _main(out):
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "per_gpu_batch": batch,
                        "global_batch": batch * world, "parallelism": "dp%d (batch-sharded, logits all_gather)" % world,
                        "head_collective": HEAD["how"],
-                       "weights": "random-init, randomised BN stats", "hip_graph": not args.no_graph,
+                       "weights": "random-init conditioned like a checkpoint (pytorchvideo_amd.utils.synthetic_trained_like_weights: BN statistics calibrated on data, block-final gamma U(0.05,0.2)); the instance of tests/test_gpu_full_geometry.py", "hip_graph": not args.no_graph,
                        "streams": res["streams"]},
             "roofline": roof,
         }

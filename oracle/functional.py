@@ -25,21 +25,27 @@ import torch.nn.functional as F
 # against the fp32 reference (tools/storage_floor.py).
 _STORE = None
 _BATCH_HINT = 1     # clips in the deploy form's batch: the MViT plan routes pooling convs by tensor size
+POOL_STREAM_MIN_ELEMS_DEFAULT = 1 << 23     # the deploy form's default routing threshold (tuning.OPTIONS["pool_stream_min_elems"]);
+_POOL_STREAM_MIN_ELEMS = POOL_STREAM_MIN_ELEMS_DEFAULT   # tests/test_host.py pins the two to each other
 
 
 class storage_emulation:
-    def __init__(self, dtype=torch.bfloat16, batch=1):
+    """`pool_stream_min_elems`: the deploy form's routing threshold for MViT pooling convs (a caller that changed the
+    knob passes the same value; tests/test_host.py checks that the default here is the emitters' default)."""
+
+    def __init__(self, dtype=torch.bfloat16, batch=1, pool_stream_min_elems=None):
         self.dtype, self.batch = dtype, batch
+        self.pool_min = POOL_STREAM_MIN_ELEMS_DEFAULT if pool_stream_min_elems is None else int(pool_stream_min_elems)
 
     def __enter__(self):
-        global _STORE, _BATCH_HINT
+        global _STORE, _BATCH_HINT, _POOL_STREAM_MIN_ELEMS
         dt = self.dtype
-        _STORE, _BATCH_HINT = (lambda t: t.to(dt).to(torch.float32)), self.batch
+        _STORE, _BATCH_HINT, _POOL_STREAM_MIN_ELEMS = (lambda t: t.to(dt).to(torch.float32)), self.batch, self.pool_min
         return self
 
     def __exit__(self, *exc):
-        global _STORE, _BATCH_HINT
-        _STORE, _BATCH_HINT = None, 1
+        global _STORE, _BATCH_HINT, _POOL_STREAM_MIN_ELEMS
+        _STORE, _BATCH_HINT, _POOL_STREAM_MIN_ELEMS = None, 1, POOL_STREAM_MIN_ELEMS_DEFAULT
         return False
 
 
@@ -479,7 +485,7 @@ def _attention_pool(sd, t, thw, p, kernel, stride, has_cls, norm_p=None, pool_fn
         # the deploy form pools big grids with the plane-streaming depthwise kernel (its output is stored, the per-head
         # LayerNorm is a second launch) and small ones with the fused pool + LayerNorm kernel (emit_mvit._streams_well)
         if norm_p is None or (tuple(kernel) == (3, 3, 3) and stride[0] == 1 and stride[1] == stride[2] and stride[1] in (1, 2)
-                              and _BATCH_HINT * T * H * W * N * C >= (1 << 23)):
+                              and _BATCH_HINT * T * H * W * N * C >= _POOL_STREAM_MIN_ELEMS):
             g = _st(g)
     thw = [g.shape[2], g.shape[3], g.shape[4]]
     t = g.reshape(B, N, C, -1).transpose(2, 3)

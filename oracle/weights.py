@@ -134,8 +134,14 @@ def calibrated_fill(model, calib_input, seed=0):
     output (measured, tools/parity_full.py) -- a property of that random instance, not of the arithmetic
     under test.  Calibrated statistics give the activation scales a trained network has (unit variance
     after every BatchNorm, residual stream growing like sqrt(depth))."""
-    import torch.nn as nn
     reference_style_fill(model, seed)
+    return _calibrate_running_stats(model, calib_input)
+
+
+@torch.no_grad()
+def _calibrate_running_stats(model, calib_input):
+    """Set every BatchNorm's running statistics to the batch statistics of its input on `calib_input`."""
+    import torch.nn as nn
     bns = [m for m in model.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
     saved = [m.momentum for m in bns]
     model.eval()
@@ -148,3 +154,54 @@ def calibrated_fill(model, calib_input, seed=0):
         m.momentum = mom
     model.eval()
     return model
+
+
+TRAINED_LIKE_FINAL_GAMMA = (0.05, 0.2)
+
+
+@torch.no_grad()
+def trained_like_fill(model, calib_input, seed=0, final_gamma=TRAINED_LIKE_FINAL_GAMMA):
+    """calibrated_fill with the gamma of every BLOCK-FINAL BatchNorm (the modules the reference flags
+    `block_final_bn`, pytorchvideo/models/resnet.py `norm_c.block_final_bn = True`) drawn from U(0.05, 0.2) instead
+    of `rand_init_bn`'s U(0.5, 1.5); the running statistics of EVERY BatchNorm are calibrated on the data afterwards
+    (a checkpoint's running statistics are the data's).
+
+    Why: the reference's own init sets that gamma to ZERO (pytorchvideo/models/weight_init.py:34-35: a residual
+    branch starts as the identity) and training moves it off zero; it is never the O(1) that
+    tests/test_fuse_bn.py:58-63 draws for a *single* fused layer.  With gamma ~ 1 on every block-final BatchNorm each
+    residual branch is as large as the trunk, 26-55 blocks compound every rounding, and bf16 STORAGE alone (exact
+    arithmetic, no kernel) moves the logits by 3-7e-2 (`calibrated_fill`, kept as the stress instance).
+
+    Measured on the CPU, no kernel involved (tools/storage_floor.py, profiles/r4/storage_floor.json; metric
+    max|d| / max|logits|, one clip at the BASELINE geometry; "5 %" = the answer of the fp32 oracle to a 5 % scaling
+    of ONE res3 conv_c filter bank, i.e. how loudly a kernel defect in one layer speaks in the logits; "clips" = the
+    difference between the logits of two different clips):
+
+        X3D-M, block-final gamma                  bf16 weights   bf16 storage   5 % defect   clips
+        U(0.5,1.5)  calibrated (stress)              2.6e-2         4.2e-2        5.9e-2     7.0e-2
+        U(0.2,0.6)  calibrated                       8.3e-3         9.4e-3        2.4e-2     6.5e-2
+        U(0.1,0.4)  calibrated                       7.5e-3         9.1e-3        9.1e-3     7.2e-2
+        U(0.05,0.2) calibrated  (THIS fill)          6.3e-3         6.3e-3        3.8e-3     6.6e-2
+        U(0.5,1.5) x 0.25 AFTER calibration,         3.1e-3         3.6e-3        6.6e-4     2.0e-3
+                   statistics left stale
+        X3D-L:  U(0.1,0.4) 9.9e-3 / 1.2e-2;  U(0.05,0.2) 6.7e-3 / 8.2e-3;  U(0.03,0.12) 7.4e-3 / 8.6e-3;  stale 2.7e-3 / 3.5e-3
+        SlowFast-R50:  U(0.1,0.4) 4.5e-3 / 5.0e-3;  U(0.05,0.2) 3.7e-3 / 3.6e-3;  stale 2.0e-3 / 2.0e-3
+
+    Two things follow.  (1) With calibrated statistics the floor of the conv stacks stops falling at ~6e-3 however small
+    the branches are made: it is set by the ~8 layers EVERY signal passes in series (stem, the four projection shortcuts,
+    the three head layers; X3D-M: head 4.5e-3, shortcuts 3.4e-3, all 26 branches together 2.2e-3): a bf16 filter's
+    rounding error times the non-negative (post-ReLU) mean of its input is a per-channel constant that the global
+    average pool does not average away.  (2) The last row -- scaling gamma after the calibration and leaving every
+    downstream running statistic stale, which is how the 3.6e-3 / 3.5e-3 / 2.0e-3 of the round-3 review were obtained
+    -- reaches its low floor by switching the signal path off: the logits of two different clips then differ by 2e-3
+    and a 5 % defect in a conv_c moves them by 6.6e-4, so a 1e-2 gate on that instance cannot fail for any kernel
+    defect below ~75 % in a layer.  This fill keeps the statistics calibrated (input-sensitive logits, clips differ by
+    6.6e-2) and takes the smallest branch scale at which every BASELINE conv stack sits below 1e-2 in bf16 storage.
+    Models without flagged norms (MViT) get exactly calibrated_fill."""
+    import torch.nn as nn
+    reference_style_fill(model, seed)
+    lo, hi = final_gamma
+    for name, mod in model.named_modules():
+        if isinstance(mod, nn.modules.batchnorm._BatchNorm) and getattr(mod, "block_final_bn", False):
+            mod.weight.copy_(_uniform(mod.weight.shape, lo, hi, _gen(name + "/final_gamma", seed)))
+    return _calibrate_running_stats(model, calib_input)

@@ -14,8 +14,8 @@ OPTIONS = {
     "split_joint_graph": True,   # sub-batches of SplitBatchDeployed as branches of ONE hipGraph  (conversion)
     "pool_stream_min_elems": 1 << 23,   # MViT pooling convs on grids at least this big use the plane-streaming kernel + a
                                         # separate per-head LayerNorm; smaller ones the fused pool + LayerNorm kernel  (emit_mvit)
-    "fuse_ln_qkv": True,
-    "fuse_ln_qkv_max_c": 192,    # ... for token widths up to this (wider / shorter tensors: the LDS-DMA GEMM wins)         # MViT norm1 + the q|k|v Linear as ONE launch (pv_ln_linear_rows)              (emit_mvit)
+    "fuse_ln_qkv": True,         # MViT norm1 + the q|k|v Linear as ONE launch (pv_ln_linear_rows)               (emit_mvit)
+    "fuse_ln_qkv_max_c": 192,    # ... for token widths up to this (wider / shorter tensors: the LDS-DMA GEMM wins)
     "fuse_mlp": True,            # MViT norm2 + fc1 + GELU + fc2 + residual as ONE launch (pv_mlp_rows)  (emit_mvit)
     "arena_guards": 0,           # debug build of the launch plan: every arena buffer gets its own memory (no re-use) followed
                                  # by this many bytes of canary; Session.check_guards() names the buffers a kernel wrote past

@@ -362,3 +362,42 @@ def test_grouped_temporal_conv_declines_the_stem_fusion_and_the_fused_producer()
     conv_a = nn.Conv3d(24, 48, 1, bias=False)
     with pytest.raises(E.Unsupported):
         E.emit_dwconv(sess, conv_b, y, producer=(conv_a, None, L.ACT_RELU))
+
+
+def test_bench_weight_fill_is_the_parity_tests_instance_bit_for_bit():
+    """bench.py times `pytorchvideo_amd.utils.synthetic_trained_like_weights`; tests/test_gpu_full_geometry.py asserts the
+    north star on `oracle.weights.trained_like_fill`.  The two draw the same key-addressed values and calibrate the same
+    way: identical state_dicts (X3D incl. SE blocks, SlowFast incl. the lateral fusions, MViT without flagged norms)."""
+    import torch
+    from oracle.weights import seeded_input, trained_like_fill
+    from pytorchvideo_amd.models import create_multiscale_vision_transformers, create_slowfast, create_x3d
+    from pytorchvideo_amd.utils import synthetic_trained_like_weights
+    cases = [
+        (lambda: create_x3d(input_clip_length=4, input_crop_size=64), seeded_input((2, 3, 4, 64, 64), 3)),
+        (lambda: create_slowfast(model_depth=18, slowfast_fusion_conv_stride=(4, 1, 1), head_pool_kernel_sizes=((2, 2, 2), (8, 2, 2))),
+         [seeded_input((2, 3, 2, 64, 64), 4), seeded_input((2, 3, 8, 64, 64), 5)]),
+        (lambda: create_multiscale_vision_transformers(spatial_size=32, temporal_size=4, depth=2, head_num_classes=101), None),
+    ]
+    for make, x in cases:
+        torch.manual_seed(0)
+        a = make()
+        torch.manual_seed(0)
+        b = make()
+        if x is None:
+            x = seeded_input((1, 3, 4, 32, 32), 6)
+        trained_like_fill(a, x, 0)
+        synthetic_trained_like_weights(b, x, 0)
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa) == list(sb)
+        assert all(torch.equal(sa[k], sb[k]) for k in sa), [k for k in sa if not torch.equal(sa[k], sb[k])][:3]
+        finals = [m for m in a.modules() if getattr(m, "block_final_bn", False)]
+        assert all(0.05 <= float(m.weight.min()) and float(m.weight.max()) <= 0.2 for m in finals)
+
+
+def test_the_oracles_storage_emulation_routes_pools_by_the_emitters_threshold():
+    from oracle import functional as OF
+    from pytorchvideo_amd.accelerator.mi355x import tuning
+    assert OF.POOL_STREAM_MIN_ELEMS_DEFAULT == tuning.OPTIONS["pool_stream_min_elems"]
+    with OF.storage_emulation(pool_stream_min_elems=123):
+        assert OF._POOL_STREAM_MIN_ELEMS == 123
+    assert OF._POOL_STREAM_MIN_ELEMS == OF.POOL_STREAM_MIN_ELEMS_DEFAULT

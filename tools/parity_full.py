@@ -1,6 +1,7 @@
 """Parity of the deploy form at the FULL BASELINE.json geometries against the CPU oracle (run on the GPU box).
 
-Weights: `calibrated` (default; oracle/weights.py::calibrated_fill -- the reference tests' BatchNorm randomisation,
+Weights: `trained_like` (oracle/weights.py::trained_like_fill: calibrated BatchNorm statistics, block-final gamma
+U(0.05, 0.2) -- the instance bench.py times and the north-star tests assert 1e-2 on), `calibrated` (the stress instance; oracle/weights.py::calibrated_fill -- the reference tests' BatchNorm randomisation,
 tests/test_fuse_bn.py:58-63, with the running statistics then set to the batch statistics of a calibration batch:
 what a trained checkpoint holds, logits O(1-10)), `reference_style` (arbitrary running statistics: activations grow
 to 1e4-1e10) or `deterministic`.
@@ -33,10 +34,12 @@ import torch  # noqa: E402
 def filled_model(workload, fill, seed=0):
     """(original-form model with the requested fill, input shape)."""
     from bench import make_model, synth_input
-    from oracle.weights import calibrated_fill, deterministic_fill, reference_style_fill
+    from oracle.weights import calibrated_fill, deterministic_fill, reference_style_fill, trained_like_fill
     torch.manual_seed(0)
     m, shape = make_model(workload)
-    if fill == "calibrated":
+    if fill == "trained_like":
+        trained_like_fill(m, synth_input(shape, 2, 7), seed)
+    elif fill == "calibrated":
         calibrated_fill(m, synth_input(shape, 2, 7), seed)
     elif fill == "reference_style":
         reference_style_fill(m, seed)
@@ -45,8 +48,8 @@ def filled_model(workload, fill, seed=0):
     return m.eval(), shape
 
 
-def oracle_numbers(workload, sd, x, batch_hint=1):
-    """(fp32 oracle, weights-only oracle, bf16-storage oracle) logits."""
+def oracle_numbers(workload, sd, x, batch_hint=1, weights_only=True):
+    """(fp32 oracle, weights-only oracle [or None], bf16-storage oracle) logits."""
     from bench import oracle_forward
     from oracle import functional as OF
     from oracle.weights import quantize_like_kernels
@@ -55,8 +58,9 @@ def oracle_numbers(workload, sd, x, batch_hint=1):
         want = fn(sd, x)
         sd_q = quantize_like_kernels(sd)
         xq = [t.bfloat16().float() for t in x] if isinstance(x, list) else x.bfloat16().float()
-        want_w = fn(sd_q, xq)
-        with OF.storage_emulation(torch.bfloat16, batch=batch_hint):
+        want_w = fn(sd_q, xq) if weights_only else None
+        from pytorchvideo_amd.accelerator.mi355x import tuning       # the plan's own routing threshold, not a copy of it
+        with OF.storage_emulation(torch.bfloat16, batch=batch_hint, pool_stream_min_elems=tuning.get("pool_stream_min_elems")):
             want_e = fn(sd_q, xq)
     return want, want_w, want_e
 
@@ -73,11 +77,11 @@ def case(workload, fill="calibrated", batch=1, streams=1, dtypes=("fp32", "bf16"
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     x = synth_input(shape, batch, 99)
     t0 = time.time()
-    want, want_w, want_e = oracle_numbers(workload, sd, x, batch_hint=max(1, batch // streams))
+    want, want_w, want_e = oracle_numbers(workload, sd, x, batch_hint=max(1, batch // streams), weights_only=batch == 1)
     out["oracle_s"] = round(time.time() - t0, 2)
     out["logit_absmax"] = round(want.abs().max().item(), 4)
     out["logit_std"] = round(want.std().item(), 4)
-    out["weights_floor"] = rel(want_w, want)
+    out["weights_floor"] = rel(want_w, want) if want_w is not None else None
     out["storage_floor"] = rel(want_e, want)
     transmute_model(m, "mi355x")
     for tag in dtypes:
@@ -93,6 +97,7 @@ def case(workload, fill="calibrated", batch=1, streams=1, dtypes=("fp32", "bf16"
             out["bf16_vs_emulated_oracle"] = rel(got, want_e)
             out["bf16_vs_fp32_oracle"] = rel(got, want)
             out["bf16_rows_worst"] = max(rel(got[i:i + 1], want_e[i:i + 1]) for i in range(batch))
+            out["bf16_rows_worst_fp32"] = max(rel(got[i:i + 1], want[i:i + 1]) for i in range(batch))
             out["top1_agree"] = int((got.argmax(1) == want.argmax(1)).sum().item())
             out["top1_agree_emulated"] = int((got.argmax(1) == want_e.argmax(1)).sum().item())
         del dm
@@ -103,7 +108,7 @@ def case(workload, fill="calibrated", batch=1, streams=1, dtypes=("fp32", "bf16"
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--workloads", default="x3d_m,x3d_l,slowfast_r50,mvit_b_32x3")
-    ap.add_argument("--fills", default="calibrated")
+    ap.add_argument("--fills", default="trained_like")
     ap.add_argument("--bench-batch", action="store_true", help="also the bench batch with its stream count, bf16")
     ap.add_argument("--json", default="")
     a = ap.parse_args()

@@ -59,7 +59,7 @@ def floors(workload, fill="calibrated"):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--workloads", default="x3d_m,x3d_l,slowfast_r50,mvit_b_32x3")
-    ap.add_argument("--fills", default="calibrated,reference_style")
+    ap.add_argument("--fills", default="trained_like,calibrated")
     ap.add_argument("--json", default="")
     a = ap.parse_args()
     rows = []

@@ -172,6 +172,20 @@ def main():
         traffic[label] = {"kernel_regex": rx, "dispatches_profiled": n1, "fetch_bytes_per_launch": round(fb),
                           "write_bytes_per_launch": round(wb), "hbm_bytes_per_launch": round(fb + wb),
                           "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, gfx950 FETCH_SIZE x2 correction"}
+    # per kernel SYMBOL (template arguments folded): every dispatch of the symbol in the passes -- the population
+    # bench.py's roofline object averages `alg_bytes_per_launch` over
+    by_sym = collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
+    for k in nf:
+        e = by_sym[k.split("<")[0]]
+        e[0] += nf[k]
+        e[1] += fetch[k].get("FETCH_SIZE", 0.0)
+        e[2] += nw.get(k, 0)
+        e[3] += write.get(k, {}).get("WRITE_SIZE", 0.0)
+    traffic["_by_kernel"] = {
+        sym: {"dispatches_profiled": e[0], "fetch_bytes_per_launch": round(2.0 * e[1] * 1024 / e[0]), "write_bytes_per_launch": round(e[3] * 1024 / e[2]),
+              "hbm_bytes_per_launch": round(2.0 * e[1] * 1024 / e[0] + e[3] * 1024 / e[2]),
+              "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, gfx950 FETCH_SIZE x2 correction"}
+        for sym, e in by_sym.items() if e[0] and e[2]}
     print("\nTRAFFIC " + json.dumps({wl: traffic}))
 
 
