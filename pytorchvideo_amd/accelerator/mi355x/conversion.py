@@ -111,7 +111,7 @@ class SplitBatchDeployed(nn.Module):
         # whole-model plan with a known input buffer; else one graph per part on its own stream
         self._joint = joint and all(getattr(p, "_pv_inputs", None) is not None and hasattr(p, "_pv_result") for p in parts)
         self.__dict__["_joint_handle"] = None
-        self.__dict__["_joint_ops"] = None       # op counts of the member plans the joint graph was captured from
+        self.__dict__["_joint_ops"] = None       # (generation, op count) of the member plans the joint graph was captured from
 
     def __del__(self):
         h = self.__dict__.get("_joint_handle")
@@ -130,7 +130,8 @@ class SplitBatchDeployed(nn.Module):
         lib = L.lib()
         s0 = self.parts[0]._pv_session
         with torch.cuda.device(self._device):
-            ops = [lib.pv_plan_size(p._pv_session.plan) for p in self.parts]
+            # (generation of the plan build, op count) per member: a re-finalized plan with the same op count is a NEW plan
+            ops = [(getattr(p._pv_session, "generation", 0), lib.pv_plan_size(p._pv_session.plan)) for p in self.parts]
             if self._joint_handle is None or ops != self._joint_ops:
                 if self._joint_handle is None:
                     self.__dict__["_joint_handle"] = lib.pv_joint_create()

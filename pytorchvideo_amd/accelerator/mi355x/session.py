@@ -139,6 +139,7 @@ class _Arena:
 
 
 class Session:
+    _generations = 0        # plans finalized in this process; see `generation`
     def __init__(self, dtype=torch.bfloat16, device=None, reuse_buffers=True):
         assert dtype in (torch.bfloat16, torch.float32), "deploy dtype must be bf16 or fp32"
         self.dtype = dtype
@@ -234,6 +235,8 @@ class Session:
         self.weights_t = blob.to(dev)
         base = {"arena": self.arena_t.data_ptr(), "weights": self.weights_t.data_ptr()}
         self.plan = C.c_void_p(lib.pv_plan_create())
+        Session._generations += 1
+        self.generation = Session._generations       # identifies THIS build of the plan (a joint graph is captured from it)
         for kind, cls, fields, label, _, _ in self.ops:
             d = cls()
             def resolve(v):

@@ -5,6 +5,8 @@
 #include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "pv_common.h"
@@ -19,7 +21,11 @@ typedef int (*fn_comm_init_rank)(void**, int, NcclId, int);
 typedef int (*fn_all_gather)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef int (*fn_comm_destroy)(void*);
 typedef const char* (*fn_error_string)(int);
+typedef int (*fn_get_version)(int*);
 constexpr int kNcclUint8 = 1;
+// The signatures above (ncclUniqueId = 128 bytes BY VALUE, ncclUint8 = 1) are those of NCCL / RCCL 2.x; a library that
+// reports another major version is refused instead of being called through a guessed ABI.
+constexpr int kNcclMajorKnown = 2;
 
 struct Rccl {
   void* handle = nullptr;
@@ -29,13 +35,35 @@ struct Rccl {
   fn_all_gather all_gather = nullptr;
   fn_comm_destroy comm_destroy = nullptr;
   fn_error_string error_string = nullptr;
+  int version = 0;        // ncclGetVersion: major * 10000 + minor * 100 + patch (2.9+), 0 if the symbol is absent
 };
 
 // One binding per distinct candidate list (in practice: one).  Candidates are tried in order; for each, a copy that
 // is ALREADY mapped (RTLD_NOLOAD: torch's librccl when torch.distributed is in the process) wins over loading a
 // second RCCL instance.
+int bind_rccl_uncached(const std::string& all, Rccl* out);
+
+// Bound once per candidate list for the life of the process (every pv_comm_* call used to dlopen again and leak a handle
+// reference per call); the handle is never closed: communicators hold function pointers into it.
 int bind_rccl(const char* lib_paths, Rccl* out) {
-  std::string all = (lib_paths && *lib_paths) ? lib_paths : "librccl.so:librccl.so.1";
+  static std::mutex mu;
+  static std::map<std::string, Rccl> cache;
+  const std::string all = (lib_paths && *lib_paths) ? lib_paths : "librccl.so:librccl.so.1";
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(all);
+  if (it == cache.end()) {
+    Rccl r;
+    const int rc = bind_rccl_uncached(all, &r);
+    if (rc != PV_OK) return rc;
+    if (lib_paths && *lib_paths)      // an explicit library list (PV_RCCL_LIB on the binding side: the CPU tests' double) is said out loud
+      fprintf(stderr, "pv_comm: RCCL bound from the caller's list \"%s\" -> %s (version %d)\n", all.c_str(), r.path.c_str(), r.version);
+    it = cache.emplace(all, r).first;
+  }
+  *out = it->second;
+  return PV_OK;
+}
+
+int bind_rccl_uncached(const std::string& all, Rccl* out) {
   std::vector<std::string> cands;
   size_t pos = 0;
   while (pos <= all.size()) {
@@ -73,6 +101,19 @@ int bind_rccl(const char* lib_paths, Rccl* out) {
                        "ncclCommDestroy symbol").c_str());
     dlclose(h);
     return PV_ERR_HIP;
+  }
+  if (auto get_version = reinterpret_cast<fn_get_version>(dlsym(h, "ncclGetVersion"))) {
+    int v = 0;
+    if (get_version(&v) == 0) out->version = v;
+    const int major = v >= 10000 ? v / 10000 : v / 1000;      // (before 2.9 the encoding was major * 1000 + ...)
+    if (v > 0 && major != kNcclMajorKnown) {
+      char buf[256];
+      snprintf(buf, sizeof(buf), "pv_comm: %s reports NCCL version %d; only major version %d is known to have the call "
+               "signatures this file declares", used.c_str(), v, kNcclMajorKnown);
+      pv_set_text_error(buf);
+      dlclose(h);
+      return PV_ERR_HIP;
+    }
   }
   return PV_OK;
 }

@@ -211,6 +211,11 @@ class ShardedForward:
 
     def __call__(self, x):
         multi = isinstance(x, (list, tuple))
+        n = (x[0] if multi else x).shape[0]
+        if n != self.n_local:                      # before any ingest
+            raise self._L.PvError("deploy form was converted for a batch of %d, got %d" % (self.n_local, n))
+        if not multi and x.dim() == 4:
+            x = x.unsqueeze(2)                     # image model: a clip of one frame (as SplitBatchDeployed.forward)
         lo = 0
         for part, b in zip(self.parts, self.splits):
             if b is None:

@@ -124,16 +124,21 @@ class DevicePacker:
             raise RuntimeError("bboxes are given to a detection model and only to a detection model")
         if clip.dim() != 5:
             raise RuntimeError("expected a [B,C,T,H,W] clip, got %s" % (tuple(clip.shape),))
-        clip = clip.to(self.sess.device, non_blocking=True)
         if self.subs is not None:
+            # validate BEFORE any ingest: a short batch must not reach the sub-plans' input buffers
+            want = sum(self.model._splits)
+            if clip.shape[0] != want:
+                raise RuntimeError("deploy form was converted for a batch of %d, got %d" % (want, clip.shape[0]))
+            if bboxes is not None:
+                raise RuntimeError("bboxes cannot be given to a split-batch deploy form (detection models are converted as one plan)")
+            clip = clip.to(self.sess.device, non_blocking=True)
             lo = 0
             for sub, b in zip(self.subs, self.model._splits):
                 sub._fill(clip[lo:lo + b])
                 lo += b
-            if lo != clip.shape[0]:
-                raise RuntimeError("deploy form was converted for a batch of %d, got %d" % (lo, clip.shape[0]))
             self.model._pv_launch()
             return self.model._pv_result()
+        clip = clip.to(self.sess.device, non_blocking=True)
         self._fill(clip)
         if load_boxes is not None:
             load_boxes(bboxes)

@@ -96,3 +96,10 @@ const char* ncclGetErrorString(int code) {
     default: return "stub error";
   }
 }
+
+/* ncclGetVersion: 2.21.5 unless PV_RCCL_STUB_VERSION says otherwise (the refusal test reports a major version 3) */
+int ncclGetVersion(int* version) {
+  const char* v = getenv("PV_RCCL_STUB_VERSION");
+  *version = v ? atoi(v) : 22105;
+  return 0;
+}

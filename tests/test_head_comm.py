@@ -108,3 +108,22 @@ def test_real_rccl_one_rank_and_forward_gather_on_the_gpu():
             torch.cuda.synchronize()
             assert got.shape == want.shape and torch.equal(got, want)
     comm.close()
+
+
+def test_an_rccl_of_an_unknown_major_version_is_refused_and_the_binding_is_cached(tmp_path):
+    """the NCCL call signatures are declared locally, so a library that reports another major version is
+    refused (never called through a guessed ABI); and a binding is made once per library list, not once per call."""
+    from pytorchvideo_amd import _lib as L
+    stub = _build_stub(tmp_path)
+    lib = L.lib()
+    assert lib.pv_comm_probe(stub.encode()) == 0
+    # the same list again: served from the cache (the environment is not even consulted any more)
+    os.environ["PV_RCCL_STUB_VERSION"] = "30000"
+    try:
+        assert lib.pv_comm_probe(stub.encode()) == 0
+        # a different list naming the same file binds afresh and now sees major version 3
+        rc = lib.pv_comm_probe((stub + ":" + stub).encode())
+        assert rc != 0
+        assert b"version" in (lib.pv_last_error() or b"")
+    finally:
+        del os.environ["PV_RCCL_STUB_VERSION"]
