@@ -146,6 +146,71 @@ __device__ __forceinline__ float pv_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// ---- "the last workgroup of a group finishes the job" (in-launch reduction, cdna_hip_programming.md 5 / 6 Guideline 16) ----
+// Every workgroup of a group (e.g. the tiles of one clip) calls this AFTER its global stores of the data to be combined:
+// all waves drain their stores, lane 0 releases at agent scope (L2 write-back) and THEN draws a ticket; the workgroup that
+// draws the last ticket re-arms the counter for the next launch, acquires, and every thread of it may read the other
+// workgroups' data with plain loads.  `s_flag`: one int of LDS no thread reads or writes concurrently.
+__device__ __forceinline__ bool pv_last_workgroup(unsigned* counter, unsigned total, int* s_flag, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (restated: ROCm 7.2 may drop the wait behind buffer_wbl2)
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t + 1u == total;
+    if (last) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+// Squeeze-excitation gate of ONE clip from its per-workgroup partial sums ps[nblk][c_p] (fixed summation order:
+// deterministic): gate[c] = sigmoid(W2 . relu(W1 . mean + b1) + b2), padding channels 0.  All `nthreads` threads of the
+// workgroup call it; s: c_p + 32 floats of LDS; cr <= 32.
+__device__ __forceinline__ void pv_se_gate_clip(const float* __restrict__ ps, int nblk, int C, int c_p, int cr, float inv_count,
+                                                const float* __restrict__ w1, const float* __restrict__ b1,
+                                                const float* __restrict__ w2, const float* __restrict__ b2,
+                                                float* __restrict__ gate, float* s, int tid, int nthreads) {
+  float* s_mean = s;
+  float* s_hid = s + c_p;
+  for (int c = tid; c < c_p; c += nthreads) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nblk; k += 4) {
+      a0 += ps[(long)k * c_p + c];
+      a1 += ps[(long)(k + 1) * c_p + c];
+      a2 += ps[(long)(k + 2) * c_p + c];
+      a3 += ps[(long)(k + 3) * c_p + c];
+    }
+    for (; k < nblk; ++k) a0 += ps[(long)k * c_p + c];
+    s_mean[c] = ((a0 + a1) + (a2 + a3)) * inv_count;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+  for (int r = wave; r < cr; r += nwaves) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a += w1[(long)r * C + c] * s_mean[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) s_hid[r] = fmaxf(a + (b1 ? b1[r] : 0.f), 0.f);
+  }
+  __syncthreads();
+  for (int c = tid; c < c_p; c += nthreads) {
+    float g = 0.f;
+    if (c < C) {
+      float a = b2 ? b2[c] : 0.f;
+      for (int r = 0; r < cr; ++r) a += w2[(long)c * cr + r] * s_hid[r];
+      g = pv_sigmoid(a);
+    }
+    gate[c] = g;
+  }
+}
+
 __device__ __forceinline__ float pv_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

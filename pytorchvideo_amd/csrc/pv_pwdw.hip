@@ -272,6 +272,11 @@ __global__ __launch_bounds__(kPlaneThreads) void pwdw_plane_kernel(const pv_dwco
       for (int rr = 0; rr < kPR; ++rr) a += s_ps[rr][tid];
       d.psum[((long)b * ntiles + tile_id) * c_p + cbase + tid] = a;
     }
+    if (d.se_gate != nullptr) {   // squeeze-excitation gate in this launch: the clip's last workgroup computes it (pv_common.h)
+      if (pv_last_workgroup(d.se_count + b, (unsigned)(ntiles * ngroups), reinterpret_cast<int*>(&s_ps[0][0]), tid))
+        pv_se_gate_clip(d.psum + (long)b * ntiles * c_p, ntiles, d.C, c_p, d.se_cr, d.se_inv_count, d.se_w1, d.se_b1, d.se_w2,
+                        d.se_b2, d.se_gate + (long)b * c_p, reinterpret_cast<float*>(&s_in[0][0][0]), tid, kPlaneThreads);
+    }
   }
 }
 
