@@ -457,6 +457,14 @@ typedef struct pv_mlp_desc {
   int32_t act;           /* pv_act between the two Linears */
   int32_t dtype;         /* PV_BF16 */
   float ln_eps;
+  /* Optional (round 4): yn != NULL -> the kernel ALSO writes yn[m][:] = LayerNorm(y[m][:]; nn_gamma, nn_beta, nn_eps) as
+   * bf16 [M][ldyn] from the rows it still holds in registers: norm1 of the NEXT MultiScaleBlock (layers/attention.py:729-737),
+   * i.e. the operand of that block's q|k|v projection, without a LayerNorm launch reading the stream back. */
+  void* yn;
+  const float* nn_gamma;
+  const float* nn_beta;
+  int32_t ldyn;
+  float nn_eps;
 } pv_mlp_desc;
 int pv_mlp_rows(const pv_mlp_desc* d, pv_stream_t stream);
 int pv_mlp_rows_supported(const pv_mlp_desc* d);

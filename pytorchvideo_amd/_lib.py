@@ -104,7 +104,8 @@ RoiAlignDesc = _struct("RoiAlignDesc", [
 
 MlpDesc = _struct("MlpDesc", [
     ("x", _p), ("w12", _p), ("y", _p), ("b2", _p), ("residual", _p), ("ln_gamma", _p), ("ln_beta", _p), ("M", _i64)]
-    + _ints("C", "H", "Cout", "ldx", "ldr", "ldy", "act", "dtype") + [("ln_eps", _f32)])
+    + _ints("C", "H", "Cout", "ldx", "ldr", "ldy", "act", "dtype") + [("ln_eps", _f32)]
+    + [("yn", _p), ("nn_gamma", _p), ("nn_beta", _p)] + _ints("ldyn") + [("nn_eps", _f32)])
 
 LnLinearDesc = _struct("LnLinearDesc", [
     ("x", _p), ("wb", _p), ("y", _p), ("ln_gamma", _p), ("ln_beta", _p), ("M", _i64)]

@@ -420,7 +420,9 @@ def _try_fuse_mvit(model, sess, dtype, input_tensor):
             raise E.Unsupported("pos_drop")
         cur = EM.emit_patch_embed_and_pos(sess, model.patch_embed, model.cls_positional_encoding, first_in)
         # first_in stays live: it is re-filled by every forward
-        for blk in model.blocks:
+        for i, blk in enumerate(model.blocks):
+            # the fused MLP of block i can write norm1 of block i + 1 (emit_mvit.emit_mlp_fused)
+            blk.__dict__["_pv_next_block"] = model.blocks[i + 1] if i + 1 < len(model.blocks) else None
             blk.convert(None, session=sess, input_ref=cur, dtype=dtype)
             sess.release(cur)
             cur = blk._out_ref

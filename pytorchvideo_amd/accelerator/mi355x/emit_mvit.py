@@ -472,6 +472,26 @@ def can_fuse_mlp(sess, blk, x1):
     return L.lib().pv_mlp_rows_supported(C.byref(d)) == 1
 
 
+def _next_norm1_standalone(sess, nxt, y):
+    """Will the NEXT MultiScaleBlock evaluate its norm1 as a LayerNorm launch of its own over `y` (this block's output)?
+    Mirrors the first lines of emit_multiscale_block: not when norm1 is fused into the q|k|v projection."""
+    if nxt is None or not tuning.get("fuse_next_norm") or sess.pv_dtype != L.PV_BF16:
+        return False
+    n1 = getattr(nxt, "norm1", None)
+    if not isinstance(n1, nn.LayerNorm) or n1.weight is None or n1.bias is None or tuple(n1.normalized_shape) != (y.C,):
+        return False
+    if y.C % 32 or y.bs != y.voxels * y.ld:
+        return False
+    widen = nxt.dim != nxt.dim_out
+    if not nxt.attn.pool_first and not (nxt.dim_mul_in_att and widen):
+        try:
+            if can_fuse_ln_linear(sess, n1, _qkv_linear(nxt.attn), y):
+                return False
+        except E.Unsupported:
+            return False
+    return True
+
+
 def emit_mlp_fused(sess, blk, x1):
     """Second half of MultiScaleBlock.forward (layers/attention.py:750-757, Mlp.forward :102-114).  With a LayerNorm
     norm2 and an unchanged width the kernel normalises the fp32 stream itself and uses it as the residual (one read);
@@ -486,16 +506,26 @@ def emit_mlp_fused(sess, blk, x1):
     y.thw, y.has_cls = x1.thw, x1.has_cls
     M = x1.B * x1.voxels
     f = dict(w12=w12, y=y.ptr, b2=sess.add_weight(b2), M=M, C=Cin, H=H, Cout=Cout, ldy=y.ld, act=act, dtype=L.PV_BF16,
-             residual=None, ln_gamma=None, ln_beta=None, ln_eps=0.0, ldr=0)
+             residual=None, ln_gamma=None, ln_beta=None, ln_eps=0.0, ldr=0, yn=None, nn_gamma=None, nn_beta=None, ldyn=0, nn_eps=0.0)
+    nxt = blk.__dict__.get("_pv_next_block")
+    if _next_norm1_standalone(sess, nxt, y):
+        # norm1 of the NEXT block from the rows this kernel still holds in registers (round 4): the next block finds the
+        # bf16 operand on its input (`prenorm`) and emits no LayerNorm launch
+        yn = sess.alloc_act(y.B, 1, 1, y.voxels, Cout)
+        yn.thw, yn.has_cls = y.thw, y.has_cls
+        f.update(yn=yn.ptr, ldyn=yn.ld, nn_gamma=sess.add_weight(nxt.norm1.weight.detach().float()),
+                 nn_beta=sess.add_weight(nxt.norm1.bias.detach().float()), nn_eps=float(nxt.norm1.eps))
+        y.prenorm = (yn, nxt.norm1)
     in_kernel_ln = isinstance(blk.norm2, nn.LayerNorm) and not ((not blk.dim_mul_in_att) and widen) and Cin == Cout \
         and blk.norm2.weight is not None and blk.norm2.bias is not None and tuple(blk.norm2.normalized_shape) == (Cin,)
     flops = 2 * M * H * (Cin + Cout)
     wbytes = 2 * H * (Cin + Cout)
+    nn_tag, nn_bytes = (" +norm1'", 2 * M * pad8(Cout)) if f["yn"] is not None else ("", 0)
     if in_kernel_ln:
         f.update(x=x1.ptr, ldx=x1.ld, ln_gamma=sess.add_weight(blk.norm2.weight.detach().float()),
                  ln_beta=sess.add_weight(blk.norm2.bias.detach().float()), ln_eps=float(blk.norm2.eps))
-        sess.add_op(L.OP_MLP_ROWS, f, label="mlp.fused|%dx%d c%d->%d->%d ln" % (x1.B, x1.voxels, Cin, H, Cout),
-                    alg_bytes=4 * M * (pad8(Cin) + pad8(Cout)) + wbytes, flops=flops)
+        sess.add_op(L.OP_MLP_ROWS, f, label="mlp.fused|%dx%d c%d->%d->%d ln%s" % (x1.B, x1.voxels, Cin, H, Cout, nn_tag),
+                    alg_bytes=4 * M * (pad8(Cin) + pad8(Cout)) + wbytes + nn_bytes, flops=flops)
         return y
     xn2 = emit_block_norm(sess, blk.norm2, x1, label="norm2")
     if (not blk.dim_mul_in_att) and widen:
@@ -503,8 +533,8 @@ def emit_mlp_fused(sess, blk, x1):
     else:
         res2 = x1
     f.update(x=xn2.ptr, ldx=xn2.ld, residual=res2.ptr, ldr=res2.ld)
-    sess.add_op(L.OP_MLP_ROWS, f, label="mlp.fused|%dx%d c%d->%d->%d" % (x1.B, x1.voxels, Cin, H, Cout),
-                alg_bytes=2 * M * pad8(Cin) + 8 * M * pad8(Cout) + wbytes, flops=flops)
+    sess.add_op(L.OP_MLP_ROWS, f, label="mlp.fused|%dx%d c%d->%d->%d%s" % (x1.B, x1.voxels, Cin, H, Cout, nn_tag),
+                alg_bytes=2 * M * pad8(Cin) + 8 * M * pad8(Cout) + wbytes + nn_bytes, flops=flops)
     sess.release(xn2)
     if res2 is not x1:
         sess.release(res2)
@@ -607,7 +637,14 @@ def emit_multiscale_block(sess, blk, x):
         if can_fuse_ln_linear(sess, blk.norm1, lin, x):
             # norm1 has no other consumer: LayerNorm + q|k|v projection in one launch, the bf16 operand tensor is never written
             qkv = emit_ln_linear(sess, blk.norm1, lin, x, label="attn.qkv")
-    if qkv is None:
+    pre = getattr(x, "prenorm", None)        # norm1(x) already written by the previous block's fused MLP (emit_mlp_fused)
+    if pre is not None:
+        x.prenorm = None
+        if qkv is None and pre[1] is blk.norm1:
+            xn = pre[0]
+        else:
+            sess.release(pre[0])
+    if qkv is None and xn is None:
         xn = emit_block_norm(sess, blk.norm1, x, label="norm1")
     skip_src = x
     if blk.dim_mul_in_att and widen:

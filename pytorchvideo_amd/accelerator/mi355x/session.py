@@ -48,12 +48,13 @@ class TRef:
     their (t,h,w) grid and cls-prefix separately."""
 
     __slots__ = ("off", "B", "T", "H", "W", "C", "ld", "bs", "itemsize", "nbytes", "owned", "f32",
-                 "thw", "has_cls")
+                 "thw", "has_cls", "prenorm")
 
     def __init__(self, off, B, T, H, W, C, ld, bs, itemsize, nbytes, owned=True, f32=False):
         self.off, self.B, self.T, self.H, self.W, self.C = off, B, T, H, W, C
         self.ld, self.bs, self.itemsize, self.nbytes, self.owned, self.f32 = ld, bs, itemsize, nbytes, owned, f32
         self.thw, self.has_cls = None, False
+        self.prenorm = None     # (TRef, norm module): LayerNorm of this stream already written by its producer (emit_mvit)
 
     @property
     def ptr(self):

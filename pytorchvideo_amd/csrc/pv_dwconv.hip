@@ -184,13 +184,15 @@ __global__ __launch_bounds__(kThreads) void dwconv_kernel(const pv_dwconv3d_desc
     for (int c = tid; c < c_p; c += kThreads) {
       float s = 0.f;
       for (int gg = 0; gg < gpb; ++gg) s += s_red[gg * c_p + c];
-      d.psum[((long)b * gridDim.x + blockIdx.x) * c_p + c] = s;
+      float* dst = d.psum + ((long)b * gridDim.x + blockIdx.x) * c_p + c;
+      if (d.se_gate != nullptr) pv_publish_f32(dst, s);     // read by another workgroup of this launch: write-through store
+      else *dst = s;
     }
     if (d.se_gate != nullptr) {   // squeeze-excitation gate in this launch: the clip's last workgroup computes it
       int* s_flag = reinterpret_cast<int*>(s_red + gpb * c_p);      // (geom() reserves kSeScratch floats behind s_red)
-      if (pv_last_workgroup(d.se_count + b, gridDim.x, s_flag, tid))
-        pv_se_gate_clip(d.psum + (long)b * gridDim.x * c_p, (int)gridDim.x, d.C, c_p, d.se_cr, d.se_inv_count, d.se_w1, d.se_b1,
-                        d.se_w2, d.se_b2, d.se_gate + (long)b * c_p, s_red + gpb * c_p + 32, tid, kThreads);
+      if (pv_last_ticket_block(d.se_count + b, gridDim.x, s_flag, tid))
+        pv_se_gate_clip<false>(d.psum + (long)b * gridDim.x * c_p, (int)gridDim.x, d.C, c_p, d.se_cr, d.se_inv_count, d.se_w1, d.se_b1,
+                               d.se_w2, d.se_b2, d.se_gate + (long)b * c_p, s_red + gpb * c_p + 32, tid, kThreads);
     }
   }
 }
@@ -437,13 +439,16 @@ __global__ __launch_bounds__(kPlaneThreads) void dw3_plane_kernel(const pv_dwcon
       float a = 0.f;
 #pragma unroll
       for (int rr = 0; rr < kPR; ++rr) a += s_ps[rr][tid];
-      d.psum[((long)b * ntiles + tile_id) * c_p + cbase + tid] = a;
+      float* dst = d.psum + ((long)b * ntiles + tile_id) * c_p + cbase + tid;
+      if (d.se_gate != nullptr) pv_publish_f32(dst, a);     // read by another workgroup of this launch: write-through store
+      else *dst = a;
     }
-    if (d.se_gate != nullptr) {   // squeeze-excitation gate in this launch: the clip's last workgroup computes it
-      // (the plane buffers are free now: scratch for the mean / hidden vectors; every wave has passed the last plane barrier)
-      if (pv_last_workgroup(d.se_count + b, (unsigned)(ntiles * ngroups), reinterpret_cast<int*>(&s_ps[0][0]), tid))
-        pv_se_gate_clip(d.psum + (long)b * ntiles * c_p, ntiles, d.C, c_p, d.se_cr, d.se_inv_count, d.se_w1, d.se_b1, d.se_w2,
-                        d.se_b2, d.se_gate + (long)b * c_p, reinterpret_cast<float*>(&s_in[0][0][0]), tid, kPlaneThreads);
+    if (d.se_gate != nullptr && tid < 64) {   // squeeze-excitation gate in this launch (wave 0 made the stores above; wave-uniform)
+      // the clip's last workgroup computes it, wave 0 on its own: the plane buffers are free (every wave has passed the last
+      // plane barrier) and serve as scratch for the mean / hidden vectors
+      if (pv_last_ticket_wave(d.se_count + b, (unsigned)(ntiles * ngroups), lane))
+        pv_se_gate_clip<true>(d.psum + (long)b * ntiles * c_p, ntiles, d.C, c_p, d.se_cr, d.se_inv_count, d.se_w1, d.se_b1, d.se_w2,
+                              d.se_b2, d.se_gate + (long)b * c_p, reinterpret_cast<float*>(&s_in[0][0][0]), tid, 64);
     }
   }
 }

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
   // THREE stage buffers: the LDS-DMA of block hb + 2 is issued while block hb is multiplied.  With two (prefetch distance
   // one block) the last pieces of a block are issued ~100 cycles before the wait at the top of the next iteration and their
   // whole L2 latency (~1.1 us) is exposed: measured 2.6 us per hidden block for 1.1 us of MFMA + GELU work.
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * G::STAGE + NOB * 128];   // + b2 (LayerNorm mode: read in the epilogue)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * G::STAGE + 3 * NOB * 128];   // + b2 (LayerNorm mode: read in the epilogue) + gamma | beta of the NEXT block's norm1 (d.yn)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,6 +98,13 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
   };
   stage(0, 0);
   stage(1, 1);      // (H = 32: block 1 is the padding block)
+
+  // gamma | beta of the next block's norm1 -> LDS (read in the epilogue between global stores, like b2 below)
+  if (d.yn != nullptr && tid < NOB * 16) {
+    const int k = tid < NOB * 8 ? tid : tid - NOB * 8;
+    reinterpret_cast<f32x4*>(smem + 3 * G::STAGE + NOB * 128)[tid] =
+        reinterpret_cast<const f32x4*>(tid < NOB * 8 ? d.nn_gamma : d.nn_beta)[k];
+  }
 
   // ---- prologue: operand fragments and accumulator initialisation --------------------------------------------
   bf16x8 bx[KS];
@@ -399,6 +406,56 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
       }
     }
   }
+  // ---- norm1 of the NEXT MultiScaleBlock (layers/attention.py:729-737) on the rows this wave still holds: the bf16 GEMM
+  //      operand the next block's q|k|v projection reads, instead of a LayerNorm launch that reads the stream back (round 4).
+  //      A row's Cout values sit in two lanes (l, l + 32): in-lane sums + one exchange; two passes (mean, then centred squares).
+  if (d.yn != nullptr) {      // wave-uniform
+    float s1 = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+      if constexpr (LN) {
+        const f32x4* c4 = reinterpret_cast<const f32x4*>(smem + 3 * G::STAGE) + 8 * ob + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 cc = c4[g];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Y[ob][4 * g + e] += cc[e];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s1 += Y[ob][r];
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    const float inv_c = 1.0f / (float)(32 * NOB);
+    const float mean = s1 * inv_c;
+    float s2 = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float t = Y[ob][r] - mean; s2 += t * t; }
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = rsqrtf(s2 * inv_c + d.nn_eps);
+    if (ok) {
+      bf16_t* nr = static_cast<bf16_t*>(d.yn) + m * d.ldyn + 16 * hi;
+      const f32x4* gam = reinterpret_cast<const f32x4*>(smem + 3 * G::STAGE + NOB * 128);
+      const f32x4* bet = gam + NOB * 8;
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 gg = gam[8 * ob + 4 * hi + g], bb = bet[8 * ob + 4 * hi + g];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = (Y[ob][4 * g + e] - mean) * rstd * gg[e] + bb[e];
+            if (g < 2) o0[4 * g + e] = (bf16_t)v; else o1[4 * (g - 2) + e] = (bf16_t)v;
+          }
+        }
+        *reinterpret_cast<bf16x8*>(nr + 32 * ob) = o0;
+        *reinterpret_cast<bf16x8*>(nr + 32 * ob + 8) = o1;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -626,6 +683,7 @@ int check(const pv_mlp_desc& d) {
   if (ln && (d.ln_beta == nullptr || d.b2 == nullptr || d.C != d.Cout || d.residual != nullptr)) return PV_ERR_INVALID;
   if (d.ldx < d.C || d.ldx % (ln ? 4 : 8) || d.ldy < d.Cout || d.ldy % 4) return PV_ERR_INVALID;
   if (d.residual && (d.ldr < d.Cout || d.ldr % 4)) return PV_ERR_INVALID;
+  if (d.yn && (!d.nn_gamma || !d.nn_beta || d.ldyn < d.Cout || d.ldyn % 8)) return PV_ERR_INVALID;
   return PV_OK;
 }
 

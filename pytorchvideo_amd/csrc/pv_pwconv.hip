@@ -459,14 +459,6 @@ int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s) {
     return (size_t)nt * 16 * (ksteps * 32 + 8) * 2 + (size_t)(d.x2 ? 3 : 2) * nt * 16 * 4 + (d.a_gate ? (size_t)4 * 2 * d.cin * 4 : 0);
   };
   size_t lds = lds_of(NT);
-  if (lds > 96 * 1024 && NT == 8 && ksteps == 14 && !d.x2 && pv_tune("pw_k14_nt4", 1)) {
-    // X3D res5 conv_c (432 -> 192) with the squeeze-excitation operand transform: a 128-channel weight slab + the gate rows
-    // do not fit beside a second workgroup, and the LDS-DMA GEMM cannot transform its operand -- round 3 left these four
-    // launches on the generic register-staged kernel (38 us against 18 us ungated).  Three 64-channel N-splits instead:
-    // 72 KB per workgroup, two per CU; the splits of a voxel chunk are consecutive workgroups of one XCD (L2 re-reads).
-    lds = lds_of(4);
-    if (lds <= 96 * 1024) return launch_pw<4, 1>(d, ksteps, lds, s);
-  }
   if (lds > 96 * 1024) return PV_ERR_UNSUPPORTED;
   if (NT == 2) return launch_pw<2, 2>(d, ksteps, lds, s);
   if (NT == 4) return launch_pw<4, 2>(d, ksteps, lds, s);

@@ -1094,6 +1094,22 @@ def test_fused_mlp_rows(M, Cin, H, Cout, ln, res):
     d.y = y2.data_ptr()
     call("pv_mlp_rows", d)
     assert torch.equal(y, y2)                       # no atomics, fixed order: bitwise reproducible
+    # round 4: norm1 of the NEXT block written from the rows the kernel still holds (d.yn): LayerNorm of the fp32 result as
+    # a bf16 operand, against torch on the kernel's own y; y itself unchanged bit for bit; row stride wider than Cout
+    ng, nb_ = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.2).cuda()
+    ldn = Cout + 8
+    yn = torch.full((M, ldn), 5.0, dtype=torch.bfloat16, device="cuda")
+    y3 = torch.zeros_like(y)
+    d.y, d.yn, d.nn_gamma, d.nn_beta, d.ldyn, d.nn_eps = y3.data_ptr(), yn.data_ptr(), ng.data_ptr(), nb_.data_ptr(), ldn, 1e-6
+    call("pv_mlp_rows", d)
+    assert torch.equal(y3, y)
+    want_n = F.layer_norm(y3, (Cout,), ng, nb_, 1e-6)
+    assert rel_err(yn[:, :Cout], want_n) <= 1e-2
+    assert (yn[:, :Cout].float() - want_n).abs().max().item() <= 2.0 ** -7 * want_n.abs().max().item()   # one bf16 rounding
+    assert torch.all(yn[:, Cout:] == 5.0)           # nothing written past the row
+    d.ldyn = Cout - 8
+    assert L.lib().pv_mlp_rows(C.byref(d), None) < 0      # inconsistent descriptor: rejected
+    d.yn = None
     # unsupported widths are declined, inconsistent descriptors rejected
     d.C = 768
     assert L.lib().pv_mlp_rows_supported(C.byref(d)) == 0
