@@ -491,6 +491,12 @@ typedef struct pv_ln_linear_desc {
   int32_t act;
   int32_t dtype;         /* PV_BF16 */
   float ln_eps;
+  /* Residual mode (round 4): residual != NULL (and ln_gamma == ln_beta == NULL, act = none) ->
+   *     y[m][:] (fp32 [M][ldy]) = residual[m][:] (fp32 [M][ldr]) + b + W . x[m][:],   x a bf16 operand tensor [M][ldx]
+   * -- MultiScaleAttention's output projection with the block's residual join (layers/attention.py:541-544,745-749) where
+   * the tiled GEMM is latency-bound; same `wb` image.  pv_ln_linear_rows_supported: (C, N) = (384, 384) or (192, 192). */
+  const float* residual;
+  int32_t ldr;
 } pv_ln_linear_desc;
 int pv_ln_linear_rows(const pv_ln_linear_desc* d, pv_stream_t stream);
 int pv_ln_linear_rows_supported(const pv_ln_linear_desc* d);

@@ -109,7 +109,7 @@ MlpDesc = _struct("MlpDesc", [
 
 LnLinearDesc = _struct("LnLinearDesc", [
     ("x", _p), ("wb", _p), ("y", _p), ("ln_gamma", _p), ("ln_beta", _p), ("M", _i64)]
-    + _ints("C", "N", "ldx", "ldy", "act", "dtype") + [("ln_eps", _f32)])
+    + _ints("C", "N", "ldx", "ldy", "act", "dtype") + [("ln_eps", _f32), ("residual", _p)] + _ints("ldr"))
 
 GatherSrc = _struct("GatherSrc", [("ptr", _p), ("row_bytes", C.c_size_t), ("row_pitch", C.c_size_t), ("rows", _i64)])
 

@@ -625,6 +625,136 @@ __global__ __launch_bounds__(256, MINW) void ln_linear_rows_kernel(const pv_ln_l
   __builtin_amdgcn_s_waitcnt(vm(0));        // the padding block's LDS-DMA must not outlive the workgroup
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Linear + residual on token rows:  y[m][:] (fp32) = R[m][:] + b + W . x[m][:],  x a bf16 operand tensor -- the output
+// projection of MultiScaleAttention with the block's residual join (layers/attention.py:541-544, :745-749) for the widths
+// where the 128 x 128-tile GEMM is latency-bound (K = N = 384: six K-steps per tile, 588 tiles on 512 slots: 31 us for
+// 7.4 GFLOP).  Same row-resident mapping as ln_linear_rows_kernel: the wave's 32 rows are MFMA B operands in registers
+// for the whole kernel, W streams through the three-stage LDS ring one 32-channel output block at a time.  The residual
+// rows are loaded into registers BEFORE the loop (16 fp32 per lane and output block) and are the C operand of each block's
+// first MFMA, so the loop issues no load the compiler would wait for behind the LDS-DMA stream; the output-block loop is
+// fully unrolled (the residual array must be indexed statically).  196 workgroups of 128 rows for MViT-B's 25 096 tokens:
+// one round.
+template <int KS, int NOB>
+__global__ __launch_bounds__(256, 1) void linear_res_rows_kernel(const pv_ln_linear_desc d) {
+  constexpr int STAGE = KS * 1024 + kB1Bytes;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long m = (long)blockIdx.x * 128 + wave * 32 + l31;
+  const bool ok = m < d.M;
+  const long mm = ok ? m : 0;
+  constexpr auto vm = [](int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); };
+
+  const unsigned char* wsrc = static_cast<const unsigned char*>(d.wb);
+  auto stage = [&](int nb, int buf) {
+    const unsigned char* src = wsrc + (long)nb * STAGE;
+    unsigned char* dst = smem + buf * STAGE;
+#pragma unroll
+    for (int p0 = 0; p0 < KS; p0 += 4) {
+      const int p = p0 + wave < KS ? p0 + wave : KS - 1;
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + p * 1024 + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
+    }
+    if (wave == (KS & 3))
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + KS * 1024 + lane * 4), (lptr_t)(dst + KS * 1024), 4, 0, 0);
+  };
+  stage(0, 0);
+  stage(1, 1);
+
+  bf16x8 bx[KS];
+  {
+    const bf16_t* xr = static_cast<const bf16_t*>(d.x) + mm * d.ldx + 16 * hi;
+#pragma unroll
+    for (int q = 0; q < KS / 2; ++q) {
+      bx[2 * q] = *reinterpret_cast<const bf16x8*>(xr + 32 * q);
+      bx[2 * q + 1] = *reinterpret_cast<const bf16x8*>(xr + 32 * q + 8);
+    }
+  }
+  f32x16 R[NOB];
+  {
+    const float* rr = d.residual + mm * d.ldr + 16 * hi;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+      const f32x4* p4 = reinterpret_cast<const f32x4*>(rr + 32 * ob);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = p4[g];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) R[ob][4 * g + e] = v[e];
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(vm(0));        // operands, residual rows and the first two weight blocks: nothing is in flight at the loop
+  float* yr = static_cast<float*>(d.y) + m * d.ldy + 16 * hi;
+  const bool wave_stores = __builtin_amdgcn_ballot_w64(ok) != 0ul;     // see ln_linear_rows_kernel
+  const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_offset(smem));
+  constexpr int PF = KS < 8 ? KS : 8;
+  constexpr int NPW = (KS + 3) / 4;
+  const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nb = 0; nb < NOB; ++nb) {
+    // Issue order of this wave's vector-memory operations: ... DMA(nb), stores(nb - 2), DMA(nb + 1), stores(nb - 1); four
+    // 16-byte stores per block.  Block nb has landed once at most the operations issued after its pieces are in flight.
+    {
+      const int dma_next = (wave == (KS & 3)) ? NPW + 1 : NPW;
+      const int st = wave_stores ? 4 : 0;
+      const int allow = dma_next + (nb >= 1 ? st : 0) + (nb >= 2 ? st : 0);
+      switch (allow - NPW) {          // (s_waitcnt takes an immediate)
+        case 0: __builtin_amdgcn_s_waitcnt(vm(NPW)); break;
+        case 1: __builtin_amdgcn_s_waitcnt(vm(NPW + 1)); break;
+        case 4: __builtin_amdgcn_s_waitcnt(vm(NPW + 4)); break;
+        case 5: __builtin_amdgcn_s_waitcnt(vm(NPW + 5)); break;
+        case 8: __builtin_amdgcn_s_waitcnt(vm(NPW + 8)); break;
+        default: __builtin_amdgcn_s_waitcnt(vm(NPW + 9)); break;
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    const int cur = nb % 3, nxt = (nb + 2) % 3;      // (compile-time: the loop is unrolled)
+    const unsigned char* nsrc = wsrc + (long)(nb + 2) * STAGE;      // (two blocks of padding behind the last: no branch)
+    const unsigned ndst_lds = smem_lds + nxt * STAGE;
+    const unsigned char* ws = smem + cur * STAGE + lane * 16;
+    const float* bs = reinterpret_cast<const float*>(smem + cur * STAGE + KS * 1024) + 16 * hi;
+    bf16x8 ring[PF];
+#pragma unroll
+    for (int f = 0; f < PF; ++f) ring[f] = *reinterpret_cast<const bf16x8*>(ws + f * 1024);
+    f32x4 bb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bb[g] = *reinterpret_cast<const f32x4*>(bs + 4 * g);
+    f32x16 D0 = R[nb], D1 = kZero16;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < KS; ++f) {
+      const bf16x8 afrag = ring[f % PF];
+      if (f + PF < KS) ring[f % PF] = *reinterpret_cast<const bf16x8*>(ws + (f + PF) * 1024);
+      if (f & 1) D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[f], D1, 0, 0, 0);
+      else D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[f], D0, 0, 0, 0);
+      if (f % (KS / NPW) == 0 && f / (KS / NPW) < NPW) {
+        const int pc = 4 * (f / (KS / NPW)) + wave;
+        const int pq = (KS % 4 == 0 || pc < KS) ? pc : KS - 1;
+        dma16_asm(nsrc + pq * 1024 + lane * 16, ndst_lds + pq * 1024);
+      }
+      if (f == KS - 1 && wave == (KS & 3)) dma4_asm(nsrc + KS * 1024 + lane * 4, ndst_lds + KS * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ok) {
+      f32x4* p4 = reinterpret_cast<f32x4*>(yr + 32 * nb);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        p4[g] = f32x4{D0[4 * g] + D1[4 * g] + bb[g][0], D0[4 * g + 1] + D1[4 * g + 1] + bb[g][1],
+                      D0[4 * g + 2] + D1[4 * g + 2] + bb[g][2], D0[4 * g + 3] + D1[4 * g + 3] + bb[g][3]};
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(vm(0));        // the padding block's LDS-DMA must not outlive the workgroup
+}
+
+template <int KS, int NOB> int launch_linear_res(const pv_ln_linear_desc& d, hipStream_t s) {
+  PV_LAUNCH((linear_res_rows_kernel<KS, NOB>), dim3((unsigned)pv_ceil_div(d.M, 128)), dim3(256), 0, s, d);
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
 template <int KS, int MINW> int launch_ln_linear(const pv_ln_linear_desc& d, hipStream_t s) {
   PV_LAUNCH((ln_linear_rows_kernel<KS, MINW>), dim3((unsigned)pv_ceil_div(d.M, 128)), dim3(256), 0, s, d);
   PV_LAUNCH_CHECK();
@@ -632,9 +762,15 @@ template <int KS, int MINW> int launch_ln_linear(const pv_ln_linear_desc& d, hip
 }
 
 int check_ln_linear(const pv_ln_linear_desc& d) {
-  if (!d.x || !d.wb || !d.y || !d.ln_gamma || !d.ln_beta || d.M <= 0 || d.M > 0x7fffffffL) return PV_ERR_INVALID;
+  if (!d.x || !d.wb || !d.y || d.M <= 0 || d.M > 0x7fffffffL) return PV_ERR_INVALID;
   if (d.dtype != PV_BF16) return PV_ERR_UNSUPPORTED;
   if (d.C <= 0 || d.C % 32 || d.N <= 0 || d.N % 32) return PV_ERR_UNSUPPORTED;
+  if (d.residual != nullptr) {      // residual mode: bf16 operand in, fp32 stream out, no LayerNorm, no activation
+    if (d.ln_gamma || d.ln_beta || d.act != PV_ACT_NONE) return PV_ERR_INVALID;
+    if (d.ldx < d.C || d.ldx % 8 || d.ldy < d.N || d.ldy % 4 || d.ldr < d.N || d.ldr % 4) return PV_ERR_INVALID;
+    return PV_OK;
+  }
+  if (!d.ln_gamma || !d.ln_beta) return PV_ERR_INVALID;
   if (d.ldx < d.C || d.ldx % 4 || d.ldy < d.N || d.ldy % 8) return PV_ERR_INVALID;
   return PV_OK;
 }
@@ -714,6 +850,7 @@ extern "C" int pv_mlp_rows(const pv_mlp_desc* dp, pv_stream_t stream) {
 
 extern "C" int pv_ln_linear_rows_supported(const pv_ln_linear_desc* d) {
   if (!d || check_ln_linear(*d) != PV_OK) return 0;
+  if (d->residual != nullptr) return (d->C == 384 && d->N == 384) || (d->C == 192 && d->N == 192);
   return d->C == 96 || d->C == 192 || d->C == 384 || d->C == 768;
 }
 
@@ -722,6 +859,11 @@ extern "C" int pv_ln_linear_rows(const pv_ln_linear_desc* dp, pv_stream_t stream
   const int rc = check_ln_linear(*dp);
   if (rc != PV_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dp->residual != nullptr) {
+    if (dp->C == 384 && dp->N == 384) return launch_linear_res<24, 12>(*dp, s);
+    if (dp->C == 192 && dp->N == 192) return launch_linear_res<12, 6>(*dp, s);
+    return PV_ERR_UNSUPPORTED;
+  }
   switch (dp->C) {
     case 96: return launch_ln_linear<6, 2>(*dp, s);
     case 192: return launch_ln_linear<12, 2>(*dp, s);

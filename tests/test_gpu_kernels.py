@@ -1115,6 +1115,56 @@ def test_fused_mlp_rows(M, Cin, H, Cout, ln, res):
     assert L.lib().pv_mlp_rows_supported(C.byref(d)) == 0
 
 
+@pytest.mark.parametrize("M,Cw", [(6274, 384), (25096, 384), (129, 384), (31, 384), (1001, 192), (513, 192)])
+def test_linear_plus_residual_on_token_rows(M, Cw):
+    """pv_ln_linear_rows, residual mode (round 4): y (fp32) = residual + b + W . x for a bf16 operand x -- the attention output
+    projection with the block's residual join (layers/attention.py:541-544,745-749) on the row-resident kernel -- against
+    fp32 torch on the same bf16-rounded operands; ragged last tile, a last workgroup whose trailing waves hold no row, row
+    strides wider than the widths; bitwise reproducible."""
+    from pytorchvideo_amd.accelerator.mi355x.emit_mvit import pack_ln_linear_weights
+    g = torch.Generator().manual_seed(178)
+    w = (torch.randn(Cw, Cw, generator=g) * Cw ** -0.5).bfloat16().float()
+    b = torch.randn(Cw, generator=g) * 0.3
+    x = (torch.randn(M, Cw, generator=g) * 1.5).bfloat16()
+    r = torch.randn(M, Cw, generator=g) * 2.0 + 3.0 * torch.randn(M, 1, generator=g)
+    want = r + F.linear(x.float(), w, b)
+    img = pack_ln_linear_weights(w, b).cuda()
+    ldx, ldr, ldy = Cw + 8, Cw + 4, Cw + 12
+    xd = torch.zeros(M, ldx, dtype=torch.bfloat16, device="cuda")
+    xd[:, :Cw] = x.cuda()
+    rd = torch.zeros(M, ldr, device="cuda")
+    rd[:, :Cw] = r.cuda()
+    y = torch.full((M, ldy), 7.0, device="cuda")
+    d = L.LnLinearDesc()
+    d.x, d.wb, d.y, d.residual = xd.data_ptr(), img.data_ptr(), y.data_ptr(), rd.data_ptr()
+    d.M, d.C, d.N, d.ldx, d.ldy, d.ldr, d.act, d.dtype = M, Cw, Cw, ldx, ldy, ldr, L.ACT_NONE, L.PV_BF16
+    assert L.lib().pv_ln_linear_rows_supported(C.byref(d)) == 1
+    call("pv_ln_linear_rows", d)
+    assert rel_err(y[:, :Cw], want) <= 2e-3          # fp32 accumulation of exact bf16 products: only the summation order differs
+    assert torch.all(y[:, Cw:] == 7.0)               # nothing written past the row
+    y2 = torch.zeros_like(y)
+    d.y = y2.data_ptr()
+    call("pv_ln_linear_rows", d)
+    assert torch.equal(y2[:, :Cw], y[:, :Cw])
+    # the tiled GEMM route of the same layer agrees (what the plan used before round 4)
+    c = L.Conv3dDesc()
+    w8 = w.bfloat16().cuda().contiguous()
+    y3 = torch.zeros(M, Cw, device="cuda")
+    bd = b.cuda()
+    c.x, c.w, c.y, c.shift, c.residual = xd.data_ptr(), w8.data_ptr(), y3.data_ptr(), bd.data_ptr(), rd.data_ptr()
+    c.x_bs, c.y_bs, c.r_bs, c.ldx, c.ldy, c.ldr = M * ldx, M * Cw, M * ldr, ldx, Cw, ldr
+    c.B, c.Ti, c.Hi, c.Wi, c.cin, c.To, c.Ho, c.Wo, c.cout = 1, 1, 1, M, Cw, 1, 1, M, Cw
+    c.kt = c.kh = c.kw = c.st = c.sh = c.sw = 1
+    c.act, c.a_act, c.dtype, c.y_f32, c.r_f32 = L.ACT_NONE, L.ACT_NONE, L.PV_BF16, 1, 1
+    call("pv_conv3d", c)
+    assert rel_err(y[:, :Cw], y3) <= 2e-3
+    # descriptors the mode does not take
+    d.act = L.ACT_RELU
+    assert L.lib().pv_ln_linear_rows_supported(C.byref(d)) == 0
+    d.act, d.N = L.ACT_NONE, 2 * Cw
+    assert L.lib().pv_ln_linear_rows_supported(C.byref(d)) == 0
+
+
 @pytest.mark.parametrize("M,Cin,N", [(300, 96, 288), (1001, 192, 576), (6274, 384, 1152), (129, 384, 96), (785 * 2, 768, 2304),
                                      (31, 96, 32)])
 def test_layernorm_fused_into_the_qkv_linear(M, Cin, N):
