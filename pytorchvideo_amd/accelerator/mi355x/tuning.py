@@ -16,7 +16,8 @@ OPTIONS = {
                                         # separate per-head LayerNorm; smaller ones the fused pool + LayerNorm kernel  (emit_mvit)
     "fuse_ln_qkv": True,         # MViT norm1 + the q|k|v Linear as ONE launch (pv_ln_linear_rows)               (emit_mvit)
     "fuse_ln_qkv_max_c": 192,    # ... for token widths up to this (wider / shorter tensors: the LDS-DMA GEMM wins)
-    "fuse_se_gate": True,        # X3D squeeze-excitation gate computed by the last workgroup of the depthwise launch (emit.emit_dwconv)
+    "fuse_se_gate": False,       # X3D squeeze-excitation gate computed by the last workgroup of the depthwise launch (emit.emit_dwconv):
+                                 # correct and tested, but SLOWER than the 15 gate launches it removes (round 4, profiles/r4/dropped/)
     "fuse_next_norm": True,      # MViT: norm1 of block i+1 written by block i's fused MLP from the rows it holds (emit_mvit.emit_mlp_fused)
     "proj_rows": True,           # MViT attention output projection + residual on the row-resident kernel (emit_mvit.emit_linear_residual_rows)
     "proj_rows_max_m": 60000,    # ... for at most this many token rows (MViT-B: the 25 096-row blocks; 100 k+ rows stream at the HBM rate on the GEMM)

@@ -49,6 +49,7 @@ struct GemmGeom {   // per-thread staging geometry of one output tile
   int x_t[4], x_h[4], x_w[4];
   long m0;
   int n0;
+  int rot;          // temporal-tap rotation of this tile (tap_rot kernels), else 0
 };
 
 // Persistent workgroups (two per CU): each walks a strided list of output tiles.  While the last K step
@@ -60,7 +61,7 @@ struct GemmGeom {   // per-thread staging geometry of one output tile
 // sits just above a multiple of the resident workgroups (the second, nearly empty round costs a full tile time).
 template <bool PW, int VT, int ABL = 0>   // ABL: ablation builds for tools/bench_gemm.py (1 no loads, 2 no MFMA, 3 no epilogue)
 __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles,
-                                                                float inv_cin) {
+                                                                float inv_cin, int tap_rot) {
   constexpr int BK = 64;
   constexpr int TILE_ELEMS = 128 * BK;                          // one operand tile (elements)
   constexpr int NJ = TILE_ELEMS * 2 / (kThreads * 16);          // 16-byte items per thread per operand tile (4)
@@ -114,6 +115,20 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
     const int tile_n = tile % tiles_n;
     gg.m0 = (long)(tile / tiles_n) * BMV;
     gg.n0 = tile_n * BN;
+    gg.rot = 0;
+    if constexpr (!PW) {
+      // (kt,1,1) = (3,1,1) convs (SlowFast's temporal conv_a, models/resnet.py:98-105): the tiles that run concurrently on an
+      // XCD lie on different frames of the same clips, and each input frame is the operand of THREE of them (as tap t-1, t,
+      // t+1) at three different moments of their K loops -- by then it has left the XCD's 4 MB L2 (profiles/r4/calib_fetch.md:
+      // L2 fills = 3.0x the input, and the layer runs 1.4-1.6x slower than the plain GEMM with the same K that really reads
+      // 3x the bytes).  Rotating the tap order by the tile's frame index makes every tile read, in loop phase j, the one
+      // frame of its three with index == j (mod 3): the three consumers of a frame fetch it at the same time.
+      if (tap_rot && gg.m0 < M) {
+        const long sp0 = gg.m0 - (long)((unsigned)gg.m0 / (unsigned)S_out) * S_out;
+        const int to0 = (int)((unsigned)sp0 / (unsigned)(d.Ho * d.Wo));
+        gg.rot = (1 + 2 * to0) % 3;      // == (1 - to0) mod 3
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int row = (j * kThreads + tid) / CPR;
@@ -158,7 +173,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
     for (int j = 0; j < NJ; ++j) {
       const int k = k0 + kch[j] * 8;
       const bool kok = k < K;
-      __builtin_amdgcn_global_load_lds((gptr_t)pick(kok && gg.w_off[j] >= 0, Wt + (gg.w_off[j] >= 0 ? gg.w_off[j] : 0) + k),
+      int kw_col = k, tap = 0, tap0 = 0;     // weight column / tap whose operand this chunk carries / tap position in the loop
+      if constexpr (!PW) {
+        tap0 = (int)(((float)k + 0.5f) * inv_cin);
+        tap = tap0 + gg.rot;                 // (rot != 0 only for three taps)
+        tap -= tap >= 3 && gg.rot ? 3 : 0;
+        kw_col = k + (tap - tap0) * d.cin;
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)pick(kok && gg.w_off[j] >= 0, Wt + (gg.w_off[j] >= 0 ? gg.w_off[j] : 0) + kw_col),
                                        (lptr_t)(wb + (j * kThreads + wave * 64) * 8), 16, 0, 0);
       if (j >= NJX) continue;   // the voxel tile has fewer rows than the filter tile in the VT = 1 variant
       bool xok = kok && gg.x_off[j] >= 0;
@@ -166,11 +188,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
       if constexpr (PW) {
         xo += k;
       } else {
-        const int tap = (int)(((float)k + 0.5f) * inv_cin);
         const int tp = s_tap[tap < taps ? tap : 0];
         const int ti = gg.x_t[j] + (tp & 255), hh = gg.x_h[j] + ((tp >> 8) & 255), ww = gg.x_w[j] + (tp >> 16);
         xok = xok && (unsigned)ti < (unsigned)d.Ti && (unsigned)hh < (unsigned)d.Hi && (unsigned)ww < (unsigned)d.Wi;
-        xo += ((long)(ti * d.Hi + hh) * d.Wi + ww) * d.ldx + (k - tap * d.cin);
+        xo += ((long)(ti * d.Hi + hh) * d.Wi + ww) * d.ldx + (k - tap0 * d.cin);
       }
       __builtin_amdgcn_global_load_lds((gptr_t)pick(xok, X + xo), (lptr_t)(xb + (j * kThreads + wave * 64) * 8), 16, 0, 0);
     }
@@ -425,26 +446,29 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   if (total <= 0 || total > 0x7fffffffL || M > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
   if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return PV_ERR_UNSUPPORTED;   // 31-bit buffer offsets
   const float inv_cin = 1.0f / (float)d.cin;
+  // temporal-tap rotation (see geom_of): pure (3,1,1) convs, stride / dilation 1, whole tiles inside one frame
+  const int tap_rot = (!pw && d.kt == 3 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.pt == 1 && d.dil_t <= 1 && d.To >= 3 &&
+                       ((long)d.Ho * d.Wo) % (64 * vt) == 0 && pv_tune("gemm_tap_rot", 1)) ? 1 : 0;
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads);
 #ifdef PV_DEV_ABLATION   // timing builds that skip loads / MFMAs / the epilogue (WRONG results): development variant of the library only
   const int abl = pv_tune("gemm_abl", 0);
   if (abl && vt == 2) {
-    if (abl == 1) { if (pw) PV_LAUNCH((gemm_glds_kernel<true, 2, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-                    else PV_LAUNCH((gemm_glds_kernel<false, 2, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin); }
-    if (abl == 2) { if (pw) PV_LAUNCH((gemm_glds_kernel<true, 2, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-                    else PV_LAUNCH((gemm_glds_kernel<false, 2, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin); }
-    if (abl == 3) { if (pw) PV_LAUNCH((gemm_glds_kernel<true, 2, 3>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-                    else PV_LAUNCH((gemm_glds_kernel<false, 2, 3>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin); }
+    if (abl == 1) { if (pw) PV_LAUNCH((gemm_glds_kernel<true, 2, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin, tap_rot);
+                    else PV_LAUNCH((gemm_glds_kernel<false, 2, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin, tap_rot); }
+    if (abl == 2) { if (pw) PV_LAUNCH((gemm_glds_kernel<true, 2, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin, tap_rot);
+                    else PV_LAUNCH((gemm_glds_kernel<false, 2, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin, tap_rot); }
+    if (abl == 3) { if (pw) PV_LAUNCH((gemm_glds_kernel<true, 2, 3>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin, tap_rot);
+                    else PV_LAUNCH((gemm_glds_kernel<false, 2, 3>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin, tap_rot); }
     PV_LAUNCH_CHECK();
     return PV_OK;
   }
 #endif
   if (vt == 1) {
-    if (pw) PV_LAUNCH((gemm_glds_kernel<true, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-    else PV_LAUNCH((gemm_glds_kernel<false, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+    if (pw) PV_LAUNCH((gemm_glds_kernel<true, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin, tap_rot);
+    else PV_LAUNCH((gemm_glds_kernel<false, 1>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin, tap_rot);
   } else {
-    if (pw) PV_LAUNCH((gemm_glds_kernel<true, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
-    else PV_LAUNCH((gemm_glds_kernel<false, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin);
+    if (pw) PV_LAUNCH((gemm_glds_kernel<true, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin, tap_rot);
+    else PV_LAUNCH((gemm_glds_kernel<false, 2>), grid, block, 0, s, d, tiles_n, (int)total, inv_cin, tap_rot);
   }
   PV_LAUNCH_CHECK();
   return PV_OK;
