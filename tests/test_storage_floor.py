@@ -14,11 +14,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 
 def test_bf16_storage_alone_is_below_1e_2_on_the_trained_like_instance():
     from storage_floor import floors
-    r = floors("x3d_m", "trained_like")
+    r = floors("x3d_m", "trained_like", formats=("bf16",), sensitivity=False)      # (the full record: profiles/r4/storage_floor.json)
     assert 0.1 < r["logit_absmax"] < 100.0
     assert r["bf16_weights_only"] < 8e-3 and r["bf16_storage"] < 8e-3
-    assert r["bf16_self_sensitivity_1ulp"] < 5e-3
-    assert r["fp16_storage"] < 2e-3
 
 
 def test_bf16_storage_alone_exceeds_1e_2_on_the_stress_instance_and_fp16_does_not():

@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
 
 
-def floors(workload, fill="calibrated"):
+def floors(workload, fill="calibrated", formats=("bf16", "fp16"), sensitivity=True):
     from bench import oracle_forward, synth_input
     from oracle import functional as OF
     from oracle.weights import quantize_like_kernels
@@ -36,6 +36,8 @@ def floors(workload, fill="calibrated"):
         want = fn(sd, x)
         out["logit_absmax"] = round(want.abs().max().item(), 4)
         for name, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+            if name not in formats:
+                continue
             sd_b = quantize_like_kernels(sd)
             sd_q = {k: (sd[k].to(dt).float() if sd_b[k] is not sd[k] else sd[k]) for k in sd}
             xq = [t.to(dt).float() for t in x] if isinstance(x, list) else x.to(dt).float()
@@ -47,6 +49,8 @@ def floors(workload, fill="calibrated"):
             # fp32 ulp (x (1 + 1e-7 N(0,1))) BEFORE it is rounded to the format: a few roundings flip, and the random-weight
             # network amplifies them.  An implementation whose fp32 arithmetic differs from the oracle's in the last bit
             # (accumulation order, FMA contraction, exp / sigmoid approximations) cannot agree with it better than this.
+            if not sensitivity:
+                continue
             g = torch.Generator().manual_seed(1)
             OF._STORE = lambda t: (t * (1 + 1e-7 * torch.randn(t.shape, generator=g))).to(dt).float()
             try:
