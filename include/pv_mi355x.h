@@ -520,13 +520,6 @@ int pv_plan_add(pv_plan* p, int op_kind, const void* desc, size_t desc_bytes); /
 int pv_plan_size(const pv_plan* p);
 int pv_plan_launch(pv_plan* p, pv_stream_t stream);                 /* eager replay   */
 int pv_plan_launch_range(pv_plan* p, int first, int last, pv_stream_t stream);
-/* Pathway lanes (round 4): op i runs on the plan's side chain (lane 1) or its main chain (lane 0, the default); a main-chain op
- * with join_before waits for everything recorded on the side chain so far.  In a graph capture (pv_plan_graph_build,
- * pv_joint_build) the side chain is a second stream forked from the main chain at the last join point (or the start), so two
- * independent pathways -- SlowFast's slow and fast stages between two lateral fusions, models/net.py:107-122 -- run side by
- * side; eager launches and the profiler run the ops in plan order on one stream (same kernels, same results).  The caller must
- * not let the two chains share scratch memory between a fork and its join. */
-int pv_plan_set_lane(pv_plan* p, int i, int lane, int join_before);
 int pv_plan_graph_build(pv_plan* p, pv_stream_t stream);           /* capture+instantiate */
 int pv_plan_graph_launch(pv_plan* p, pv_stream_t stream);
 /* `n` independent plans (sub-batches of one forward: pytorchvideo_amd.accelerator.mi355x.conversion.SplitBatchDeployed)

@@ -160,7 +160,6 @@ _SYMBOLS = [
     ("pv_plan_size", C.c_int, [_p]),
     ("pv_plan_launch", C.c_int, [_p, _p]),
     ("pv_plan_launch_range", C.c_int, [_p, C.c_int, C.c_int, _p]),
-    ("pv_plan_set_lane", C.c_int, [_p, C.c_int, C.c_int, C.c_int]),
     ("pv_plan_graph_build", C.c_int, [_p, _p]),
     ("pv_plan_graph_launch", C.c_int, [_p, _p]),
     ("pv_joint_create", _p, []),
@@ -181,7 +180,7 @@ _SYMBOLS = [
     ("pv_forward_gather", C.c_int, [_p, _p, _p, C.POINTER(GatherSrc), C.c_int, _p, _p, _p]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 25
+ABI_VERSION = 24
 
 _lib = None
 

@@ -881,14 +881,6 @@ def out_shape(m, x):
 
 
 def emit_multipathway(sess, mp, xs):
-    try:
-        return _emit_multipathway(sess, mp, xs)
-    except Exception:
-        sess.region_abort()      # (an emitter that gives up must not leave the session inside a lane region)
-        raise
-
-
-def _emit_multipathway(sess, mp, xs):
     """MultiPathWayWithFuse.forward (models/net.py:107-122) with FuseFastToSlow
     (models/slowfast.py:720-729): the lateral conv (7x1x1, temporal stride 4) + BN + ReLU
     writes straight into the channel slice [C_slow, C_slow + 2*beta*C) of a slow-pathway
@@ -909,29 +901,11 @@ def _emit_multipathway(sess, mp, xs):
     else:
         raise Unsupported("fusion %s" % _cls_name(fusion))
 
-    # The pathways' blocks are independent of each other up to the fusion (net.py:111-118 runs them one after the other on
-    # their own inputs): the second pathway goes on the plan's side chain and runs beside the first (pv_plan_set_lane) --
-    # the fast pathway's narrow, latency-shaped kernels beside the slow pathway's GEMMs.  The fusion (or whatever consumes
-    # the outputs next) joins.
-    lanes = tuning.get("pathway_lanes") and len(blocks) == 2 and blocks[0] is not None and blocks[1] is not None \
-        and not sess._in_region
     if fuse_kind == "none":
-        if lanes:
-            sess.region_begin()
-            sess.lane = 1
-            out1 = emit_module(sess, blocks[1], xs[1])
-            sess.lane = 0
-            out0 = emit_module(sess, blocks[0], xs[0])
-            sess.region_end()
-            return [out0, out1], [out0, out1]
         outs = [emit_module(sess, b, x) if b is not None else x for b, x in zip(blocks, xs)]
         return outs, outs
 
-    if lanes:
-        sess.region_begin()
-        sess.lane = 1
     fast = emit_module(sess, blocks[1], xs[1])
-    sess.lane = 0
     conv = fusion.conv_fast_to_slow
     check_conv3d(conv)
     t_s, h_s, w_s, c_s = out_shape(blocks[0], xs[0])
@@ -941,8 +915,6 @@ def _emit_multipathway(sess, mp, xs):
     wide = sess.alloc_act(xs[0].B, t_s, h_s, w_s, c_s + c_f)
     slow_slice = wide.channel_slice(0, c_s)
     emit_module_out(sess, blocks[0], xs[0], slow_slice)
-    if lanes:
-        sess.region_end()       # the lateral conv reads the fast pathway's output: join
     emit_lateral(sess, conv, fast, fusion.norm, act_code(fusion.activation), wide.channel_slice(c_s, c_f))
     return [wide, fast], [slow_slice, fast]
 

@@ -159,12 +159,6 @@ class Session:
         self.weights_t = None
         self._graph_ready = False
         self._desc_keep = []
-        # pathway lanes (pv_plan_set_lane): ops emitted while `lane` == 1 are recorded on the plan's side chain
-        self.lane = 0
-        self._lanes = {}          # op index -> (lane, join_before)
-        self._in_region = False   # between region_begin() and region_end(): buffer releases are deferred
-        self._deferred = []
-        self._join_next = False
 
     # ------------------------------------------------------------------ memory
     def alloc_input(self, B, T, H, W, C):
@@ -186,36 +180,8 @@ class Session:
     def alloc_raw(self, nbytes):
         return Ptr("arena", self._arena.alloc(nbytes))
 
-    def region_begin(self):
-        """Start of a stretch of the plan whose lane-0 and lane-1 ops are independent of each other and may run side by side
-        (SlowFast's two pathways between two lateral fusions).  Until region_end() no released buffer is handed out again:
-        arena reuse assumes that ops run in emission order, which holds inside each lane only."""
-        assert not self._in_region and self.lane == 0
-        self._in_region = True
-
-    def region_end(self):
-        """Join: the next lane-0 op waits for the side chain; the buffers released inside the region become available."""
-        assert self._in_region and self.lane == 0
-        self._in_region = False
-        for ref in self._deferred:
-            self.release(ref)
-        self._deferred = []
-        self._join_next = True
-
-    def region_abort(self):
-        """An emitter gave up inside a region (Unsupported): back to a plain chain."""
-        self.lane = 0
-        if self._in_region:
-            self._in_region = False
-            for ref in self._deferred:
-                self.release(ref)
-            self._deferred = []
-
     def release(self, ref):
         if not self.reuse or ref is None:
-            return
-        if self._in_region:
-            self._deferred.append(ref)
             return
         if isinstance(ref, TRef):
             if ref.owned:
@@ -236,10 +202,6 @@ class Session:
         assert not self.finalized
         self._check_live(fields, label)
         self.ops.append((kind, L.DESC_FOR_OP[kind], fields, label, alg_bytes, flops))
-        join = self._join_next and self.lane == 0
-        if join:
-            self._join_next = False
-        self._lanes[len(self.ops) - 1] = (self.lane, join)
         return len(self.ops) - 1
 
     def _check_live(self, fields, label):
@@ -290,10 +252,7 @@ class Session:
                 else:
                     setattr(d, k, resolve(v))
             self._desc_keep.append(d)
-            idx = L.check(lib.pv_plan_add(self.plan, kind, C.byref(d), C.sizeof(d)), "pv_plan_add(%s)" % label)
-            lane, join = self._lanes.get(idx, (0, False))
-            if lane or join:
-                L.check(lib.pv_plan_set_lane(self.plan, idx, lane, 1 if join else 0), "pv_plan_set_lane(%s)" % label)
+            L.check(lib.pv_plan_add(self.plan, kind, C.byref(d), C.sizeof(d)), "pv_plan_add(%s)" % label)
         self.finalized = True
 
     def check_guards(self):

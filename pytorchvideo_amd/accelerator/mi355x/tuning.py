@@ -22,7 +22,6 @@ OPTIONS = {
     "proj_rows": False,          # MViT attention output projection + residual on the row-resident kernel (emit_mvit.emit_linear_residual_rows):
                                  # correct and tested, 4 % SLOWER on the whole model than the tiled GEMM (round 4, profiles/r4/dropped/)
     "proj_rows_max_m": 60000,    # ... for at most this many token rows (MViT-B: the 25 096-row blocks; 100 k+ rows stream at the HBM rate on the GEMM)
-    "pathway_lanes": True,       # SlowFast: the fast pathway's stage on the plan's side chain, beside the slow pathway's (emit.emit_multipathway)
     "fuse_mlp": True,            # MViT norm2 + fc1 + GELU + fc2 + residual as ONE launch (pv_mlp_rows)  (emit_mvit)
     "arena_guards": 0,           # debug build of the launch plan: every arena buffer gets its own memory (no re-use) followed
                                  # by this many bytes of canary; Session.check_guards() names the buffers a kernel wrote past

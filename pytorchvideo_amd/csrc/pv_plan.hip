@@ -10,7 +10,7 @@
 
 namespace {
 thread_local std::string g_last_error;
-constexpr int kAbiVersion = 25;
+constexpr int kAbiVersion = 24;
 }  // namespace
 
 int pv_set_hip_error(hipError_t e, const char* what) {
@@ -74,8 +74,6 @@ struct pv_plan {
     int kind;
     std::vector<unsigned char> desc;
     std::string kernel;      // symbol of the (last) kernel the op launched; filled by pv_plan_profile
-    int lane = 0;            // 0: the plan's main chain; 1: the side chain (independent pathway, pv_plan_set_lane)
-    bool join_before = false;  // main-chain op that needs everything recorded on the side chain so far
   };
   std::vector<Op> ops;
   hipGraph_t graph = nullptr;
@@ -181,81 +179,6 @@ extern "C" int pv_plan_launch(pv_plan* p, pv_stream_t stream) {
   return pv_plan_launch_range(p, 0, (int)p->ops.size(), stream);
 }
 
-// ---- pathway lanes (round 4) ------------------------------------------------------------------------------------
-// SlowFast's two pathways do not depend on each other between two lateral fusions (models/net.py:107-122: every
-// pathway's block runs on its own input, THEN the fusion), yet a launch plan is one chain of kernels.  Ops may therefore be
-// tagged lane 1 ("side"): in a graph capture they are recorded on a second stream, forked from the main chain at the last
-// join point (or the start) and joined before the first main-chain op marked `join_before` -- the narrow, latency-shaped
-// kernels of the fast pathway then run beside the slow pathway's GEMMs.  Outside a capture (eager launches, the per-op
-// profiler) the ops simply run in plan order on one stream: same kernels, same results.
-extern "C" int pv_plan_set_lane(pv_plan* p, int i, int lane, int join_before) {
-  if (!p || i < 0 || i >= (int)p->ops.size() || lane < 0 || lane > 1) return PV_ERR_INVALID;
-  if (lane != 0 && join_before) return PV_ERR_INVALID;
-  p->ops[i].lane = lane;
-  p->ops[i].join_before = join_before != 0;
-  drop_graph(p);
-  return PV_OK;
-}
-
-namespace {
-struct LaneCapture {            // what a capture with a side chain creates; destroyed AFTER hipStreamEndCapture
-  hipStream_t side = nullptr;
-  std::vector<hipEvent_t> events;
-  ~LaneCapture() {
-    if (side) (void)hipStreamDestroy(side);
-    for (auto e : events) (void)hipEventDestroy(e);
-  }
-  hipError_t fresh(hipEvent_t* e) {
-    const hipError_t r = hipEventCreateWithFlags(e, hipEventDisableTiming);
-    if (r == hipSuccess) events.push_back(*e);
-    return r;
-  }
-};
-
-// record the plan's ops into the capture that is running on `main`
-int capture_ops(pv_plan* p, hipStream_t main, LaneCapture* lc) {
-  bool any_side = false;
-  for (const auto& op : p->ops) any_side = any_side || op.lane != 0;
-  if (!any_side) return pv_plan_launch(p, main);
-  PV_HIP_CHECK(hipStreamCreateWithFlags(&lc->side, hipStreamNonBlocking));
-  hipEvent_t fork = nullptr;
-  PV_HIP_CHECK(lc->fresh(&fork));
-  PV_HIP_CHECK(hipEventRecord(fork, main));           // fork point: the start of the plan
-  bool side_forked = false, side_dirty = false;
-  auto join = [&]() -> hipError_t {
-    if (side_dirty) {
-      hipEvent_t done = nullptr;
-      hipError_t e = lc->fresh(&done);
-      if (e == hipSuccess) e = hipEventRecord(done, lc->side);
-      if (e == hipSuccess) e = hipStreamWaitEvent(main, done, 0);
-      if (e != hipSuccess) return e;
-      side_dirty = false;
-    }
-    hipError_t e = lc->fresh(&fork);                    // the next side ops depend on the main chain up to HERE only
-    if (e == hipSuccess) e = hipEventRecord(fork, main);
-    side_forked = false;
-    return e;
-  };
-  for (auto& op : p->ops) {
-    if (op.lane != 0) {
-      if (!side_forked) {
-        PV_HIP_CHECK(hipStreamWaitEvent(lc->side, fork, 0));
-        side_forked = true;
-      }
-      const int r = run_op(op, lc->side);
-      if (r != PV_OK) return r;
-      side_dirty = true;
-    } else {
-      if (op.join_before) PV_HIP_CHECK(join());
-      const int r = run_op(op, main);
-      if (r != PV_OK) return r;
-    }
-  }
-  if (side_dirty) PV_HIP_CHECK(join());                 // a capture must end with every forked stream joined
-  return PV_OK;
-}
-}  // namespace
-
 extern "C" int pv_plan_graph_build(pv_plan* p, pv_stream_t stream) {
   if (!p) return PV_ERR_INVALID;
   drop_graph(p);
@@ -270,8 +193,7 @@ extern "C" int pv_plan_graph_build(pv_plan* p, pv_stream_t stream) {
     (void)hipStreamDestroy(cs);
     return pv_set_hip_error(e, "hipStreamBeginCapture");
   }
-  LaneCapture lc;
-  const int r = capture_ops(p, cs, &lc);
+  const int r = pv_plan_launch(p, cs);
   hipGraph_t g = nullptr;
   e = hipStreamEndCapture(cs, &g);
   (void)hipStreamDestroy(cs);
@@ -334,11 +256,10 @@ extern "C" int pv_joint_build(pv_joint* j, pv_plan* const* plans, int n) {
   hipError_t e = hipStreamBeginCapture(ss[0], hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) { cleanup(); return pv_set_hip_error(e, "hipStreamBeginCapture"); }
   int r = PV_OK;
-  std::vector<LaneCapture> lanes(n);                      // side chains of the member plans (destroyed after the capture ends)
   hipError_t he = hipEventRecord(ev[0], ss[0]);
   for (int i = 1; i < n && he == hipSuccess; ++i) he = hipStreamWaitEvent(ss[i], ev[0], 0);
   for (int i = n - 1; i >= 0 && he == hipSuccess && r == PV_OK; --i) {
-    r = capture_ops(plans[i], ss[i], &lanes[i]);
+    r = pv_plan_launch(plans[i], ss[i]);
     if (i > 0 && r == PV_OK) he = hipEventRecord(ev[i], ss[i]);
   }
   // join only after the origin stream's own branch is recorded (a wait placed earlier would order that branch

@@ -427,63 +427,3 @@ def test_the_oracles_storage_emulation_routes_pools_by_the_emitters_threshold():
     with OF.storage_emulation(pool_stream_min_elems=123):
         assert OF._POOL_STREAM_MIN_ELEMS == 123
     assert OF._POOL_STREAM_MIN_ELEMS == OF.POOL_STREAM_MIN_ELEMS_DEFAULT
-
-
-def test_slowfast_pathways_are_two_lanes_joined_at_every_fusion_without_sharing_scratch():
-    """Round 4 (pv_plan_set_lane): between two lateral fusions the fast pathway's ops sit on the plan's side chain (lane 1)
-    and the slow pathway's on the main chain; the lateral conv -- and the head's first pool -- join.  Arena reuse assumes
-    emission order, which holds inside a lane only: inside a fork-join region no buffer that an op of one lane reads or
-    writes may overlap a buffer an op of the OTHER lane writes."""
-    from pytorchvideo_amd.models import create_slowfast
-    m = create_slowfast(model_depth=50, model_num_class=7, head_pool_kernel_sizes=((8, 2, 2), (32, 2, 2))).eval()
-    transmute_model(m, "mi355x")
-    sess, cur = Session(dtype=torch.bfloat16), None
-    for i, b in enumerate(m.blocks):
-        b.convert([(2, 3, 8, 64, 64), (2, 3, 32, 64, 64)] if i == 0 else None, session=sess, input_ref=cur)
-        cur = b._out_ref
-    lanes = [sess._lanes[i] for i in range(len(sess.ops))]
-    labels = [o[3].split("|")[0] for o in sess.ops]
-    assert sum(1 for l, _ in lanes if l == 1) > 30 and sum(1 for l, _ in lanes if l == 0) > 30
-    joins = [labels[i] for i, (_, j) in enumerate(lanes) if j]
-    assert joins.count("lateral_fuse") == 4 and len(joins) == 5 and joins[-1].startswith("head.pool")
-    assert all(l == 0 for (l, j) in lanes if j)
-    # every fast-pathway op (8 ... 256 channels wide at beta = 1/8) is on the side chain
-    # regions = maximal stretches between joins; inside one, cross-lane buffers must not overlap
-    def spans(fields):
-        out = []
-        for k, v in fields.items():
-            for p in (v if isinstance(v, (list, tuple)) else (v,)):
-                if hasattr(p, "space") and p.space == "arena":
-                    out.append((k, p.off))
-        return out
-    live = sess._arena        # allocation sizes by offset are not kept after release: compare offsets of WRITTEN buffers
-    region, regions = [], []
-    for i, (lane, join) in enumerate(lanes):
-        if join:
-            regions.append(region)
-            region = []
-        region.append(i)
-    regions.append(region)
-    for reg in regions:
-        written = {0: set(), 1: set()}
-        touched = {0: set(), 1: set()}
-        for i in reg:
-            lane = lanes[i][0]
-            for k, off in spans(sess.ops[i][2]):
-                touched[lane].add(off)
-                if k in ("y", "psum", "gate"):
-                    written[lane].add(off)
-        assert not (written[0] & touched[1]) and not (written[1] & touched[0]), (written, touched)
-    # the knob gives the plain chain back
-    from pytorchvideo_amd.accelerator.mi355x import tuning
-    tuning.OPTIONS["pathway_lanes"] = False
-    try:
-        m2 = create_slowfast(model_depth=50, model_num_class=7, head_pool_kernel_sizes=((8, 2, 2), (32, 2, 2))).eval()
-        transmute_model(m2, "mi355x")
-        s2, c2 = Session(dtype=torch.bfloat16), None
-        for i, b in enumerate(m2.blocks):
-            b.convert([(2, 3, 8, 64, 64), (2, 3, 32, 64, 64)] if i == 0 else None, session=s2, input_ref=c2)
-            c2 = b._out_ref
-        assert all(v == (0, False) for v in s2._lanes.values()) and len(s2.ops) == len(sess.ops)
-    finally:
-        tuning.OPTIONS["pathway_lanes"] = True
