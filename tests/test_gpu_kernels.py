@@ -1179,3 +1179,12 @@ def test_layernorm_fused_into_the_qkv_linear(M, Cin, N):
     d.y = y2.data_ptr()
     call("pv_ln_linear_rows", d)
     assert torch.equal(y, y2)
+    # the two-row-set variant (pv_tune "ln_linear_rs" = 2; narrow widths): the same arithmetic per row, the same bits
+    L.tune(ln_linear_rs=2)
+    try:
+        y3 = torch.full((M, N), 3.0, dtype=torch.bfloat16, device="cuda")
+        d.y = y3.data_ptr()
+        call("pv_ln_linear_rows", d)
+        assert torch.equal(y, y3)
+    finally:
+        L.tune(ln_linear_rs=1)
