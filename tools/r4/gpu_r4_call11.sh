@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 4, GPU call 11: the whole GPU suite, smoke and the default bench line on the round's final HEAD
+OUT=gpurun_out/r4k; mkdir -p $OUT; rm -f $OUT/status.txt
+export PV_PARITY_DUMP=$PWD/$OUT/parity_full.jsonl; rm -f $PV_PARITY_DUMP
+timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/gpu_suite.log 2>&1; echo "gpu_suite rc=$?" >> $OUT/status.txt
+tail -3 $OUT/gpu_suite.log
+timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/status.txt
+tail -4 $OUT/smoke.log
+timeout 900 python bench.py > $OUT/bench_default_line.json 2> $OUT/bench_default.err; echo "bench rc=$?" >> $OUT/status.txt
+python -c "
+import json; d=json.load(open('$OUT/bench_default_line.json')); r=d['roofline']
+print('x3d_m', d['value'], d['ms_per_step'], r['kernel'], r['frac'], r.get('traffic'))
+for k,v in d.get('secondary',{}).items(): print(k, v['value'], v['ms_per_step'], v['roofline']['kernel'], v['roofline']['frac'])
+"
+cat $OUT/status.txt
