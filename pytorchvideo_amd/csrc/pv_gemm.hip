@@ -47,6 +47,7 @@ struct GemmGeom {   // per-thread staging geometry of one output tile
   long w_off[4];    // element offset of the weight row carried by item j, or -1
   long x_off[4];    // PW: element offset of the voxel row, or -1 ; general: clip offset or -1
   int x_t[4], x_h[4], x_w[4];
+  long x_sp[4];     // temporal fast path: element offset of (t*st - pt, h, w) inside the clip (may be negative: masked by x_t)
   long m0;
   int n0;
   int rot;          // temporal-tap rotation of this tile (tap_rot kernels), else 0
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
       // L2 fills = 3.0x the input, and the layer runs 1.4-1.6x slower than the plain GEMM with the same K that really reads
       // 3x the bytes).  Rotating the tap order by the tile's frame index makes every tile read, in loop phase j, the one
       // frame of its three with index == j (mod 3): the three consumers of a frame fetch it at the same time.
-      if (tap_rot && gg.m0 < M) {
+      if ((tap_rot & 1) && gg.m0 < M) {
         const long sp0 = gg.m0 - (long)((unsigned)gg.m0 / (unsigned)S_out) * S_out;
         const int to0 = (int)((unsigned)sp0 / (unsigned)(d.Ho * d.Wo));
         gg.rot = (1 + 2 * to0) % 3;      // == (1 - to0) mod 3
@@ -141,18 +142,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
         const long sp = m - b * S_out;
         if constexpr (PW) {
           gg.x_off[j] = b * d.x_bs + sp * d.ldx;
+          gg.x_sp[j] = 0;
           gg.x_t[j] = gg.x_h[j] = gg.x_w[j] = 0;
         } else {
           const int to = (int)((unsigned)sp / (unsigned)(d.Ho * d.Wo));
           const int r2 = (int)(sp - (long)to * d.Ho * d.Wo);
           const int ho = r2 / d.Wo;
           gg.x_off[j] = b * d.x_bs;
+          gg.x_sp[j] = ((long)((to * d.st - d.pt) * d.Hi + (ho * d.sh - d.ph)) * d.Wi + ((r2 - ho * d.Wo) * d.sw - d.pw)) * d.ldx;
           gg.x_t[j] = to * d.st - d.pt;
           gg.x_h[j] = ho * d.sh - d.ph;
           gg.x_w[j] = (r2 - ho * d.Wo) * d.sw - d.pw;
         }
       } else {
         gg.x_off[j] = -1;
+        gg.x_sp[j] = 0;
         gg.x_t[j] = gg.x_h[j] = gg.x_w[j] = 0;
       }
     }
@@ -169,15 +173,34 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
     bf16_t* wb = smem + buf * 2 * TILE_ELEMS;
     bf16_t* xb = wb + TILE_ELEMS;
     const int k0 = ks * BK;
+    // Temporal fast path ((kt,1,1) convs whose input width is a multiple of the K step: SlowFast's conv_a, the lateral
+    // fusions; flag bit 1): a K step lies inside ONE tap, so the tap, its weight-column shift and its frame offset are
+    // wave-uniform and computed once per step -- the per-chunk tap decoding (a float multiply, an LDS look-up, three bounds
+    // tests and a 64-bit multiply chain) was what kept the (3,1,1) layer 1.3x behind the plain GEMM of the same K
+    // (profiles/r4/calib_fetch_times*.txt: B vs C).
+    const bool tmode = !PW && (tap_rot & 2);
+    int tap0_u = 0, tap_u = 0;
+    long tap_off_u = 0;
+    if (tmode) {
+      tap0_u = (int)(((float)k0 + 0.5f) * inv_cin);
+      tap_u = tap0_u + gg.rot;
+      tap_u -= tap_u >= 3 && gg.rot ? 3 : 0;
+      tap_off_u = (long)(tap_u * (d.dil_t > 1 ? d.dil_t : 1)) * d.Hi * d.Wi * d.ldx;
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int k = k0 + kch[j] * 8;
       const bool kok = k < K;
       int kw_col = k, tap = 0, tap0 = 0;     // weight column / tap whose operand this chunk carries / tap position in the loop
       if constexpr (!PW) {
-        tap0 = (int)(((float)k + 0.5f) * inv_cin);
-        tap = tap0 + gg.rot;                 // (rot != 0 only for three taps)
-        tap -= tap >= 3 && gg.rot ? 3 : 0;
+        if (tmode) {
+          tap0 = tap0_u;
+          tap = tap_u;
+        } else {
+          tap0 = (int)(((float)k + 0.5f) * inv_cin);
+          tap = tap0 + gg.rot;                 // (rot != 0 only for three taps)
+          tap -= tap >= 3 && gg.rot ? 3 : 0;
+        }
         kw_col = k + (tap - tap0) * d.cin;
       }
       __builtin_amdgcn_global_load_lds((gptr_t)pick(kok && gg.w_off[j] >= 0, Wt + (gg.w_off[j] >= 0 ? gg.w_off[j] : 0) + kw_col),
@@ -187,6 +210,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
       long xo = gg.x_off[j] >= 0 ? gg.x_off[j] : 0;
       if constexpr (PW) {
         xo += k;
+      } else if (tmode) {
+        const int ti = gg.x_t[j] + tap * (d.dil_t > 1 ? d.dil_t : 1);
+        xok = xok && (unsigned)ti < (unsigned)d.Ti;
+        xo += gg.x_sp[j] + tap_off_u + (k - tap0 * d.cin);
       } else {
         const int tp = s_tap[tap < taps ? tap : 0];
         const int ti = gg.x_t[j] + (tp & 255), hh = gg.x_h[j] + ((tp >> 8) & 255), ww = gg.x_w[j] + (tp >> 16);
@@ -452,8 +479,13 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return PV_ERR_UNSUPPORTED;   // 31-bit buffer offsets
   const float inv_cin = 1.0f / (float)d.cin;
   // temporal-tap rotation (see geom_of): pure (3,1,1) convs, stride / dilation 1, whole tiles inside one frame
-  const int tap_rot = (!pw && d.kt == 3 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.pt == 1 && d.dil_t <= 1 && d.To >= 3 &&
-                       ((long)d.Ho * d.Wo) % (64 * vt) == 0 && pv_tune("gemm_tap_rot", 1)) ? 1 : 0;
+  int tap_rot = (!pw && d.kt == 3 && d.kh == 1 && d.kw == 1 && d.st == 1 && d.pt == 1 && d.dil_t <= 1 && d.To >= 3 &&
+                 ((long)d.Ho * d.Wo) % (64 * vt) == 0 && pv_tune("gemm_tap_rot", 1)) ? 1 : 0;
+  // flag bit 1: the temporal fast path of stage() -- (kt,1,1) taps, unit spatial stride, no spatial padding, input width a
+  // multiple of the 64-wide K step (a step then lies inside one tap)
+  if (!pw && d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.cin % 64 == 0 && d.kt > 1 &&
+      pv_tune("gemm_tmode", 1))
+    tap_rot |= 2;
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads);
 #ifdef PV_DEV_ABLATION   // timing builds that skip loads / MFMAs / the epilogue (WRONG results): development variant of the library only
   const int abl = pv_tune("gemm_abl", 0);
