@@ -179,13 +179,24 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
     // tests and a 64-bit multiply chain) was what kept the (3,1,1) layer 1.3x behind the plain GEMM of the same K
     // (profiles/r4/calib_fetch_times*.txt: B vs C).
     const bool tmode = !PW && (tap_rot & 2);
-    int tap0_u = 0, tap_u = 0;
+    // ... and its generalisation to any tap shape (flag bit 2, pv_tune "gemm_umode"; round 5: validated through the model
+    // suites, on by default): with the input width a multiple of the K step the tap (dt, dh, dw) of a step is still wave-uniform;
+    // what stays per chunk are the three bounds tests of the row's window position.
+    const bool umode = !PW && (tap_rot & 4);
+    int tap0_u = 0, tap_u = 0, udt = 0, udh = 0, udw = 0;
     long tap_off_u = 0;
     if (tmode) {
       tap0_u = (int)(((float)k0 + 0.5f) * inv_cin);
       tap_u = tap0_u + gg.rot;
       tap_u -= tap_u >= 3 && gg.rot ? 3 : 0;
       tap_off_u = (long)(tap_u * (d.dil_t > 1 ? d.dil_t : 1)) * d.Hi * d.Wi * d.ldx;
+    } else if (umode) {
+      tap0_u = tap_u = (int)(((float)k0 + 0.5f) * inv_cin);
+      const int tp = s_tap[tap_u < taps ? tap_u : 0];
+      udt = tp & 255;
+      udh = (tp >> 8) & 255;
+      udw = tp >> 16;
+      tap_off_u = ((long)(udt * d.Hi + udh) * d.Wi + udw) * d.ldx;
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
       const bool kok = k < K;
       int kw_col = k, tap = 0, tap0 = 0;     // weight column / tap whose operand this chunk carries / tap position in the loop
       if constexpr (!PW) {
-        if (tmode) {
+        if (tmode || umode) {
           tap0 = tap0_u;
           tap = tap_u;
         } else {
@@ -213,6 +224,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(const pv_conv3d_
       } else if (tmode) {
         const int ti = gg.x_t[j] + tap * (d.dil_t > 1 ? d.dil_t : 1);
         xok = xok && (unsigned)ti < (unsigned)d.Ti;
+        xo += gg.x_sp[j] + tap_off_u + (k - tap0 * d.cin);
+      } else if (umode) {
+        const int ti = gg.x_t[j] + udt, hh = gg.x_h[j] + udh, ww = gg.x_w[j] + udw;
+        xok = xok && (unsigned)ti < (unsigned)d.Ti && (unsigned)hh < (unsigned)d.Hi && (unsigned)ww < (unsigned)d.Wi;
         xo += gg.x_sp[j] + tap_off_u + (k - tap0 * d.cin);
       } else {
         const int tp = s_tap[tap < taps ? tap : 0];
@@ -486,6 +501,8 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   if (!pw && d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.ph == 0 && d.pw == 0 && d.cin % 64 == 0 && d.kt > 1 &&
       pv_tune("gemm_tmode", 1))
     tap_rot |= 2;
+  else if (!pw && taps > 1 && d.cin % 64 == 0 && pv_tune("gemm_umode", 1))
+    tap_rot |= 4;
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads);
 #ifdef PV_DEV_ABLATION   // timing builds that skip loads / MFMAs / the epilogue (WRONG results): development variant of the library only
   const int abl = pv_tune("gemm_abl", 0);

@@ -32,6 +32,16 @@ SHAPES = [  # (label, B, T,H,W in, cin, cout, k(t,h,w), s(t,h,w), p)
     ("sf conv_b res4 slow 1x3x3 256->256", 16, 8, 16, 16, 256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("sf conv_b res2 slow 1x3x3 64->64", 16, 8, 64, 64, 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("sf conv_c res2 slow 64->256", 16, 8, 64, 64, 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("sf conv_a res3 slow 512->128", 16, 8, 32, 32, 512, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("sf conv_b res3 slow 1x3x3 128->128", 16, 8, 32, 32, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("sf conv_c res3 slow 128->512", 16, 8, 32, 32, 128, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("sf conv_c res4 slow 256->1024", 16, 8, 16, 16, 256, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("sf conv_a res5 slow 3x1x1 2048->512", 16, 8, 8, 8, 2048, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("sf conv_b res5 slow 1x3x3 512->512", 16, 8, 8, 8, 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("sf conv_c res5 slow 512->2048", 16, 8, 8, 8, 512, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("sf conv_a res4 first 3x1x1 640->256", 16, 8, 32, 32, 640, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("mvit proj b4  M25k  K384 N384", 8, 1, 1, 3137, 384, 384, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("mvit qkv b14  M25k  K768 N2304", 8, 1, 1, 3137, 768, 2304, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("sf stem slow 1x7x7 3->64", 16, 8, 256, 256, 8, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
     ("sf stem fast 5x7x7 3->8", 16, 32, 256, 256, 8, 8, (5, 7, 7), (1, 2, 2), (2, 3, 3)),
     ("x3d stem 1x3x3 3->24", 32, 16, 224, 224, 8, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
