@@ -21,6 +21,7 @@ int pv_pwconv_stream_try(const pv_conv3d_desc& d, hipStream_t s);      // pv_pwc
 int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);  // pv_gemm.hip
 int pv_head_rows_try(const pv_conv3d_desc& d, hipStream_t s);              // pv_headgemm.hip
 int pv_gemm8_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);      // pv_gemm8.hip
+int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);      // pv_gemm9.hip
 int pv_tapstream_try(const pv_conv3d_desc& d, hipStream_t s);           // pv_lateral.hip
 int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s);                 // pv_stem.hip
 int pv_stem_dwt_supported(const pv_conv3d_desc& d);                     // pv_stem.hip
@@ -401,7 +402,9 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
         if (r != PV_ERR_UNSUPPORTED) return r;
       }
       const bool gemm_ok = route == 2 || pw || (cout_p8 >= 64 && d.cin >= 64);
-      int r = gemm_ok ? pv_gemm8_try(d, pw, s) : PV_ERR_UNSUPPORTED;     // large tiles, 4-stage ring: big layers
+      int r = gemm_ok ? pv_gemm9_try(d, pw, s) : PV_ERR_UNSUPPORTED;     // 256 x 256 tiles, eight-phase loop: layers that fill the chip with them
+      if (r != PV_ERR_UNSUPPORTED) return r;
+      r = gemm_ok ? pv_gemm8_try(d, pw, s) : PV_ERR_UNSUPPORTED;         // large tiles, 4-stage ring: big layers
       if (r != PV_ERR_UNSUPPORTED) return r;
       r = gemm_ok ? pv_gemm_glds_try(d, pw, s) : PV_ERR_UNSUPPORTED;
       if (r != PV_ERR_UNSUPPORTED) return r;

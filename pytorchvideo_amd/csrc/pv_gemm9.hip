@@ -1,0 +1,486 @@
+// MFMA-bound dense convolution / linear layer, 256 x 256 tile with an eight-phase main loop (round 5).
+//
+//   out[voxel m][channel n] = act( (sum_k X'[m][k] W[n][k]) * scale[n] + shift[n] + residual[m][n] )
+//   k = tap*cin + c ;  X'[m][k] = x[voxel m shifted by tap][c]  (zero outside the image)
+//
+// Why a third GEMM kernel.  Counters and ablations of the two older ones (pv_gemm.hip: 128 x 128 tile, two LDS buffers,
+// `vmcnt(0)` + barrier per K step; pv_gemm8.hip: 256-wide tiles on a ring of 32-deep stages) say the same thing from two
+// sides: a CU moves 64 bytes per clock from L2 into LDS and multiplies 4096 bf16 FLOP per clock, so a tile needs MORE than
+// 64 FLOP per staged byte -- the 128 x 128 tile has exactly 64 -- and the staged rows must be whole 128-byte lines: a
+// 32-deep stage fetches every line twice, half at a time, through a 32 KB L1 that has long lost the first half (the
+// 256 x 256 x 32 ring measured 960 TFLOP/s on 32768 x 4096 x 4096, a third of the matrix pipe).  This kernel is the
+// structure /opt/skills/guides/cdna_hip_programming.md 5 describes for that regime (T2 + T3 + T4 + T5), rebuilt around
+// the implicit-GEMM staging of this library:
+//   * 256 x 256 x 64 tile, 512 threads = 8 waves as 4 (voxels) x 2 (channels); a wave owns 64 voxels x 128 channels =
+//     8 accumulator blocks of v_mfma_f32_32x32x16_bf16 (weights are the A operand with permuted rows, so a lane's 16
+//     accumulator registers are 16 consecutive channels of one voxel: epilogue in registers, 16-byte stores);
+//   * the K step of 64 is multiplied in FOUR PHASES, one quadrant (64 channels x 32 voxels x K 64 = 8 MFMAs) each, in snake
+//     order (a0,v0) (a0,v1) (a1,v1) (a1,v0): a phase re-reads only the operand half that changed (12 / 4 / 8 / 0
+//     `ds_read_b128`), and -- the point of quadrant phases -- the LDS rows of a K tile are RETIRED progressively: the
+//     channel half a0 and voxel half v0 are last read in phase 0, v1 in phase 1, a1 in phase 2;
+//   * LDS = 2 K tiles x 4 units of 16 KB (channel halves AE / AO, voxel halves BE / BO; 128 rows of one full 128-byte line
+//     each), filled by LDS-DMA, ONE unit (two `global_load_lds_dwordx4` per thread) per phase, each unit as soon as its
+//     rows are two phases dead:  phase 0 -> BO(t+1), phase 1 -> AO(t+1), phase 2 -> AE(t+2), phase 3 -> BE(t+2).  Every
+//     unit is requested five to six phases (>= 2.5 k cycles) before its first read; the wait of each phase is the counted
+//     `vmcnt(8)` (the four youngest units stay in flight across the barriers), never 0;
+//   * the two halves of the workgroup (waves 0-3 / 4-7: one of each per SIMD) run the same stream ONE BARRIER APART: a
+//     phase is  [fragment reads, DMA issue, counted wait] B1 [8 MFMAs at raised priority] B2, so on every SIMD one wave
+//     feeds the matrix pipe while its partner reads LDS and issues loads;
+//   * staging arithmetic per DMA is a 64-bit add and a select: a K step of 64 lies inside ONE tap (the input width is a
+//     multiple of 64), so tap, frame / row / column shift and weight column are wave-uniform scalars; a thread keeps, per
+//     tile, the byte offsets of its 4 + 4 staging rows and a 24-bit window mask per voxel row (which dt / dh / dw land
+//     inside the image); out-of-image taps and the exhausted stream read a 16-byte zero page; M / N tails read a clamped
+//     row whose results are never stored;
+//   * persistent workgroups (one per CU) walk an XCD-aware tile list and the DMA stream runs on ACROSS tiles: the first
+//     six units of the next tile are in flight during the epilogue; the epilogue's stores are counted into the waits of the
+//     K step that follows it (masked stores get an out-of-range buffer offset: every wave issues the same number).
+// LDS swizzle as in the older kernels (chunk ^= (row >> 1) & 7 on the DMA's SOURCE address and on the read: conflict-free
+// `ds_read_b128`, both sides or neither).
+#include <stdlib.h>
+#include "pv_common.h"
+
+__device__ __attribute__((aligned(16))) unsigned int pv_zero_page9[4] = {0u, 0u, 0u, 0u};
+
+namespace {
+
+constexpr int kThreads9 = 512;
+constexpr int BT9 = 256;              // tile edge: voxels and channels
+constexpr int UNIT9 = 128 * 64;       // elements of one staging unit (128 rows x 64 K, 16 KB)
+// LDS (elements): [AE0 | AO0 | AE1 | AO1 | BE0 | BO0 | BE1 | BO1] -- K tile parity P, half h: the channel units at
+// (2 P + h) * UNIT9, the voxel units 4 * UNIT9 further; every fragment read is then one per-lane base register + a 16-bit
+// immediate (the main loop is written once per parity), no address arithmetic and no second set of address registers
+constexpr int LDS9_ELEMS = 8 * UNIT9;   // 128 KB
+__device__ __forceinline__ constexpr int unit_a(int P, int a) { return (2 * P + a) * UNIT9; }
+__device__ __forceinline__ constexpr int unit_b(int P, int v) { return (4 + 2 * P + v) * UNIT9; }
+constexpr int kRegionB9 = 4 * UNIT9 * 2;   // byte offset of the voxel units (folded into the read base: immediates stay < 64 K)
+
+typedef const __attribute__((address_space(1))) void* gptr9_t;
+typedef __attribute__((address_space(3))) void* lptr9_t;
+
+// LDS row -> channel inside a 32-row MFMA tile (accumulator register r of lane-half hi is channel 16*hi + r)
+__device__ __forceinline__ int chi9(int rho) {
+  return (rho & ~31) + 16 * ((rho >> 2) & 1) + 4 * ((rho >> 3) & 3) + (rho & 3);
+}
+
+struct Geom9 {         // per-thread staging rows of one output tile
+  unsigned a_off[4];   // [a*2 + j]  byte offset of (weight row, chunk) in w
+  int b_off[4];        // [v*2 + j]  element offset of (voxel row's window origin, chunk) in x (negative: padding rows)
+  unsigned b_msk[4];   // window mask of the voxel row: bit dt | bit 8 + dh | bit 16 + dw set when that tap is inside
+};
+
+template <bool PW, bool YF32>
+__global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem9_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem9_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int S_out = d.To * d.Ho * d.Wo;
+  const long M = (long)d.B * S_out;
+  const int K = d.kt * d.kh * d.kw * d.cin;
+  const int nk = K >> 6;
+  const int cout_p8 = pv_round_up(d.cout, 8);
+  const int dil_t = d.dil_t > 1 ? d.dil_t : 1, dil_h = d.dil_h > 1 ? d.dil_h : 1, dil_w = d.dil_w > 1 ? d.dil_w : 1;
+  const bf16_t* __restrict__ X = static_cast<const bf16_t*>(d.x);
+  const char* __restrict__ Wb = static_cast<const char*>(d.w);
+  const unsigned long zaddr = (unsigned long)reinterpret_cast<const bf16_t*>(pv_zero_page9);
+
+  // ---- staging rows of this thread (the same for every unit): DMA j covers unit rows 64 j + 8 wave + lane / 8 ----
+  auto tile_origin = [&](int it, long& m0, int& n0) __attribute__((always_inline)) {   // XCD-aware tile order (bijective for any tile count)
+    const int xcd = it & 7, slot = it >> 3;
+    const int qn = total_tiles >> 3, rn = total_tiles & 7;
+    const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+    m0 = (long)(tile / tiles_n) * BT9;
+    n0 = (tile % tiles_n) * BT9;
+  };
+  auto geom_of = [&](int it, Geom9& g) __attribute__((always_inline)) {
+    long m0;
+    int n0;
+    tile_origin(it, m0, n0);
+    const int rho0 = 8 * wave + (lane >> 3);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rho = 64 * j + rho0;
+      const int chunk8 = ((lane & 7) ^ ((rho >> 1) & 7)) * 8;   // K chunk that lands on LDS position lane % 8 of the row
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        int n = n0 + 128 * (rho >> 6) + 64 * a + 32 * ((rho >> 5) & 1) + chi9(rho & 31);
+        n = n < d.cout ? n : d.cout - 1;                    // N tail: a clamped row, zeroed in the epilogue
+        g.a_off[a * 2 + j] = ((unsigned)n * (unsigned)K + (unsigned)chunk8) * 2u;
+      }
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        long m = m0 + 64 * (rho >> 5) + 32 * v + (rho & 31);
+        m = m < M ? m : M - 1;                              // M tail: a clamped row, never stored
+        const unsigned b = (unsigned)m / (unsigned)S_out;
+        const unsigned sp = (unsigned)m - b * (unsigned)S_out;
+        if constexpr (PW) {
+          g.b_off[v * 2 + j] = (int)((long)b * d.x_bs + (long)sp * d.ldx) + chunk8;
+          g.b_msk[v * 2 + j] = 0u;
+        } else {
+          const unsigned to = sp / (unsigned)(d.Ho * d.Wo);
+          const unsigned r2 = sp - to * (unsigned)(d.Ho * d.Wo);
+          const unsigned ho = r2 / (unsigned)d.Wo;
+          const int t0 = (int)to * d.st - d.pt, h0 = (int)ho * d.sh - d.ph, w0 = (int)(r2 - ho * (unsigned)d.Wo) * d.sw - d.pw;
+          g.b_off[v * 2 + j] = (int)((long)b * d.x_bs + ((long)(t0 * d.Hi + h0) * d.Wi + w0) * d.ldx) + chunk8;
+          unsigned msk = 0u;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if (q < d.kt && (unsigned)(t0 + q * dil_t) < (unsigned)d.Ti) msk |= 1u << q;
+            if (q < d.kh && (unsigned)(h0 + q * dil_h) < (unsigned)d.Hi) msk |= 1u << (8 + q);
+            if (q < d.kw && (unsigned)(w0 + q * dil_w) < (unsigned)d.Wi) msk |= 1u << (16 + q);
+          }
+          g.b_msk[v * 2 + j] = msk;
+        }
+      }
+    }
+  };
+
+  // ---- issue side: the DMA stream, K tile by K tile across output tiles (all of this state is wave-uniform) ----
+  Geom9 g;
+  int iss_it = blockIdx.x, iss_ku = 0;
+  bool iss_live = iss_it < total_tiles;
+  int iss_c0 = 0, iss_dt = 0, iss_dh = 0, iss_dw = 0;   // channel offset inside the tap, tap coordinates
+  geom_of(iss_live ? iss_it : 0, g);
+
+  // source selection with bit masks, not `?:` (a select between two pointers becomes two exec-masked DMAs)
+  auto pick = [&](bool ok, unsigned long p) __attribute__((always_inline)) -> gptr9_t {
+    const unsigned long m = 0ul - (unsigned long)ok;
+    return (gptr9_t)((p & m) | (zaddr & ~m));
+  };
+  auto issue_a = [&](int a, int unit) __attribute__((always_inline)) {   // channel half a of the stream's K tile -> LDS unit at element offset `unit`
+    const unsigned kb = (unsigned)iss_ku * 128u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds(pick(iss_live, (unsigned long)(Wb + (g.a_off[a * 2 + j] + kb))),
+                                       (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
+  };
+  auto issue_b = [&](int v, int unit) __attribute__((always_inline)) {   // voxel half v
+    int uni;        // element offset of the K tile's tap + channel block, wave-uniform
+    unsigned sel;   // the bits of b_msk that must be set for this tap
+    if constexpr (PW) {
+      uni = iss_ku * 64;
+      sel = 0u;
+    } else {
+      uni = ((iss_dt * dil_t * d.Hi + iss_dh * dil_h) * d.Wi + iss_dw * dil_w) * d.ldx + iss_c0;
+      sel = (1u << iss_dt) | (1u << (8 + iss_dh)) | (1u << (16 + iss_dw));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = iss_live && (g.b_msk[v * 2 + j] & sel) == sel;
+      __builtin_amdgcn_global_load_lds(pick(ok, (unsigned long)(X + (long)(g.b_off[v * 2 + j] + uni))),
+                                       (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
+    }
+  };
+  auto advance = [&]() __attribute__((always_inline)) {   // next K tile of the stream
+    ++iss_ku;
+    if constexpr (!PW) {
+      iss_c0 += 64;
+      if (iss_c0 == d.cin) {
+        iss_c0 = 0;
+        if (++iss_dw == d.kw) {
+          iss_dw = 0;
+          if (++iss_dh == d.kh) { iss_dh = 0; ++iss_dt; }
+        }
+      }
+    }
+    if (iss_ku == nk) {
+      iss_ku = 0;
+      iss_c0 = iss_dt = iss_dh = iss_dw = 0;
+      iss_it += gridDim.x;
+      iss_live = iss_it < total_tiles;
+      if (iss_live) geom_of(iss_it, g);
+    }
+  };
+
+  // ---- read side: this lane's fragment position inside a unit, as a BYTE offset from the LDS base ----
+  // A rows: wn*64 + ta*32 + (lane & 31) (ta = 1: + 32 rows = + 4096 bytes, same swizzle); B rows: wm*32 + (lane & 31).
+  // K slice s reads chunk (2 s + hi) ^ swz(row) = (hi ^ swz(row)) ^ 2 s: ONE register per operand holds the position of
+  // slice 0, slices 1-3 are that register ^ (s * 32) -- recomputed at every read (an empty asm keeps the compiler from
+  // hoisting the three variants into registers of their own: the kernel sits at the 256-register limit)
+  unsigned rd_a0, rd_b0;
+  {
+    const int ra = (wave & 1) * 64 + (lane & 31), rb = (wave >> 1) * 32 + (lane & 31);
+    const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) unsigned char*)smem9_raw);
+    rd_a0 = lds0 + (unsigned)(ra * 128 + (((lane >> 5) ^ ((ra >> 1) & 7)) << 4));
+    rd_b0 = lds0 + (unsigned)(kRegionB9 + rb * 128 + (((lane >> 5) ^ ((rb >> 1) & 7)) << 4));
+  }
+  typedef const __attribute__((address_space(3))) bf16x8* lfrag9_t;
+#define PV9_RD(BASE, S, BYTES) (*(lfrag9_t)(unsigned long)(((BASE) ^ ((S) * 32u)) + (unsigned)(BYTES)))
+
+  // s_waitcnt simm16 on gfx9: vmcnt = bits [3:0] | [15:14]; expcnt [6:4] "no wait"; lgkmcnt [11:8] = 0
+  constexpr auto vml = [](int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4); };
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr unsigned kOOB = 0x80000000u;
+  __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      d.y, 0, (int)((unsigned)d.B * (unsigned)d.y_bs * (YF32 ? 4u : 2u)), 0x00020000);   // stores per thread per tile: 32 (fp32) / 16
+
+  // ---- prologue: AE BE BO AO of K tile 0, AE BE of K tile 1 ----
+  issue_a(0, unit_a(0, 0));
+  issue_b(0, unit_b(0, 0));
+  issue_b(1, unit_b(0, 1));
+  issue_a(1, unit_a(0, 1));
+  advance();
+  issue_a(0, unit_a(1, 0));
+  issue_b(0, unit_b(1, 0));
+  __builtin_amdgcn_s_waitcnt(vml(8));   // AE, BE of K tile 0: this thread's share
+  __builtin_amdgcn_s_barrier();
+  const bool half_b = wave >= 4;        // wave-uniform
+  if (half_b) __builtin_amdgcn_s_barrier();   // the offset between the two halves
+  __builtin_amdgcn_sched_barrier(0);
+
+  bool stores_behind = false;   // the previous tile's stores sit behind the units the first K tile's waits cover (wave-uniform)
+  f32x16 acc[4][2];
+  bf16x8 af[4][2], b0[4], b1[4];
+
+  // one phase:  [reads] [DMA] wait | B1 | 8 MFMAs | B2.   FIRST: the K tile that follows an epilogue
+#define PV9_WAIT_B1(FIRST)                                                                \
+  do {                                                                                    \
+    if ((FIRST) && stores_behind) __builtin_amdgcn_s_waitcnt(vml(8 + (YF32 ? 32 : 16)));  \
+    else __builtin_amdgcn_s_waitcnt(vml(8));                                              \
+    __builtin_amdgcn_s_barrier();                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+#define PV9_MFMA(A0, V, BF)                                                                \
+  do {                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                        \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                         \
+      _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                    \
+        acc[(A0) + ta][V] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][ta], BF[s], acc[(A0) + ta][V], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    __builtin_amdgcn_s_barrier();                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+  // one K tile of parity P (compile-time: every LDS address below is a per-lane base + an immediate)
+#define PV9_KTILE(P, FIRST)                                                                                               \
+  do {                                                                                                                    \
+    /* phase 0: (a0, v0); BO of the next K tile */                                                                        \
+    asm volatile("" : "+v"(rd_a0), "+v"(rd_b0));                                                                          \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) b0[s] = PV9_RD(rd_b0, s, unit_b(P, 0) * 2 - kRegionB9);                             \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                         \
+      _Pragma("unroll") for (int ta = 0; ta < 2; ++ta) af[s][ta] = PV9_RD(rd_a0, s, unit_a(P, 0) * 2 + ta * 4096);        \
+    issue_b(1, unit_b(1 - (P), 1));                                                                                       \
+    PV9_WAIT_B1(FIRST);                                                                                                   \
+    PV9_MFMA(0, 0, b0);                                                                                                   \
+    /* phase 1: (a0, v1); AO of the next K tile */                                                                        \
+    asm volatile("" : "+v"(rd_b0));                                                                                       \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) b1[s] = PV9_RD(rd_b0, s, unit_b(P, 1) * 2 - kRegionB9);                             \
+    issue_a(1, unit_a(1 - (P), 1));                                                                                       \
+    PV9_WAIT_B1(FIRST);                                                                                                   \
+    PV9_MFMA(0, 1, b1);                                                                                                   \
+    /* phase 2: the stream moves on to the K tile after next (a new output tile's staging rows are computed HERE, where    \
+       only the accumulators and the voxel fragments are live); (a1, v1); AE of that K tile -- this parity's AE, last      \
+       read two phases ago */                                                                                             \
+    advance();                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    asm volatile("" : "+v"(rd_a0));                                                                                       \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                         \
+      _Pragma("unroll") for (int ta = 0; ta < 2; ++ta) af[s][ta] = PV9_RD(rd_a0, s, unit_a(P, 1) * 2 + ta * 4096);        \
+    issue_a(0, unit_a(P, 0));                                                                                             \
+    PV9_WAIT_B1(FIRST);                                                                                                   \
+    PV9_MFMA(2, 1, b1);                                                                                                   \
+    /* phase 3: (a1, v0); BE of the K tile after next */                                                                  \
+    issue_b(0, unit_b(P, 0));                                                                                             \
+    PV9_WAIT_B1(FIRST);                                                                                                   \
+    PV9_MFMA(2, 0, b0);                                                                                                   \
+  } while (0)
+
+  const int nkp = nk >> 1;   // K tiles come in pairs (K % 128 == 0, host check): every output tile starts on LDS parity 0
+  for (int it = blockIdx.x; it < total_tiles; it += gridDim.x) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][v][r] = 0.f;
+
+    PV9_KTILE(0, true);
+    PV9_KTILE(1, false);
+    for (int kp = 1; kp < nkp; ++kp) {
+      PV9_KTILE(0, false);
+      PV9_KTILE(1, false);
+    }
+
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wn = wave & 1, wm = wave >> 1;
+    // ---- epilogue: lane owns channels cb..cb+15 of voxel m for every (channel tile a, voxel tile v) ----
+    long m0;
+    int n0;
+    tile_origin(it, m0, n0);
+    long e_b[2], e_sp[2];
+    bool e_ok[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const long m = m0 + wm * 64 + v * 32 + l31;
+      e_ok[v] = m < M;
+      const long mm = e_ok[v] ? m : 0;
+      e_b[v] = (long)((unsigned)mm / (unsigned)S_out);
+      e_sp[v] = mm - e_b[v] * S_out;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int cb = n0 + wn * 128 + a * 32 + 16 * hi;
+      f32x4 res[2][2][2];   // [v][h8][half]
+      if (d.residual != nullptr) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int h8 = 0; h8 < 2; ++h8) {
+            const bool ok = e_ok[v] && cb + h8 * 8 < cout_p8;
+            const long ro = ok ? e_b[v] * d.r_bs + e_sp[v] * d.ldr + cb + h8 * 8 : 0;
+            if (d.r_f32) {
+              const float* rp = static_cast<const float*>(d.residual) + ro;
+              res[v][h8][0] = *reinterpret_cast<const f32x4*>(rp);
+              res[v][h8][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+            } else {
+              res[v][h8][0] = *reinterpret_cast<const f32x4*>(static_cast<const bf16_t*>(d.residual) + ro);
+            }
+          }
+      }
+      if (d.scale != nullptr) {
+        float sc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = cb + r < d.cout ? d.scale[cb + r] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] *= sc[r];
+      }
+      if (d.shift != nullptr) {
+        float sh[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sh[r] = cb + r < d.cout ? d.shift[cb + r] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] += sh[r];
+      }
+      if (d.residual != nullptr) {
+        if (d.r_f32) {
+#pragma unroll
+          for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][v][r] += res[v][r >> 3][(r >> 2) & 1][r & 3];
+        } else {
+#pragma unroll
+          for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][v][r] += (float)__builtin_bit_cast(bf16x8, res[v][r >> 3][0])[r & 7];
+        }
+      }
+      if (d.act == PV_ACT_RELU) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] = fmaxf(acc[a][v][r], 0.f);
+      } else if (d.act == PV_ACT_GELU) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] = pv_gelu_fast(acc[a][v][r]);
+      } else if (d.act == PV_ACT_SWISH) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] *= pv_sigmoid(acc[a][v][r]);
+      } else if (d.act == PV_ACT_SIGMOID) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] = pv_sigmoid(acc[a][v][r]);
+      }
+      if (cb + 16 > d.cout) {   // ragged last channel tile: the padding up to the 8-multiple is written as zeros
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][v][r] = cb + r < d.cout ? acc[a][v][r] : 0.f;
+      }
+      // one channel tile's residual rows and scale / shift tables live at a time
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ... then nothing but stores (E_BF16 / E_F32 of them, whatever is masked)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int cb = n0 + wn * 128 + a * 32 + 16 * hi;
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const unsigned yo = (unsigned)(e_b[v] * d.y_bs + e_sp[v] * d.ldy + cb);
+#pragma unroll
+        for (int h8 = 0; h8 < 2; ++h8) {
+          const bool ok = e_ok[v] && cb + h8 * 8 < cout_p8;
+          const int r0 = h8 * 8;
+          if constexpr (YF32) {
+            const unsigned off = ok ? (yo + r0) * 4u : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b128(
+                u32x4{__float_as_uint(acc[a][v][r0 + 0]), __float_as_uint(acc[a][v][r0 + 1]),
+                      __float_as_uint(acc[a][v][r0 + 2]), __float_as_uint(acc[a][v][r0 + 3])}, ry, (int)off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(
+                u32x4{__float_as_uint(acc[a][v][r0 + 4]), __float_as_uint(acc[a][v][r0 + 5]),
+                      __float_as_uint(acc[a][v][r0 + 6]), __float_as_uint(acc[a][v][r0 + 7])}, ry,
+                (int)(ok ? off + 16u : kOOB), 0, 0);
+          } else {
+            bf16x8 ob;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ob[r] = (bf16_t)acc[a][v][r0 + r];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), ry, (int)(ok ? (yo + r0) * 2u : kOOB), 0, 0);
+          }
+        }
+      }
+    }
+    stores_behind = true;   // the four phases of the next K tile wait on units requested BEFORE these stores
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef PV9_KTILE
+#undef PV9_MFMA
+#undef PV9_WAIT_B1
+#undef PV9_RD
+  if (!half_b) __builtin_amdgcn_s_barrier();   // matches the second half's offset barrier
+  __builtin_amdgcn_s_waitcnt(vml(0));          // the stream's trailing (zero-page) DMAs land before the LDS is released
+}
+
+template <bool PW, bool YF32>
+int launch9(const pv_conv3d_desc& d, int tiles_n, long total, hipStream_t s) {
+  const size_t lds = (size_t)LDS9_ELEMS * 2;   // 128 KB
+  auto kern = gemm_quad_kernel<PW, YF32>;
+  PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long resident = 256;   // one workgroup per CU
+  dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads9);
+  PV_LAUNCH(kern, grid, block, lds, s, d, tiles_n, (int)total);
+  pv_note_kernel("gemm_quad_kernel");   // (launched through a function pointer: PV_LAUNCH saw only the variable)
+  PV_LAUNCH_CHECK();
+  return PV_OK;
+}
+
+}  // namespace
+
+// Returns PV_OK when this kernel took the op, PV_ERR_UNSUPPORTED to leave it to the older GEMM kernels.
+int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
+  const int mode = pv_tune("gemm9", 1);   // 0 off, 1 heuristic, 2 wherever the kernel can run
+  if (mode == 0) return PV_ERR_UNSUPPORTED;
+  if (d.dtype != PV_BF16 || d.a_gate != nullptr || d.a_act != PV_ACT_NONE || d.x2 != nullptr) return PV_ERR_UNSUPPORTED;
+  if (d.kt > 8 || d.kh > 8 || d.kw > 8) return PV_ERR_UNSUPPORTED;                 // 8-bit window masks per axis
+  const int taps = d.kt * d.kh * d.kw;
+  if (d.cin % 64 != 0 || ((long)taps * d.cin) % 128 != 0) return PV_ERR_UNSUPPORTED;   // a K step of 64 inside one tap; K tiles in pairs
+  const long M = (long)d.B * d.To * d.Ho * d.Wo;
+  const long K = (long)taps * d.cin;
+  const int cout_p8 = pv_round_up(d.cout, 8);
+  if (K < 256) return PV_ERR_UNSUPPORTED;                                           // >= 4 K tiles behind every epilogue
+  // 31-bit element offsets into x, 32-bit byte offsets into w, 31-bit byte offsets in the store descriptor
+  if (M > 0x7fffffffL || (long)d.B * d.x_bs > 0x7fffffffL || (long)d.cout * K * 2 > 0xffffffffL) return PV_ERR_UNSUPPORTED;
+  if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
+  const long tiles_m = pv_ceil_div(M, BT9);
+  const int tiles_n = (int)pv_ceil_div(cout_p8, BT9);
+  const long total = tiles_m * tiles_n;
+  if (total <= 0 || total > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
+  if (mode == 1) {
+    // one workgroup per CU: the tile list must fill the chip, and a 256-channel tile must not be mostly padding
+    const double waste = (double)((long)tiles_n * BT9 - cout_p8) / (double)cout_p8;
+    const long min_tiles = pv_tune("gemm9_min_tiles", 200);
+    if (total < min_tiles || waste > 0.15) return PV_ERR_UNSUPPORTED;
+  }
+  if (d.y_f32) return pw ? launch9<true, true>(d, tiles_n, total, s) : launch9<false, true>(d, tiles_n, total, s);
+  return pw ? launch9<true, false>(d, tiles_n, total, s) : launch9<false, false>(d, tiles_n, total, s);
+}

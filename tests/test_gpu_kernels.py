@@ -943,8 +943,22 @@ def test_lateral_fusion_writes_the_slow_buffers_channel_slice(dtype, B, Ti, H, W
 
 
 # ------------------------------------------------------------------ large-tile GEMM (256-voxel tiles, 4-stage LDS ring)
-def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine):
-    """pv_conv3d forced onto the large-tile kernel (pv_tune gemm8 = 2 | 4) vs torch on the same bf16-rounded data."""
+def _routed_kernel(op, d):
+    """Symbol of the kernel the library routes descriptor `d` to under the current knobs (a one-op plan, profiled once)."""
+    import ctypes as C
+    lib = L.lib()
+    plan = lib.pv_plan_create()
+    try:
+        L.check(lib.pv_plan_add(plan, op, C.byref(d), C.sizeof(d)), "pv_plan_add")
+        ms = (C.c_float * 1)()
+        L.check(lib.pv_plan_profile(plan, C.c_void_p(torch.cuda.current_stream().cuda_stream), 1, ms), "pv_plan_profile")
+        return (lib.pv_plan_op_kernel(plan, 0) or b"").decode()
+    finally:
+        lib.pv_plan_destroy(plan)
+
+
+def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm8"):
+    """pv_conv3d forced onto a large-tile kernel (pv_tune gemm8 = 2 | 4, or gemm9 = 2) vs torch on the same bf16-rounded data."""
     dtype = torch.bfloat16
     pad = tuple(kk // 2 for kk in k)
     g = torch.Generator().manual_seed(7 * cin + cout)
@@ -973,13 +987,15 @@ def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine):
     d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, cin, To, Ho, Wo, cout
     d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *stride, *pad)
     d.act, d.a_act, d.dtype, d.y_f32, d.r_f32 = act, L.ACT_NONE, L.PV_BF16, int(y_f32), int(y_f32 and res)
-    L.tune(gemm8=ct)
+    L.tune(**{knob: ct})
     try:
         call("pv_conv3d", d)
+        routed = _routed_kernel(L.OP_CONV3D, d)
         got1 = y.clone()
         call("pv_conv3d", d)                       # a second launch gives the same bits
     finally:
-        L.tune(gemm8=1)
+        L.tune(**{knob: 1})
+    assert routed == {"gemm8": "gemm8_kernel", "gemm9": "gemm_quad_kernel"}[knob], routed
     assert torch.equal(got1, y)
     assert rel_err(y[..., :cout].permute(0, 4, 1, 2, 3), want) <= 1e-2
     if cp > cout:
@@ -999,6 +1015,27 @@ def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine):
 ])
 def test_large_tile_gemm_kernel(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine):
     _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine)
+
+
+# ------------------------------------------------------------------ 256 x 256 tiles, eight-phase main loop (pv_gemm9.hip, round 5)
+@pytest.mark.parametrize("B,T,H,W,cin,cout,k,stride,act,res,y_f32,affine", [
+    (1, 1, 1, 1000, 256, 200, (1, 1, 1), (1, 1, 1), L.ACT_RELU, True, False, True),     # ragged M and N tails, 4 K tiles
+    (1, 1, 1, 100, 512, 72, (1, 1, 1), (1, 1, 1), L.ACT_NONE, False, False, False),     # less than one tile in M and N
+    (8, 1, 1, 785, 768, 768, (1, 1, 1), (1, 1, 1), L.ACT_NONE, True, True, False),      # MViT proj: fp32 stream in / out
+    (2, 1, 1, 3137, 384, 1536, (1, 1, 1), (1, 1, 1), L.ACT_GELU, False, False, False),  # MViT fc1
+    (1, 1, 1, 70000, 256, 520, (1, 1, 1), (1, 1, 1), L.ACT_NONE, True, False, True),    # 822 tiles: several per workgroup (the
+                                                                                         # DMA stream crosses tiles behind stores)
+    (1, 1, 1, 40000, 256, 300, (1, 1, 1), (1, 1, 1), L.ACT_RELU, True, True, True),     # the same with fp32 stores (32 per tile)
+    (2, 8, 10, 10, 128, 96, (3, 1, 1), (1, 1, 1), L.ACT_RELU, False, False, True),      # SlowFast conv_a (3,1,1): temporal padding
+    (16, 8, 16, 16, 256, 256, (3, 1, 1), (1, 1, 1), L.ACT_RELU, False, False, True),    # ... at res4's grid, 128 tiles
+    (2, 4, 17, 13, 128, 136, (1, 3, 3), (1, 2, 2), L.ACT_RELU, True, False, True),      # conv_b (1,3,3), stride 2, odd grid
+    (3, 4, 16, 16, 128, 256, (1, 3, 3), (1, 1, 1), L.ACT_RELU, False, False, True),     # conv_b (1,3,3): spatial padding
+    (2, 3, 9, 11, 64, 264, (3, 3, 3), (1, 1, 1), L.ACT_NONE, False, False, False),      # all three axes padded, 27 taps
+    (1, 32, 6, 6, 128, 256, (7, 1, 1), (4, 1, 1), L.ACT_RELU, False, False, True),      # lateral-shaped (7,1,1) / stride 4
+    (2, 4, 16, 16, 256, 512, (1, 1, 1), (1, 2, 2), L.ACT_NONE, False, False, True),     # projection shortcut: strided 1x1x1
+])
+def test_quad_phase_gemm_kernel(B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine):
+    _gemm8_case(2, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm9")
 
 
 @pytest.mark.parametrize("B,T,H,W,cin,cout,k,stride", [
