@@ -146,15 +146,15 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   geom_of(iss_live ? iss_it : 0, g);
 
   // source selection with bit masks, not `?:` (a select between two pointers becomes two exec-masked DMAs)
-  auto pick = [&](bool ok, unsigned long p) __attribute__((always_inline)) -> gptr9_t {
+  auto pick = [&](bool ok, unsigned long p) __attribute__((always_inline)) -> const bf16_t* {
     const unsigned long m = 0ul - (unsigned long)ok;
-    return (gptr9_t)((p & m) | (zaddr & ~m));
+    return reinterpret_cast<const bf16_t*>((p & m) | (zaddr & ~m));
   };
   auto issue_a = [&](int a, int unit) __attribute__((always_inline)) {   // channel half a of the stream's K tile -> LDS unit at element offset `unit`
     const unsigned kb = (unsigned)iss_ku * 128u;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds(pick(iss_live, (unsigned long)(Wb + (g.a_off[a * 2 + j] + kb))),
+      __builtin_amdgcn_global_load_lds((gptr9_t)pick(iss_live, (unsigned long)(Wb + (g.a_off[a * 2 + j] + kb))),
                                        (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
   };
   auto issue_b = [&](int v, int unit) __attribute__((always_inline)) {   // voxel half v
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const bool ok = iss_live && (g.b_msk[v * 2 + j] & sel) == sel;
-      __builtin_amdgcn_global_load_lds(pick(ok, (unsigned long)(X + (long)(g.b_off[v * 2 + j] + uni))),
+      __builtin_amdgcn_global_load_lds((gptr9_t)pick(ok, (unsigned long)(X + (long)(g.b_off[v * 2 + j] + uni))),
                                        (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
     }
   };
