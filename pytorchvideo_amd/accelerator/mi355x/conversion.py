@@ -423,9 +423,16 @@ def _try_fuse_mvit(model, sess, dtype, input_tensor):
         for i, blk in enumerate(model.blocks):
             # the fused MLP of block i can write norm1 of block i + 1 (emit_mvit.emit_mlp_fused)
             blk.__dict__["_pv_next_block"] = model.blocks[i + 1] if i + 1 < len(model.blocks) else None
-            blk.convert(None, session=sess, input_ref=cur, dtype=dtype)
+            try:
+                blk.convert(None, session=sess, input_ref=cur, dtype=dtype)
+            finally:       # never leave the hint behind: a block converted standalone later must not emit `yn` for a stranger
+                blk.__dict__.pop("_pv_next_block", None)
             sess.release(cur)
             cur = blk._out_ref
+        pre = getattr(cur, "prenorm", None)     # (a next-block operand nobody consumed would stay live in the arena)
+        if pre is not None:
+            cur.prenorm = None
+            sess.release(pre[0])
         out = EM.emit_vit_head(sess, model.norm_embed, model.head, cur)
         sess.release(cur)
     except E.Unsupported:

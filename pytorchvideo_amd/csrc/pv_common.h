@@ -170,7 +170,11 @@ __device__ __forceinline__ bool pv_last_ticket_wave(unsigned* counter, unsigned 
     if (t + 1u == total) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-  return t + 1u == total;
+  const bool last = t + 1u == total;
+  // the reducer's sc1 loads must not be ordered ahead of the ticket: one agent-scope acquire in the ONE wave
+  // per clip that draws the last ticket (buffer_inv sc1: this CU's L1 only, nothing is written back)
+  if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return last;
 }
 // The whole workgroup publishes (every thread may have made pv_publish_f32 stores); true for all threads of the workgroup
 // that drew the last ticket.  `s_flag`: one int of LDS nobody else touches.
@@ -181,6 +185,7 @@ __device__ __forceinline__ bool pv_last_ticket_block(unsigned* counter, unsigned
     const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = t + 1u == total;
     if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (see pv_last_ticket_wave)
     *s_flag = last;
   }
   __syncthreads();

@@ -52,6 +52,8 @@ constexpr int UNIT9 = 128 * 64;       // elements of one staging unit (128 rows 
 constexpr int LDS9_ELEMS = 8 * UNIT9;   // 128 KB
 __device__ __forceinline__ constexpr int unit_a(int P, int a) { return (2 * P + a) * UNIT9; }
 __device__ __forceinline__ constexpr int unit_b(int P, int v) { return (4 + 2 * P + v) * UNIT9; }
+constexpr int kTab9 = LDS9_ELEMS * 2;       // byte offset of the epilogue tables: [tile parity][scale 256 f32 | shift 256 f32]
+constexpr int kLds9Bytes = kTab9 + 2 * 2048;
 constexpr int kRegionB9 = 4 * UNIT9 * 2;   // byte offset of the voxel units (folded into the read base: immediates stay < 64 K)
 
 typedef const __attribute__((address_space(1))) void* gptr9_t;
@@ -62,10 +64,11 @@ __device__ __forceinline__ int chi9(int rho) {
   return (rho & ~31) + 16 * ((rho >> 2) & 1) + 4 * ((rho >> 3) & 3) + (rho & 3);
 }
 
-struct Geom9 {         // per-thread staging rows of one output tile
-  unsigned a_off[4];   // [a*2 + j]  byte offset of (weight row, chunk) in w
-  int b_off[4];        // [v*2 + j]  element offset of (voxel row's window origin, chunk) in x (negative: padding rows)
-  unsigned b_msk[4];   // window mask of the voxel row: bit dt | bit 8 + dh | bit 16 + dw set when that tap is inside
+struct Geom9 {         // per-thread staging rows of one output tile (DMA j of a unit covers unit rows 64 j + 8 wave + lane / 8)
+  int a_row;           // weight row of (a = 0, j = 0); (a, j) is a_row + 64 a + 128 j, clamped to cout - 1 at use
+  int b_row;           // PW: voxel row of (v = 0, j = 0); (v, j) is b_row + 32 v + 128 j, clamped to M - 1 at use (rows contiguous)
+  int b_off[4];        // !PW: [v*2 + j] element offset of the voxel row's window origin in x (negative: padding rows)
+  unsigned b_msk[4];   // !PW: window mask of the voxel row: bit dt | bit 8 + dh | bit 16 + dw set when that tap is inside
 };
 
 template <bool PW, bool YF32>
@@ -95,31 +98,26 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     m0 = (long)(tile / tiles_n) * BT9;
     n0 = (tile % tiles_n) * BT9;
   };
+  // K chunk (8 elements) that lands on LDS position lane % 8 of this thread's staging rows: the swizzle key (row >> 1) & 7 is
+  // the same for both DMAs of a unit (rows 64 apart) -- one register for all eight staging rows
+  const int chunk8 = ((lane & 7) ^ (((8 * wave + (lane >> 3)) >> 1) & 7)) * 8;
   auto geom_of = [&](int it, Geom9& g) __attribute__((always_inline)) {
     long m0;
     int n0;
     tile_origin(it, m0, n0);
-    const int rho0 = 8 * wave + (lane >> 3);
+    const int rho0 = 8 * wave + (lane >> 3);   // unit row of DMA 0 (< 64)
+    g.a_row = n0 + 32 * (rho0 >> 5) + chi9(rho0 & 31);
+    if constexpr (PW) {
+      g.b_row = (int)m0 + 64 * (rho0 >> 5) + (rho0 & 31);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int rho = 64 * j + rho0;
-      const int chunk8 = ((lane & 7) ^ ((rho >> 1) & 7)) * 8;   // K chunk that lands on LDS position lane % 8 of the row
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        int n = n0 + 128 * (rho >> 6) + 64 * a + 32 * ((rho >> 5) & 1) + chi9(rho & 31);
-        n = n < d.cout ? n : d.cout - 1;                    // N tail: a clamped row, zeroed in the epilogue
-        g.a_off[a * 2 + j] = ((unsigned)n * (unsigned)K + (unsigned)chunk8) * 2u;
-      }
-#pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        long m = m0 + 64 * (rho >> 5) + 32 * v + (rho & 31);
-        m = m < M ? m : M - 1;                              // M tail: a clamped row, never stored
-        const unsigned b = (unsigned)m / (unsigned)S_out;
-        const unsigned sp = (unsigned)m - b * (unsigned)S_out;
-        if constexpr (PW) {
-          g.b_off[v * 2 + j] = (int)((long)b * d.x_bs + (long)sp * d.ldx) + chunk8;
-          g.b_msk[v * 2 + j] = 0u;
-        } else {
+        for (int v = 0; v < 2; ++v) {
+          long m = m0 + 128 * j + 64 * (rho0 >> 5) + 32 * v + (rho0 & 31);
+          m = m < M ? m : M - 1;                              // M tail: a clamped row, never stored
+          const unsigned b = (unsigned)m / (unsigned)S_out;
+          const unsigned sp = (unsigned)m - b * (unsigned)S_out;
           const unsigned to = sp / (unsigned)(d.Ho * d.Wo);
           const unsigned r2 = sp - to * (unsigned)(d.Ho * d.Wo);
           const unsigned ho = r2 / (unsigned)d.Wo;
@@ -134,13 +132,12 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
           }
           g.b_msk[v * 2 + j] = msk;
         }
-      }
     }
   };
 
   // ---- issue side: the DMA stream, K tile by K tile across output tiles (all of this state is wave-uniform) ----
   Geom9 g;
-  int iss_it = blockIdx.x, iss_ku = 0;
+  int iss_it = blockIdx.x, iss_ku = 0, iss_jt = 0;   // work item, K tile inside it, this workgroup's tile count
   bool iss_live = iss_it < total_tiles;
   int iss_c0 = 0, iss_dt = 0, iss_dh = 0, iss_dw = 0;   // channel offset inside the tap, tap coordinates
   geom_of(iss_live ? iss_it : 0, g);
@@ -151,27 +148,51 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     return reinterpret_cast<const bf16_t*>((p & m) | (zaddr & ~m));
   };
   auto issue_a = [&](int a, int unit) __attribute__((always_inline)) {   // channel half a of the stream's K tile -> LDS unit at element offset `unit`
-    const unsigned kb = (unsigned)iss_ku * 128u;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((gptr9_t)pick(iss_live, (unsigned long)(Wb + (g.a_off[a * 2 + j] + kb))),
-                                       (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
-  };
-  auto issue_b = [&](int v, int unit) __attribute__((always_inline)) {   // voxel half v
-    int uni;        // element offset of the K tile's tap + channel block, wave-uniform
-    unsigned sel;   // the bits of b_msk that must be set for this tap
-    if constexpr (PW) {
-      uni = iss_ku * 64;
-      sel = 0u;
-    } else {
-      uni = ((iss_dt * dil_t * d.Hi + iss_dh * dil_h) * d.Wi + iss_dw * dil_w) * d.ldx + iss_c0;
-      sel = (1u << iss_dt) | (1u << (8 + iss_dh)) | (1u << (16 + iss_dw));
-    }
+    const unsigned kc = (unsigned)(iss_ku * 64 + chunk8);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const bool ok = iss_live && (g.b_msk[v * 2 + j] & sel) == sel;
-      __builtin_amdgcn_global_load_lds((gptr9_t)pick(ok, (unsigned long)(X + (long)(g.b_off[v * 2 + j] + uni))),
+      int n = g.a_row + 64 * a + 128 * j;
+      n = n < d.cout ? n : d.cout - 1;                      // N tail: a clamped row, zeroed in the epilogue
+      const unsigned off = ((unsigned)n * (unsigned)K + kc) * 2u;
+      __builtin_amdgcn_global_load_lds((gptr9_t)pick(iss_live, (unsigned long)(Wb + off)),
                                        (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
+    }
+  };
+  auto issue_b = [&](int v, int unit) __attribute__((always_inline)) {   // voxel half v
+    if constexpr (PW) {
+      const int kc = iss_ku * 64 + chunk8;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int m = g.b_row + 32 * v + 128 * j;
+        m = m < (int)M ? m : (int)M - 1;                    // M tail: a clamped row, never stored
+        __builtin_amdgcn_global_load_lds((gptr9_t)pick(iss_live, (unsigned long)(X + ((long)m * d.ldx + kc))),
+                                         (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
+      }
+    } else {
+      // element offset of the K tile's tap + channel block and the bits of b_msk that must be set for this tap (wave-uniform)
+      const int uni = ((iss_dt * dil_t * d.Hi + iss_dh * dil_h) * d.Wi + iss_dw * dil_w) * d.ldx + iss_c0;
+      const unsigned sel = (1u << iss_dt) | (1u << (8 + iss_dh)) | (1u << (16 + iss_dw));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bool ok = iss_live && (g.b_msk[v * 2 + j] & sel) == sel;
+        __builtin_amdgcn_global_load_lds((gptr9_t)pick(ok, (unsigned long)(X + (long)(g.b_off[v * 2 + j] + uni))),
+                                         (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
+      }
+    }
+  };
+  // folded BatchNorm / bias tables of the stream's tile -> LDS, one 4-byte DMA per thread: wave w < 4 carries scale[64 w ..
+  // 64 w + 63] of the tile's 256 channels, w >= 4 the shift (channels past cout read a clamped entry: zeroed in the epilogue).
+  // The global round trips of 2 x 64 table loads per thread were a third of the per-tile fixed cost (epilogue reads: ds_read).
+  // Extra DMAs inside the counted windows only make the waits stricter (an older unit completes earlier), never weaker.
+  auto issue_tables = [&]() __attribute__((always_inline)) {
+    const float* tab = wave < 4 ? d.scale : d.shift;
+    if (tab != nullptr && iss_live) {
+      long m0;
+      int n0;
+      tile_origin(iss_it, m0, n0);
+      int n = n0 + 64 * (wave & 3) + lane;
+      n = n < d.cout ? n : d.cout - 1;
+      __builtin_amdgcn_global_load_lds((gptr9_t)(tab + n), (lptr9_t)(smem9_raw + kTab9 + (iss_jt & 1) * 2048 + wave * 256), 4, 0, 0);
     }
   };
   auto advance = [&]() __attribute__((always_inline)) {   // next K tile of the stream
@@ -190,8 +211,10 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
       iss_ku = 0;
       iss_c0 = iss_dt = iss_dh = iss_dw = 0;
       iss_it += gridDim.x;
+      ++iss_jt;
       iss_live = iss_it < total_tiles;
       if (iss_live) geom_of(iss_it, g);
+      issue_tables();
     }
   };
 
@@ -217,7 +240,8 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
       d.y, 0, (int)((unsigned)d.B * (unsigned)d.y_bs * (YF32 ? 4u : 2u)), 0x00020000);   // stores per thread per tile: 32 (fp32) / 16
 
-  // ---- prologue: AE BE BO AO of K tile 0, AE BE of K tile 1 ----
+  // ---- prologue: the first tile's tables, AE BE BO AO of K tile 0, AE BE of K tile 1 ----
+  issue_tables();
   issue_a(0, unit_a(0, 0));
   issue_b(0, unit_b(0, 0));
   issue_b(1, unit_b(0, 1));
@@ -232,8 +256,9 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   __builtin_amdgcn_sched_barrier(0);
 
   bool stores_behind = false;   // the previous tile's stores sit behind the units the first K tile's waits cover (wave-uniform)
+  int jt = 0;                   // tiles finished by this workgroup (table parity)
   f32x16 acc[4][2];
-  bf16x8 af[4][2], b0[4], b1[4];
+  bf16x8 af0[4][2], af1[4][2], b0[4], b1[4];   // channel halves a0 / a1, voxel halves v0 / v1 of the K tile (4 K slices each)
 
   // one phase:  [reads] [DMA] wait | B1 | 8 MFMAs | B2.   FIRST: the K tile that follows an epilogue
 #define PV9_WAIT_B1(FIRST)                                                                \
@@ -243,53 +268,66 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     __builtin_amdgcn_s_barrier();                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
-#define PV9_MFMA(A0, V, BF)                                                                \
+#define PV9_MFMA(AF, A0, V, BF)                                                            \
   do {                                                                                    \
     __builtin_amdgcn_s_setprio(1);                                                        \
     _Pragma("unroll") for (int s = 0; s < 4; ++s)                                         \
       _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                    \
-        acc[(A0) + ta][V] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][ta], BF[s], acc[(A0) + ta][V], 0, 0, 0); \
+        acc[(A0) + ta][V] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[s][ta], BF[s], acc[(A0) + ta][V], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                    \
     __builtin_amdgcn_s_barrier();                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
-  // one K tile of parity P (compile-time: every LDS address below is a per-lane base + an immediate)
-#define PV9_KTILE(P, FIRST)                                                                                               \
+#define PV9_READ_A(AF, P, A)                                                                                              \
   do {                                                                                                                    \
-    /* phase 0: (a0, v0); BO of the next K tile */                                                                        \
-    asm volatile("" : "+v"(rd_a0), "+v"(rd_b0));                                                                          \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) b0[s] = PV9_RD(rd_b0, s, unit_b(P, 0) * 2 - kRegionB9);                             \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                         \
-      _Pragma("unroll") for (int ta = 0; ta < 2; ++ta) af[s][ta] = PV9_RD(rd_a0, s, unit_a(P, 0) * 2 + ta * 4096);        \
-    issue_b(1, unit_b(1 - (P), 1));                                                                                       \
-    PV9_WAIT_B1(FIRST);                                                                                                   \
-    PV9_MFMA(0, 0, b0);                                                                                                   \
-    /* phase 1: (a0, v1); AO of the next K tile */                                                                        \
-    asm volatile("" : "+v"(rd_b0));                                                                                       \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) b1[s] = PV9_RD(rd_b0, s, unit_b(P, 1) * 2 - kRegionB9);                             \
-    issue_a(1, unit_a(1 - (P), 1));                                                                                       \
-    PV9_WAIT_B1(FIRST);                                                                                                   \
-    PV9_MFMA(0, 1, b1);                                                                                                   \
-    /* phase 2: the stream moves on to the K tile after next (a new output tile's staging rows are computed HERE, where    \
-       only the accumulators and the voxel fragments are live); (a1, v1); AE of that K tile -- this parity's AE, last      \
-       read two phases ago */                                                                                             \
-    advance();                                                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                                    \
     asm volatile("" : "+v"(rd_a0));                                                                                       \
     _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                         \
-      _Pragma("unroll") for (int ta = 0; ta < 2; ++ta) af[s][ta] = PV9_RD(rd_a0, s, unit_a(P, 1) * 2 + ta * 4096);        \
+      _Pragma("unroll") for (int ta = 0; ta < 2; ++ta) AF[s][ta] = PV9_RD(rd_a0, s, unit_a(P, A) * 2 + ta * 4096);        \
+  } while (0)
+#define PV9_READ_B(BF, P, V)                                                                                              \
+  do {                                                                                                                    \
+    asm volatile("" : "+v"(rd_b0));                                                                                       \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) BF[s] = PV9_RD(rd_b0, s, unit_b(P, V) * 2 - kRegionB9);                 \
+  } while (0)
+  // One K tile of LDS parity P (compile-time: every LDS address is a per-lane base + an immediate).  The fragment reads are
+  // spread 4 / 4 / 8 / 8 over the phases: the channel half a0 of the NEXT K tile is read in phase 3 (its unit was requested
+  // six phases ago and is covered by phase 2's wait), so no phase carries more than 8 reads beside its two DMAs.
+  // FIRST: follows an epilogue (a0 was not read ahead: its 32 registers belong to the epilogue); LAST: no read-ahead.
+  // The implicit-GEMM form carries 8 more staging registers per thread (offsets + window masks) and has no room for the second
+  // channel-half fragment set: it reads a0 in phase 0 (12 / 4 / 8 / 0 reads).
+#define PV9_KTILE(P, FIRST, LAST)                                                                                         \
+  do {                                                                                                                    \
+    /* phase 0: (a0, v0); BO of the next K tile */                                                                        \
+    PV9_READ_B(b0, P, 0);                                                                                                 \
+    if ((FIRST) || !RA) PV9_READ_A(af0, P, 0);                                                                                     \
+    issue_b(1, unit_b(1 - (P), 1));                                                                                       \
+    PV9_WAIT_B1(FIRST);                                                                                                   \
+    PV9_MFMA(af0, 0, 0, b0);                                                                                              \
+    /* phase 1: (a0, v1); AO of the next K tile */                                                                        \
+    PV9_READ_B(b1, P, 1);                                                                                                 \
+    issue_a(1, unit_a(1 - (P), 1));                                                                                       \
+    PV9_WAIT_B1(FIRST);                                                                                                   \
+    PV9_MFMA(af0, 0, 1, b1);                                                                                              \
+    /* phase 2: the stream moves on to the K tile after next (a new output tile's staging rows are computed HERE, where    \
+       only the accumulators and the voxel fragments are live); (a1, v1); AE of that K tile -- this parity's AE, last      \
+       read a K tile ago */                                                                                               \
+    advance();                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    PV9_READ_A(af1, P, 1);                                                                                                \
     issue_a(0, unit_a(P, 0));                                                                                             \
     PV9_WAIT_B1(FIRST);                                                                                                   \
-    PV9_MFMA(2, 1, b1);                                                                                                   \
-    /* phase 3: (a1, v0); BE of the K tile after next */                                                                  \
+    PV9_MFMA(af1, 2, 1, b1);                                                                                              \
+    /* phase 3: (a1, v0); BE of the K tile after next; a0 of the NEXT K tile (other parity) */                            \
+    if (RA && !(LAST)) PV9_READ_A(af0, 1 - (P), 0);                                                                             \
     issue_b(0, unit_b(P, 0));                                                                                             \
     PV9_WAIT_B1(FIRST);                                                                                                   \
-    PV9_MFMA(2, 0, b0);                                                                                                   \
+    PV9_MFMA(af1, 2, 0, b0);                                                                                              \
   } while (0)
 
+  constexpr bool RA = PW;    // read-ahead of the next K tile's a0 fragments
   const int nkp = nk >> 1;   // K tiles come in pairs (K % 128 == 0, host check): every output tile starts on LDS parity 0
-  for (int it = blockIdx.x; it < total_tiles; it += gridDim.x) {
+  for (int it = blockIdx.x; it < total_tiles; it += gridDim.x, ++jt) {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -297,13 +335,20 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][v][r] = 0.f;
 
-    PV9_KTILE(0, true);
-    PV9_KTILE(1, false);
-    for (int kp = 1; kp < nkp; ++kp) {
-      PV9_KTILE(0, false);
-      PV9_KTILE(1, false);
+    PV9_KTILE(0, true, false);
+    PV9_KTILE(1, false, false);
+    for (int kp = 2; kp < nkp; ++kp) {
+      PV9_KTILE(0, false, false);
+      PV9_KTILE(1, false, false);
     }
+    PV9_KTILE(0, false, false);
+    PV9_KTILE(1, false, true);
 
+    // The first half has just passed its last B2; the second half is still multiplying its last quadrant.  One extra barrier
+    // here (matched by that half's last B2) and one at the END of the second half's epilogue (matched by the first half's next
+    // B1) let both halves run their epilogues side by side instead of one after the other, and restore the offset.
+    if (!half_b) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     const int l31 = lane & 31, hi = lane >> 5;
     const int wn = wave & 1, wm = wave >> 1;
     // ---- epilogue: lane owns channels cb..cb+15 of voxel m for every (channel tile a, voxel tile v) ----
@@ -320,43 +365,46 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
       e_b[v] = (long)((unsigned)mm / (unsigned)S_out);
       e_sp[v] = mm - e_b[v] * S_out;
     }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    const float* tabs = reinterpret_cast<const float*>(smem9_raw + kTab9 + (jt & 1) * 2048);
+    typedef f32x4 res_t[2][2][2];   // [v][h8][half]: 8 channels as 2 x f32x4 (fp32) or 1 x 16 bytes (bf16)
+    auto load_res = [&](int a, res_t& res) __attribute__((always_inline)) {
+      if (d.residual == nullptr) return;
       const int cb = n0 + wn * 128 + a * 32 + 16 * hi;
-      f32x4 res[2][2][2];   // [v][h8][half]
-      if (d.residual != nullptr) {
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+      for (int v = 0; v < 2; ++v)
 #pragma unroll
-          for (int h8 = 0; h8 < 2; ++h8) {
-            const bool ok = e_ok[v] && cb + h8 * 8 < cout_p8;
-            const long ro = ok ? e_b[v] * d.r_bs + e_sp[v] * d.ldr + cb + h8 * 8 : 0;
-            if (d.r_f32) {
-              const float* rp = static_cast<const float*>(d.residual) + ro;
-              res[v][h8][0] = *reinterpret_cast<const f32x4*>(rp);
-              res[v][h8][1] = *reinterpret_cast<const f32x4*>(rp + 4);
-            } else {
-              res[v][h8][0] = *reinterpret_cast<const f32x4*>(static_cast<const bf16_t*>(d.residual) + ro);
-            }
+        for (int h8 = 0; h8 < 2; ++h8) {
+          const bool ok = e_ok[v] && cb + h8 * 8 < cout_p8;
+          const long ro = ok ? e_b[v] * d.r_bs + e_sp[v] * d.ldr + cb + h8 * 8 : 0;
+          if (d.r_f32) {
+            const float* rp = static_cast<const float*>(d.residual) + ro;
+            res[v][h8][0] = *reinterpret_cast<const f32x4*>(rp);
+            res[v][h8][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+          } else {
+            res[v][h8][0] = *reinterpret_cast<const f32x4*>(static_cast<const bf16_t*>(d.residual) + ro);
           }
-      }
+        }
+    };
+    auto finish = [&](int a, const res_t& res) __attribute__((always_inline)) {
+      const int cl = wn * 128 + a * 32 + 16 * hi;   // channel inside the tile
+      const int cb = n0 + cl;
       if (d.scale != nullptr) {
-        float sc[16];
+        f32x4 sc[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = cb + r < d.cout ? d.scale[cb + r] : 0.f;
+        for (int q = 0; q < 4; ++q) sc[q] = *reinterpret_cast<const f32x4*>(tabs + cl + 4 * q);
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][v][r] *= sc[r];
+          for (int r = 0; r < 16; ++r) acc[a][v][r] *= sc[r >> 2][r & 3];
       }
       if (d.shift != nullptr) {
-        float sh[16];
+        f32x4 sh[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sh[r] = cb + r < d.cout ? d.shift[cb + r] : 0.f;
+        for (int q = 0; q < 4; ++q) sh[q] = *reinterpret_cast<const f32x4*>(tabs + 256 + cl + 4 * q);
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][v][r] += sh[r];
+          for (int r = 0; r < 16; ++r) acc[a][v][r] += sh[r >> 2][r & 3];
       }
       if (d.residual != nullptr) {
         if (d.r_f32) {
@@ -398,8 +446,21 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][v][r] = cb + r < d.cout ? acc[a][v][r] : 0.f;
       }
-      // one channel tile's residual rows and scale / shift tables live at a time
       __builtin_amdgcn_sched_barrier(0);
+    };
+    // the residual rows of channel tile a + 1 are requested before tile a is finished (two register sets); every load of the
+    // epilogue is consumed before the first store is issued
+    {
+      res_t r0, r1;
+      load_res(0, r0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_res(1, r1);
+      finish(0, r0);
+      load_res(2, r0);
+      finish(1, r1);
+      load_res(3, r1);
+      finish(2, r0);
+      finish(3, r1);
     }
     // ... then nothing but stores (E_BF16 / E_F32 of them, whatever is masked)
 #pragma unroll
@@ -431,9 +492,12 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
       }
     }
     stores_behind = true;   // the four phases of the next K tile wait on units requested BEFORE these stores
+    if (half_b) __builtin_amdgcn_s_barrier();   // (see above: matched by the first half's next B1)
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef PV9_KTILE
+#undef PV9_READ_A
+#undef PV9_READ_B
 #undef PV9_MFMA
 #undef PV9_WAIT_B1
 #undef PV9_RD
@@ -443,7 +507,7 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
 
 template <bool PW, bool YF32>
 int launch9(const pv_conv3d_desc& d, int tiles_n, long total, hipStream_t s) {
-  const size_t lds = (size_t)LDS9_ELEMS * 2;   // 128 KB
+  const size_t lds = (size_t)kLds9Bytes;   // 128 KB of units + 4 KB of epilogue tables
   auto kern = gemm_quad_kernel<PW, YF32>;
   PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long resident = 256;   // one workgroup per CU
@@ -467,7 +531,7 @@ int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   const long M = (long)d.B * d.To * d.Ho * d.Wo;
   const long K = (long)taps * d.cin;
   const int cout_p8 = pv_round_up(d.cout, 8);
-  if (K < 256) return PV_ERR_UNSUPPORTED;                                           // >= 4 K tiles behind every epilogue
+  if (K < 256) return PV_ERR_UNSUPPORTED;                                           // a first and a last pair of K tiles
   // 31-bit element offsets into x, 32-bit byte offsets into w, 31-bit byte offsets in the store descriptor
   if (M > 0x7fffffffL || (long)d.B * d.x_bs > 0x7fffffffL || (long)d.cout * K * 2 > 0xffffffffL) return PV_ERR_UNSUPPORTED;
   if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
@@ -481,6 +545,8 @@ int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
     const long min_tiles = pv_tune("gemm9_min_tiles", 200);
     if (total < min_tiles || waste > 0.15) return PV_ERR_UNSUPPORTED;
   }
-  if (d.y_f32) return pw ? launch9<true, true>(d, tiles_n, total, s) : launch9<false, true>(d, tiles_n, total, s);
-  return pw ? launch9<true, false>(d, tiles_n, total, s) : launch9<false, false>(d, tiles_n, total, s);
+  // the pointwise form addresses voxel row m at x + m * ldx: batch items must follow each other without a gap
+  const bool rows = pw && d.x_bs == (long)d.To * d.Ho * d.Wo * d.ldx;
+  if (d.y_f32) return rows ? launch9<true, true>(d, tiles_n, total, s) : launch9<false, true>(d, tiles_n, total, s);
+  return rows ? launch9<true, false>(d, tiles_n, total, s) : launch9<false, false>(d, tiles_n, total, s);
 }

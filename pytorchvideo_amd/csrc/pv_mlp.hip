@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256, MINW) void mlp_rows_kernel(const pv_mlp_desc d
   stage(1, 1);      // (H = 32: block 1 is the padding block)
 
   // gamma | beta of the next block's norm1 -> LDS (read in the epilogue between global stores, like b2 below)
+  static_assert(NOB * 16 <= 256, "the gamma | beta preload is one f32x4 per thread of a 256-thread workgroup");
   if (d.yn != nullptr && tid < NOB * 16) {
     const int k = tid < NOB * 8 ? tid : tid - NOB * 8;
     reinterpret_cast<f32x4*>(smem + 3 * G::STAGE + NOB * 128)[tid] =

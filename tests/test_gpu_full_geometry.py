@@ -4,6 +4,14 @@ models/hub/vision_transformers.py:31-39) and X3D-L 16x224^2 (configs[4]) -- the 
 
 Metric everywhere: max|d| / max|oracle output|.  Every bound is a FIXED number.
 
+0. Round 5 (verdict items): the bench-batch case asserts EVERY ROW (normalised by the row's own logits, a stricter metric than
+   the batch-wide one): against the bf16-storage oracle a fixed per-workload kernel-arithmetic bound (round 4's measured worst
+   row x 1.3), against the fp32 oracle max(1e-2, 1.15 x what bf16 storage ALONE does to that row with exact arithmetic, no
+   kernel) -- X3D-L's worst row is 1.06e-2 where storage alone gives ~1.0e-2; the per-block kernel gate is the measured worst
+   x 1.3 per workload instead of a flat 1e-2; the block-final gamma U(0.1, 0.4) instance is a reported second case held to its own
+   storage floor; a defect-injection case proves which gate sees a 5 % error in one filter bank (and which cannot: on
+   `trained_like` a residual branch is ~1/8 of the trunk, a 5 % defect in conv_c moves a block's output by 5-9e-3, below any
+   honest bf16 gate -- so the per-block gate is ALSO run on the stress instance, where it moves it by ~3e-2).
 1. North star, plainly (round 4): on the `trained_like` instance (oracle/weights.py::trained_like_fill -- BatchNorm
    statistics calibrated on data like a checkpoint's, block-final gamma U(0.05, 0.2) between the reference's own zero
    init, models/weight_init.py:34-35, and `rand_init_bn`; the instance bench.py times)
@@ -31,7 +39,14 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 WORKLOADS4 = ["x3d_m", "x3d_l", "slowfast_r50", "mvit_b_32x3"]
 FP32_TOL = 1e-3
 BF16_TOL = 1e-2                                      # the north star's bar, no allowance
-BLOCK_BF16_TOL = 1e-2
+# teacher-forced per-block gate: round 4's measured worst block (profiles/r4/parity_full.jsonl: 6.5e-3 / 5.2e-3 / 6.2e-3 / 4.0e-3)
+# x 1.3 -- a kernel whose arithmetic regresses by a third fails in exactly the blocks it serves
+BLOCK_BF16_TOL = {"x3d_m": 8.5e-3, "x3d_l": 6.8e-3, "slowfast_r50": 8.0e-3, "mvit_b_32x3": 5.3e-3}
+# the same gate on the STRESS instance (block-final gamma ~ 1: the branch is as large as the trunk, so a defect in the branch's
+# kernels is not diluted by the identity path): measured clean in round 5 (profiles/r5/parity_full.jsonl) x 1.3
+BLOCK_BF16_TOL_STRESS = {"x3d_m": 1.2e-2, "slowfast_r50": 1.2e-2}
+# bench batch, per ROW against the bf16-storage oracle: round 4's measured worst row (4.1e-3 / 6.6e-3 / 1.2e-3 / 3.7e-3) x 1.3
+ROW_KERNEL_BF16 = {"x3d_m": 5.3e-3, "x3d_l": 8.6e-3, "slowfast_r50": 1.6e-3, "mvit_b_32x3": 4.9e-3}
 # stress instance: the larger of (measured on the MI355X in round 3, profiles/r3/parity_full.jsonl, x 1.3) and (1.35 x the
 # bf16-storage oracle's own answer to a ONE-ulp nudge of its fp32 values, tools/storage_floor.py: 1.6e-2 / 6.7e-2 / 9.3e-3 /
 # 3.2e-3) -- an implementation whose fp32 arithmetic differs in the last bit cannot agree with the emulation better than
@@ -83,6 +98,9 @@ def test_north_star_bench_batch_with_bench_streams_every_row(workload):
     _well_scaled(r)
     assert r["bf16_replay_equal"]
     assert r["bf16_vs_fp32_oracle"] <= BF16_TOL
+    # every row, normalised by the row's own logits
+    assert r["bf16_rows_worst"] <= ROW_KERNEL_BF16[workload]                                  # the kernels' own arithmetic
+    assert r["bf16_rows_worst_fp32"] <= max(BF16_TOL, 1.15 * r["storage_rows_worst"])         # bf16 storage is the floor
     assert r["top1_agree"] >= r["batch"] - 1
 
 
@@ -97,8 +115,51 @@ def test_every_block_teacher_forced_bf16(workload):
            "per_block": {k: float("%.3e" % v) for k, v in rows}}, "teacher-forced per block, bf16 deploy form vs fp32 oracle")
     expect = {"x3d_m": 26, "x3d_l": 55, "slowfast_r50": 32, "mvit_b_32x3": 16}[workload]
     assert len(rows) >= expect
-    bad = [(k, v) for k, v in rows if not v <= BLOCK_BF16_TOL]
+    bad = [(k, v) for k, v in rows if not v <= BLOCK_BF16_TOL[workload]]
     assert not bad, bad
+
+
+@pytest.mark.parametrize("workload", sorted(BLOCK_BF16_TOL_STRESS))
+def test_every_block_teacher_forced_bf16_on_the_stress_instance(workload):
+    """The kernel gate where a branch defect is not diluted by the identity path: block-final gamma ~ 1."""
+    from parity_blocks import blocks_case
+    rows = blocks_case(workload, "calibrated")
+    worst = max(rows, key=lambda t: t[1])
+    print("\n%s [calibrated]: %d blocks teacher-forced, worst %.2e at %s" % (workload, len(rows), worst[1], worst[0]))
+    _dump({"workload": workload, "fill": "calibrated", "blocks": len(rows), "worst": worst[1], "worst_block": worst[0],
+           "per_block": {k: float("%.3e" % v) for k, v in rows}}, "teacher-forced per block, stress instance")
+    bad = [(k, v) for k, v in rows if not v <= BLOCK_BF16_TOL_STRESS[workload]]
+    assert not bad, bad
+
+
+def test_the_block_gate_sees_a_five_percent_defect_in_one_filter_bank():
+    """Defect injection: conv_c of ONE X3D-M bottleneck scaled by 1.05 in the deploy form only.  On the stress
+    instance the teacher-forced block gate fails loudly; on `trained_like` the same defect hides below the gate (reported)."""
+    from parity_blocks import defect_case
+    r = defect_case("x3d_m", "blocks.2.res_blocks.1", scale=1.05)
+    print("\nx3d_m blocks.2.res_blocks.1, conv_c x 1.05: stress instance clean %.2e -> defect %.2e (gate %.1e); trained_like clean "
+          "%.2e -> defect %.2e (gate %.1e)" % (r["calibrated"]["clean"], r["calibrated"]["defect"], BLOCK_BF16_TOL_STRESS["x3d_m"],
+                                              r["trained_like"]["clean"], r["trained_like"]["defect"], BLOCK_BF16_TOL["x3d_m"]))
+    _dump(r, "defect injection: one conv_c filter bank x 1.05")
+    assert r["calibrated"]["clean"] <= BLOCK_BF16_TOL_STRESS["x3d_m"]
+    assert r["calibrated"]["defect"] > 1.5 * BLOCK_BF16_TOL_STRESS["x3d_m"]
+    assert r["trained_like"]["clean"] <= BLOCK_BF16_TOL["x3d_m"]
+
+
+@pytest.mark.parametrize("workload", WORKLOADS4)
+def test_second_instance_block_final_gamma_0p1_to_0p4(workload):
+    """The reported second case (round-4 verdict): the gamma range is not the only thing between pass and fail -- with
+    U(0.1, 0.4) the kernels' own arithmetic (vs the bf16-storage oracle) stays below 1e-2 and the distance to the fp32 oracle is
+    the storage floor of that instance (CPU, exact arithmetic) + 30 %."""
+    from parity_full import case
+    r = case(workload, "trained_like_wide", dtypes=("bf16",))
+    print("\n%s [block-final gamma U(0.1,0.4)]: bf16 vs fp32 oracle %.2e (bf16 storage alone %.2e) | vs bf16-storage oracle %.2e"
+          % (workload, r["bf16_vs_fp32_oracle"], r["storage_floor"], r["bf16_vs_emulated_oracle"]))
+    _dump(r, "second instance: block-final gamma U(0.1, 0.4), one clip")
+    _well_scaled(r)
+    assert r["bf16_vs_emulated_oracle"] <= BF16_TOL
+    assert r["bf16_vs_fp32_oracle"] <= max(BF16_TOL, 1.3 * r["storage_floor"])
+    assert r["top1_agree"] == 1
 
 
 @pytest.mark.parametrize("workload", WORKLOADS4)

@@ -1017,6 +1017,50 @@ def test_large_tile_gemm_kernel(ct, B, T, H, W, cin, cout, k, stride, act, res, 
     _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine)
 
 
+# ------------------------------------------------------------------ temporal-tap rotation / uniform-tap staging of the 128 x 128 GEMM
+@pytest.mark.parametrize("B,T,H,W,cin,cout", [
+    (2, 8, 16, 16, 64, 96),      # Ho*Wo % 128 == 0, cin % 64 == 0: rotation AND the uniform-tap fast path
+    (2, 8, 16, 16, 128, 256),
+    (2, 6, 16, 8, 72, 80),       # cin % 64 != 0: rotation without the fast path (per-chunk tap decoding)
+])
+def test_temporal_conv_tap_rotation_and_uniform_tap_staging(B, T, H, W, cin, cout):
+    """(3,1,1) convs, pt = 1, st = 1, whole tiles inside one frame: the rotated tap order (pv_gemm.hip geom_of) and the
+    wave-uniform tap staging are on by default -- against torch, and bit-for-bit against the same kernel with them switched off
+    except for the summation order of the three taps (no kernel-level case reached the rotated path)."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, T, H, W, cin, generator=g).to(dtype).cuda()
+    w = (torch.randn(cout, cin, 3, 1, 1, generator=g) * (3 * cin) ** -0.5).to(dtype).cuda()
+    shift = torch.randn(cout, generator=g).cuda()
+    want = F.relu(F.conv3d(x.float().permute(0, 4, 1, 2, 3), w.float(), padding=(1, 0, 0)) + shift.view(1, -1, 1, 1, 1))
+    cp = (cout + 7) // 8 * 8
+    wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous()
+    outs = {}
+    for knobs in ({"gemm_tap_rot": 1, "gemm_tmode": 1}, {"gemm_tap_rot": 0, "gemm_tmode": 1}, {"gemm_tap_rot": 1, "gemm_tmode": 0},
+                  {"gemm_tap_rot": 0, "gemm_tmode": 0}):
+        y = torch.full((B, T, H, W, cp), 5.0, dtype=dtype, device="cuda")
+        d = L.Conv3dDesc()
+        d.x, d.w, d.y, d.shift = x.data_ptr(), wp.data_ptr(), y.data_ptr(), shift.data_ptr()
+        d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * cin, T * H * W * cp, cin, cp
+        d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, cin, T, H, W, cout
+        d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = 3, 1, 1, 1, 1, 1, 1, 0, 0
+        d.act, d.a_act, d.dtype = L.ACT_RELU, L.ACT_NONE, L.PV_BF16
+        L.tune(conv_route=2, gemm8=0, gemm9=0, **knobs)
+        try:
+            call("pv_conv3d", d)
+            assert _routed_kernel(L.OP_CONV3D, d) == "gemm_glds_kernel"
+        finally:
+            L.tune(conv_route=0, gemm8=1, gemm9=1, gemm_tap_rot=1, gemm_tmode=1)
+        outs[tuple(sorted(knobs.items()))] = y
+        assert rel_err(y[..., :cout].permute(0, 4, 1, 2, 3), want) <= 1e-2
+    ys = list(outs.values())
+    for other in ys[1:]:       # the same three products summed in another order: agreement to bf16 rounding of the output
+        assert rel_err(other.float(), ys[0].float()) <= 8e-3
+    k = lambda rot, tm: (("gemm_tap_rot", rot), ("gemm_tmode", tm))
+    assert torch.equal(outs[k(0, 1)], outs[k(0, 0)])   # the fast path changes addresses, not arithmetic
+    assert torch.equal(outs[k(1, 1)], outs[k(1, 0)])
+
+
 # ------------------------------------------------------------------ 256 x 256 tiles, eight-phase main loop (pv_gemm9.hip, round 5)
 @pytest.mark.parametrize("B,T,H,W,cin,cout,k,stride,act,res,y_f32,affine", [
     (1, 1, 1, 1000, 256, 200, (1, 1, 1), (1, 1, 1), L.ACT_RELU, True, False, True),     # ragged M and N tails, 4 K tiles
@@ -1030,7 +1074,7 @@ def test_large_tile_gemm_kernel(ct, B, T, H, W, cin, cout, k, stride, act, res, 
     (16, 8, 16, 16, 256, 256, (3, 1, 1), (1, 1, 1), L.ACT_RELU, False, False, True),    # ... at res4's grid, 128 tiles
     (2, 4, 17, 13, 128, 136, (1, 3, 3), (1, 2, 2), L.ACT_RELU, True, False, True),      # conv_b (1,3,3), stride 2, odd grid
     (3, 4, 16, 16, 128, 256, (1, 3, 3), (1, 1, 1), L.ACT_RELU, False, False, True),     # conv_b (1,3,3): spatial padding
-    (2, 3, 9, 11, 64, 264, (3, 3, 3), (1, 1, 1), L.ACT_NONE, False, False, False),      # all three axes padded, 27 taps
+    (2, 3, 9, 11, 128, 264, (3, 3, 3), (1, 1, 1), L.ACT_NONE, False, False, False),     # all three axes padded, 27 taps
     (1, 32, 6, 6, 128, 256, (7, 1, 1), (4, 1, 1), L.ACT_RELU, False, False, True),      # lateral-shaped (7,1,1) / stride 4
     (2, 4, 16, 16, 256, 512, (1, 1, 1), (1, 2, 2), L.ACT_NONE, False, False, True),     # projection shortcut: strided 1x1x1
 ])

@@ -172,6 +172,39 @@ def blocks_case(workload, fill="trained_like"):
     return rows
 
 
+def defect_case(workload, block, scale=1.05, fills=("calibrated", "trained_like")):
+    """Defect injection: `block` = "blocks.S.res_blocks.I" of an X3D model, teacher-forced; the deploy form is
+    built twice -- as is, and with conv_c's filter bank scaled by `scale` (a 5 % arithmetic defect in one kernel's operand) --
+    and both are compared with the fp32 oracle's output of the UNTOUCHED block.  {fill: {"clean": e, "defect": e}}."""
+    assert workload in ("x3d_m", "x3d_l")
+    from bench import synth_input
+    from oracle import functional as OF
+    from parity_full import filled_model
+    S, I = int(block.split(".")[1]), int(block.split(".")[3])
+    out = {"workload": workload, "block": block, "scale": scale}
+    for fill in fills:
+        m, shape = filled_model(workload, fill)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        x = synth_input(shape, 1, 99)
+        with torch.no_grad():
+            h = OF.x3d_stem(sd, _q(x))
+            for s in range(1, S + 1):
+                for i in range(len(m.blocks[s].res_blocks)):
+                    if (s, i) == (S, I):
+                        break
+                    h = OF.x3d_res_block(sd, _q(h), "blocks.%d.res_blocks.%d" % (s, i), (1, 2, 2) if i == 0 else (1, 1, 1))
+            xin = _q(h)
+            want = OF.x3d_res_block(sd, xin, block, (1, 2, 2) if I == 0 else (1, 1, 1))
+            rb = m.blocks[S].res_blocks[I]
+            clean = _rel(_deploy_single(rb, xin), want)
+            bad = copy.deepcopy(rb)
+            bad.branch2.conv_c.weight.mul_(scale)
+            defect = _rel(_deploy_single(bad, xin), want)
+        out[fill] = {"clean": clean, "defect": defect}
+        torch.cuda.empty_cache()
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--workloads", default="x3d_m,x3d_l,slowfast_r50,mvit_b_32x3")
