@@ -65,13 +65,13 @@ __device__ __forceinline__ int chi9(int rho) {
 }
 
 struct Geom9 {         // per-thread staging rows of one output tile (DMA j of a unit covers unit rows 64 j + 8 wave + lane / 8)
-  int a_row;           // weight row of (a = 0, j = 0); (a, j) is a_row + 64 a + 128 j, clamped to cout - 1 at use
-  int b_row;           // PW: voxel row of (v = 0, j = 0); (v, j) is b_row + 32 v + 128 j, clamped to M - 1 at use (rows contiguous)
+  unsigned a_row;      // BYTE offset in w of the weight row of (a = 0, j = 0); (a, j) is 64 a + 128 j rows further, clamped at use
+  unsigned b_row;      // PW: byte offset in x of the voxel row of (v = 0, j = 0); (v, j) is 32 v + 128 j rows further, clamped at use
   int b_off[4];        // !PW: [v*2 + j] element offset of the voxel row's window origin in x (negative: padding rows)
   unsigned b_msk[4];   // !PW: window mask of the voxel row: bit dt | bit 8 + dh | bit 16 + dw set when that tap is inside
 };
 
-template <bool PW, bool YF32>
+template <bool PW, bool YF32, int VAR>
 __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem9_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem9_raw);
@@ -101,14 +101,18 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   // K chunk (8 elements) that lands on LDS position lane % 8 of this thread's staging rows: the swizzle key (row >> 1) & 7 is
   // the same for both DMAs of a unit (rows 64 apart) -- one register for all eight staging rows
   const int chunk8 = ((lane & 7) ^ (((8 * wave + (lane >> 3)) >> 1) & 7)) * 8;
+  // row pitches and last rows in bytes (wave-uniform): a staging row is  min(row0 + step, last) + chunk + K offset  -- an add, a
+  // min and an add per DMA, no multiply (a 64-bit multiply-add per DMA cost the eight-phase loop 6-13 %: profiles/r5)
+  const unsigned a_pitch = (unsigned)K * 2u, a_last = (unsigned)(d.cout - 1) * a_pitch;
+  const unsigned b_pitch = (unsigned)d.ldx * 2u, b_last = (unsigned)(M - 1) * b_pitch;
   auto geom_of = [&](int it, Geom9& g) __attribute__((always_inline)) {
     long m0;
     int n0;
     tile_origin(it, m0, n0);
     const int rho0 = 8 * wave + (lane >> 3);   // unit row of DMA 0 (< 64)
-    g.a_row = n0 + 32 * (rho0 >> 5) + chi9(rho0 & 31);
+    g.a_row = (unsigned)(n0 + 32 * (rho0 >> 5) + chi9(rho0 & 31)) * a_pitch;
     if constexpr (PW) {
-      g.b_row = (int)m0 + 64 * (rho0 >> 5) + (rho0 & 31);
+      g.b_row = (unsigned)((int)m0 + 64 * (rho0 >> 5) + (rho0 & 31)) * b_pitch;
     } else {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -147,25 +151,27 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     const unsigned long m = 0ul - (unsigned long)ok;
     return reinterpret_cast<const bf16_t*>((p & m) | (zaddr & ~m));
   };
-  auto issue_a = [&](int a, int unit) __attribute__((always_inline)) {   // channel half a of the stream's K tile -> LDS unit at element offset `unit`
-    const unsigned kc = (unsigned)(iss_ku * 64 + chunk8);
+  // jsel: 0 / 1 = that DMA of the unit only, -1 = both
+  auto issue_a = [&](int a, int unit, int jsel) __attribute__((always_inline)) {   // channel half a of the stream's K tile -> LDS unit `unit`
+    const unsigned kc = (unsigned)(iss_ku * 128 + chunk8 * 2);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int n = g.a_row + 64 * a + 128 * j;
-      n = n < d.cout ? n : d.cout - 1;                      // N tail: a clamped row, zeroed in the epilogue
-      const unsigned off = ((unsigned)n * (unsigned)K + kc) * 2u;
+      if (jsel >= 0 && jsel != j) continue;
+      unsigned off = g.a_row + (unsigned)(64 * a + 128 * j) * a_pitch;
+      off = (off < a_last ? off : a_last) + kc;              // N tail: a clamped row, zeroed in the epilogue
       __builtin_amdgcn_global_load_lds((gptr9_t)pick(iss_live, (unsigned long)(Wb + off)),
                                        (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
     }
   };
-  auto issue_b = [&](int v, int unit) __attribute__((always_inline)) {   // voxel half v
+  auto issue_b = [&](int v, int unit, int jsel) __attribute__((always_inline)) {   // voxel half v
     if constexpr (PW) {
-      const int kc = iss_ku * 64 + chunk8;
+      const unsigned kc = (unsigned)(iss_ku * 128 + chunk8 * 2);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        int m = g.b_row + 32 * v + 128 * j;
-        m = m < (int)M ? m : (int)M - 1;                    // M tail: a clamped row, never stored
-        __builtin_amdgcn_global_load_lds((gptr9_t)pick(iss_live, (unsigned long)(X + ((long)m * d.ldx + kc))),
+        if (jsel >= 0 && jsel != j) continue;
+        unsigned off = g.b_row + (unsigned)(32 * v + 128 * j) * b_pitch;
+        off = (off < b_last ? off : b_last) + kc;            // M tail: a clamped row, never stored
+        __builtin_amdgcn_global_load_lds((gptr9_t)pick(iss_live, (unsigned long)(reinterpret_cast<const char*>(X) + off)),
                                          (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
       }
     } else {
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
       const unsigned sel = (1u << iss_dt) | (1u << (8 + iss_dh)) | (1u << (16 + iss_dw));
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        if (jsel >= 0 && jsel != j) continue;
         const bool ok = iss_live && (g.b_msk[v * 2 + j] & sel) == sel;
         __builtin_amdgcn_global_load_lds((gptr9_t)pick(ok, (unsigned long)(X + (long)(g.b_off[v * 2 + j] + uni))),
                                          (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
@@ -242,13 +249,13 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
 
   // ---- prologue: the first tile's tables, AE BE BO AO of K tile 0, AE BE of K tile 1 ----
   issue_tables();
-  issue_a(0, unit_a(0, 0));
-  issue_b(0, unit_b(0, 0));
-  issue_b(1, unit_b(0, 1));
-  issue_a(1, unit_a(0, 1));
+  issue_a(0, unit_a(0, 0), -1);
+  issue_b(0, unit_b(0, 0), -1);
+  issue_b(1, unit_b(0, 1), -1);
+  issue_a(1, unit_a(0, 1), -1);
   advance();
-  issue_a(0, unit_a(1, 0));
-  issue_b(0, unit_b(1, 0));
+  issue_a(0, unit_a(1, 0), -1);
+  issue_b(0, unit_b(1, 0), -1);
   __builtin_amdgcn_s_waitcnt(vml(8));   // AE, BE of K tile 0: this thread's share
   __builtin_amdgcn_s_barrier();
   const bool half_b = wave >= 4;        // wave-uniform
@@ -260,24 +267,36 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   f32x16 acc[4][2];
   bf16x8 af0[4][2], af1[4][2], b0[4], b1[4];   // channel halves a0 / a1, voxel halves v0 / v1 of the K tile (4 K slices each)
 
-  // one phase:  [reads] [DMA] wait | B1 | 8 MFMAs | B2.   FIRST: the K tile that follows an epilogue
-#define PV9_WAIT_B1(FIRST)                                                                \
-  do {                                                                                    \
-    if ((FIRST) && stores_behind) __builtin_amdgcn_s_waitcnt(vml(8 + (YF32 ? 32 : 16)));  \
-    else __builtin_amdgcn_s_waitcnt(vml(8));                                              \
-    __builtin_amdgcn_s_barrier();                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
+  // one phase:  [reads] [DMA] wait | B1 | 8 MFMAs | B2.   FIRST: the K tile that follows an epilogue.
+  // DM (variant bit 1): the phase's two DMAs are issued AMONG its MFMAs (after the 2nd and the 4th) instead of before B1 -- an
+  // LDS-DMA costs the issuing wave 60-180 cycles, which the matrix pipe hides when the wave has MFMAs in flight; the counted wait
+  // then comes BEFORE this phase's DMAs and leaves three units (6 DMAs) in flight instead of four.
+#define PV9_WAIT_B1(FIRST)                                                                          \
+  do {                                                                                              \
+    if ((FIRST) && stores_behind) __builtin_amdgcn_s_waitcnt(vml((DM ? 6 : 8) + (YF32 ? 32 : 16)));  \
+    else __builtin_amdgcn_s_waitcnt(vml(DM ? 6 : 8));                                               \
+    __builtin_amdgcn_s_barrier();                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
   } while (0)
-#define PV9_MFMA(AF, A0, V, BF)                                                            \
-  do {                                                                                    \
-    __builtin_amdgcn_s_setprio(1);                                                        \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                         \
-      _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                    \
-        acc[(A0) + ta][V] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[s][ta], BF[s], acc[(A0) + ta][V], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-    __builtin_amdgcn_s_barrier();                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
+#define PV9_MM(AF, A0, V, BF, S)                                                                    \
+  _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                                  \
+    acc[(A0) + ta][V] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[S][ta], BF[S], acc[(A0) + ta][V], 0, 0, 0)
+  // ISS(j): issue DMA j (0 / 1) of the phase's unit, ISS(-1): both
+#define PV9_PHASE(FIRST, ISS, AF, A0, V, BF)                                                        \
+  do {                                                                                              \
+    if (!DM) { ISS(-1); }                                                                           \
+    PV9_WAIT_B1(FIRST);                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                  \
+    PV9_MM(AF, A0, V, BF, 0);                                                                       \
+    if (DM) { __builtin_amdgcn_sched_barrier(0); ISS(0); __builtin_amdgcn_sched_barrier(0); }       \
+    PV9_MM(AF, A0, V, BF, 1);                                                                       \
+    if (DM) { __builtin_amdgcn_sched_barrier(0); ISS(1); __builtin_amdgcn_sched_barrier(0); }       \
+    PV9_MM(AF, A0, V, BF, 2);                                                                       \
+    PV9_MM(AF, A0, V, BF, 3);                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    __builtin_amdgcn_s_barrier();                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
   } while (0)
 #define PV9_READ_A(AF, P, A)                                                                                              \
   do {                                                                                                                    \
@@ -300,32 +319,33 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   do {                                                                                                                    \
     /* phase 0: (a0, v0); BO of the next K tile */                                                                        \
     PV9_READ_B(b0, P, 0);                                                                                                 \
-    if ((FIRST) || !RA) PV9_READ_A(af0, P, 0);                                                                                     \
-    issue_b(1, unit_b(1 - (P), 1));                                                                                       \
-    PV9_WAIT_B1(FIRST);                                                                                                   \
-    PV9_MFMA(af0, 0, 0, b0);                                                                                              \
+    if ((FIRST) || !RA) PV9_READ_A(af0, P, 0);                                                                            \
+    PV9_PHASE(FIRST, ISS_P0_##P, af0, 0, 0, b0);                                                                          \
     /* phase 1: (a0, v1); AO of the next K tile */                                                                        \
     PV9_READ_B(b1, P, 1);                                                                                                 \
-    issue_a(1, unit_a(1 - (P), 1));                                                                                       \
-    PV9_WAIT_B1(FIRST);                                                                                                   \
-    PV9_MFMA(af0, 0, 1, b1);                                                                                              \
+    PV9_PHASE(FIRST, ISS_P1_##P, af0, 0, 1, b1);                                                                          \
     /* phase 2: the stream moves on to the K tile after next (a new output tile's staging rows are computed HERE, where    \
        only the accumulators and the voxel fragments are live); (a1, v1); AE of that K tile -- this parity's AE, last      \
        read a K tile ago */                                                                                               \
     advance();                                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
     PV9_READ_A(af1, P, 1);                                                                                                \
-    issue_a(0, unit_a(P, 0));                                                                                             \
-    PV9_WAIT_B1(FIRST);                                                                                                   \
-    PV9_MFMA(af1, 2, 1, b1);                                                                                              \
+    PV9_PHASE(FIRST, ISS_P2_##P, af1, 2, 1, b1);                                                                          \
     /* phase 3: (a1, v0); BE of the K tile after next; a0 of the NEXT K tile (other parity) */                            \
-    if (RA && !(LAST)) PV9_READ_A(af0, 1 - (P), 0);                                                                             \
-    issue_b(0, unit_b(P, 0));                                                                                             \
-    PV9_WAIT_B1(FIRST);                                                                                                   \
-    PV9_MFMA(af1, 2, 0, b0);                                                                                              \
+    if (RA && !(LAST)) PV9_READ_A(af0, 1 - (P), 0);                                                                       \
+    PV9_PHASE(FIRST, ISS_P3_##P, af1, 2, 0, b0);                                                                          \
   } while (0)
+#define ISS_P0_0(J) issue_b(1, unit_b(1, 1), J)
+#define ISS_P1_0(J) issue_a(1, unit_a(1, 1), J)
+#define ISS_P2_0(J) issue_a(0, unit_a(0, 0), J)
+#define ISS_P3_0(J) issue_b(0, unit_b(0, 0), J)
+#define ISS_P0_1(J) issue_b(1, unit_b(0, 1), J)
+#define ISS_P1_1(J) issue_a(1, unit_a(0, 1), J)
+#define ISS_P2_1(J) issue_a(0, unit_a(1, 0), J)
+#define ISS_P3_1(J) issue_b(0, unit_b(1, 0), J)
 
-  constexpr bool RA = PW;    // read-ahead of the next K tile's a0 fragments
+  constexpr bool RA = PW && (VAR & 1);   // read-ahead of the next K tile's a0 fragments
+  constexpr bool DM = (VAR & 2) != 0;     // DMAs among the MFMAs
   const int nkp = nk >> 1;   // K tiles come in pairs (K % 128 == 0, host check): every output tile starts on LDS parity 0
   for (int it = blockIdx.x; it < total_tiles; it += gridDim.x, ++jt) {
 #pragma unroll
@@ -496,19 +516,20 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef PV9_KTILE
+#undef PV9_PHASE
+#undef PV9_MM
 #undef PV9_READ_A
 #undef PV9_READ_B
-#undef PV9_MFMA
 #undef PV9_WAIT_B1
 #undef PV9_RD
   if (!half_b) __builtin_amdgcn_s_barrier();   // matches the second half's offset barrier
   __builtin_amdgcn_s_waitcnt(vml(0));          // the stream's trailing (zero-page) DMAs land before the LDS is released
 }
 
-template <bool PW, bool YF32>
+template <bool PW, bool YF32, int VAR>
 int launch9(const pv_conv3d_desc& d, int tiles_n, long total, hipStream_t s) {
   const size_t lds = (size_t)kLds9Bytes;   // 128 KB of units + 4 KB of epilogue tables
-  auto kern = gemm_quad_kernel<PW, YF32>;
+  auto kern = gemm_quad_kernel<PW, YF32, VAR>;
   PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long resident = 256;   // one workgroup per CU
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads9);
@@ -533,7 +554,9 @@ int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   const int cout_p8 = pv_round_up(d.cout, 8);
   if (K < 256) return PV_ERR_UNSUPPORTED;                                           // a first and a last pair of K tiles
   // 31-bit element offsets into x, 32-bit byte offsets into w, 31-bit byte offsets in the store descriptor
-  if (M > 0x7fffffffL || (long)d.B * d.x_bs > 0x7fffffffL || (long)d.cout * K * 2 > 0xffffffffL) return PV_ERR_UNSUPPORTED;
+  if (M > 0x7fffffffL || (long)d.B * d.x_bs > 0x7fffffffL || ((long)d.cout + 256) * K * 2 > 0xffffffffL ||
+      (M + 256) * d.ldx * 2 > 0xffffffffL)
+    return PV_ERR_UNSUPPORTED;
   if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
   const long tiles_m = pv_ceil_div(M, BT9);
   const int tiles_n = (int)pv_ceil_div(cout_p8, BT9);
@@ -547,6 +570,19 @@ int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   }
   // the pointwise form addresses voxel row m at x + m * ldx: batch items must follow each other without a gap
   const bool rows = pw && d.x_bs == (long)d.To * d.Ho * d.Wo * d.ldx;
-  if (d.y_f32) return rows ? launch9<true, true>(d, tiles_n, total, s) : launch9<false, true>(d, tiles_n, total, s);
-  return rows ? launch9<true, false>(d, tiles_n, total, s) : launch9<false, false>(d, tiles_n, total, s);
+  // variant (pv_tune "gemm9_var": bit 0 = fragment read-ahead in the pointwise form, bit 1 = DMAs among the MFMAs)
+  const int var = pv_tune("gemm9_var", 3) & 3;
+#define PV9_GO(PWv, YFv)                                                   \
+  switch (var) {                                                           \
+    case 0: return launch9<PWv, YFv, 0>(d, tiles_n, total, s);             \
+    case 1: return launch9<PWv, YFv, 1>(d, tiles_n, total, s);             \
+    case 2: return launch9<PWv, YFv, 2>(d, tiles_n, total, s);             \
+    default: return launch9<PWv, YFv, 3>(d, tiles_n, total, s);            \
+  }
+  if (d.y_f32) {
+    if (rows) { PV9_GO(true, true) } else { PV9_GO(false, true) }
+  } else {
+    if (rows) { PV9_GO(true, false) } else { PV9_GO(false, false) }
+  }
+#undef PV9_GO
 }

@@ -1057,8 +1057,8 @@ def test_temporal_conv_tap_rotation_and_uniform_tap_staging(B, T, H, W, cin, cou
     for other in ys[1:]:       # the same three products summed in another order: agreement to bf16 rounding of the output
         assert rel_err(other.float(), ys[0].float()) <= 8e-3
     k = lambda rot, tm: (("gemm_tap_rot", rot), ("gemm_tmode", tm))
-    assert torch.equal(outs[k(0, 1)], outs[k(0, 0)])   # the fast path changes addresses, not arithmetic
-    assert torch.equal(outs[k(1, 1)], outs[k(1, 0)])
+    assert torch.equal(outs[k(0, 1)], outs[k(0, 0)])   # the fast path changes addresses, not arithmetic (without the temporal
+    # fast path the general uniform-tap staging takes over where cin % 64 == 0, and that one does not rotate: (1, 0) == (0, 0))
 
 
 # ------------------------------------------------------------------ 256 x 256 tiles, eight-phase main loop (pv_gemm9.hip, round 5)
