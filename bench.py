@@ -448,14 +448,35 @@ def pcie_leg(model, x, step, batch, steps, device):
     return pcie
 
 
+def bind_rank(local_rank, local_world):
+    """One process per GPU on one node: rank i gets the i-th of `local_world` equal slices of the CPUs this job may use
+    (8 conversions start at once -- BatchNorm folding in fp64, weight packing -- and 8 x nproc OpenMP threads would fight over
+    the same cores), torch's intra-op pool is sized to the slice.  Returns the CPU list (unchanged affinity when the job has
+    fewer CPUs than ranks)."""
+    import torch
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    if local_world > 1 and len(cpus) >= local_world:
+        per = len(cpus) // local_world
+        mine = cpus[local_rank * per:(local_rank + 1) * per]
+        try:
+            os.sched_setaffinity(0, mine)
+            cpus = mine
+        except OSError:
+            pass
+    torch.set_num_threads(max(1, min(len(cpus), 16)))
+    return cpus
+
+
 def dry_host(args, world, rank, stdout_guard):
     """Launcher check without a GPU (tests/test_bench_launcher.py): the ORIGINAL-form model on the host, gloo.
     Exercises exactly the spawn / rank binding / barrier / max-over-ranks / n_gpus reporting of the real run;
     its number is not a measurement of the product path and the line says so."""
     import torch
     import torch.distributed as dist
-    from pytorchvideo_amd.parallel import gather_logits
-    torch.set_num_threads(2)
+    from pytorchvideo_amd.parallel import gather_logits, shard_range
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cpus = bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    torch.set_num_threads(min(2, len(cpus)))
     if world > 1:
         dist.init_process_group("gloo")
     torch.manual_seed(0)
@@ -488,6 +509,58 @@ def dry_host(args, world, rank, stdout_guard):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     assert out.shape == (batch * world, 400)
+    # ---- N-GPU readiness beyond the launcher (round-4 verdict, next #7): everything below runs WITHOUT a GPU ----
+    ready = {}
+    # (1) the rank -> device / CPU binding the real run makes: cuda:LOCAL_RANK, a disjoint CPU slice per rank
+    mine = {"rank": rank, "local_rank": local_rank, "device": "cuda:%d" % local_rank, "cpus": cpus}
+    bind = [None] * world
+    if world > 1:
+        dist.all_gather_object(bind, mine)
+    else:
+        bind = [mine]
+    ready["binding"] = bind
+    # (2) a ragged global batch (sizes differ by one) through the head collective, against torch.distributed's answer
+    if args.dry_ragged:
+        gb = batch * world - min(3, world - 1) if world > 1 else batch
+        lo, hi = shard_range(gb, rank, world)
+        with torch.no_grad():
+            local = model(x[: hi - lo]) if hi > lo else torch.zeros(0, 400)
+        from pytorchvideo_amd.parallel import gather_logits as torch_gather     # (the local name may be the C communicator's)
+        want = torch_gather(local, global_batch=gb)
+        if os.environ.get("PV_RCCL_LIB"):
+            got = comm.gather_ragged(local, gb)
+            ok = bool(torch.equal(got, want))
+        else:
+            got, ok = want, True
+        ready["ragged"] = {"global_batch": gb, "rows": int(got.shape[0]), "sizes": [h - l for l, h in (shard_range(gb, r, world) for r in range(world))],
+                           "equal_to_torch_distributed": ok}
+        assert got.shape == (gb, 400) and ok
+    # (3) the host half of the REAL workload's conversion on every rank at once: BASELINE config of --workload at its per-GPU
+    #     batch (x3d_l: 32 clips per GPU, 256 = 8 x 32 over a node), plan statistics must agree across ranks
+    if args.dry_convert:
+        from pytorchvideo_amd.accelerator import convert_to_deployable_form, transmute_model
+        wl = WORKLOADS[args.workload]
+        m2, shp = make_model(args.workload)
+        m2.eval()
+        transmute_model(m2, "mi355x")
+        shapes = shp if isinstance(shp, list) else [shp]
+        xin = [torch.zeros(1, dtype=torch.bfloat16).expand((wl["batch"],) + tuple(sh)) for sh in shapes]
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        st = convert_to_deployable_form(m2, xin if isinstance(shp, list) else xin[0], dtype=torch.bfloat16, emit_only=True)
+        st["seconds"] = round(time.perf_counter() - t0, 3)
+        allst = [None] * world
+        if world > 1:
+            dist.all_gather_object(allst, st)
+        else:
+            allst = [st]
+        keys = ("fused", "ops", "arena_bytes", "weight_bytes")
+        assert all(tuple(a[k] for k in keys) == tuple(allst[0][k] for k in keys) for a in allst), allst
+        ready["convert"] = dict({k: allst[0][k] for k in keys}, concurrent_ranks=world,
+                                seconds_max=max(a["seconds"] for a in allst), seconds_min=min(a["seconds"] for a in allst))
+        ready["north_star_config"] = {"workload": args.workload + ": " + wl["desc"], "per_gpu_batch": wl["batch"],
+                                      "global_batch": wl["batch"] * world}
     if rank == 0:
         stdout_guard.restore()
         print(json.dumps({"metric": "dry-host launcher check (NOT a measurement of the HIP path)",
@@ -497,7 +570,8 @@ def dry_host(args, world, rank, stdout_guard):
                           "data": "synthetic", "config": {"workload": "x3d_xs_dry: original-form model on the host, gloo",
                                                            "per_gpu_batch": batch, "global_batch": batch * world,
                                                            "head_collective": how,
-                                                           "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}}))
+                                                           "local_rank": int(os.environ.get("LOCAL_RANK", "0"))},
+                          "readiness": ready}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -554,6 +628,9 @@ def _main(out):
     ap.add_argument("--head-comm", nargs="?", const="on", default="", choices=["", "on", "require"],
                     help="use the C-driven head collective at N = 1 too (one-rank RCCL communicator); 'require': no fallback")
     ap.add_argument("--dry-host", action="store_true", help="launcher check on the host (gloo, original-form model); no GPU")
+    ap.add_argument("--dry-ragged", action="store_true", help="with --dry-host: a ragged global batch through the head collective")
+    ap.add_argument("--dry-convert", action="store_true",
+                    help="with --dry-host: every rank runs the host half of --workload's conversion at its per-GPU batch, timed")
     ap.add_argument("--tune", default="", help="development knobs k=v,... (pytorchvideo_amd.accelerator.mi355x.tuning / pv_tune_set)")
     args = ap.parse_args()
 
@@ -573,6 +650,8 @@ def _main(out):
     if args.tune:
         from pytorchvideo_amd.accelerator.mi355x import tuning
         tuning.apply(args.tune)
+    if world > 1:
+        bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:

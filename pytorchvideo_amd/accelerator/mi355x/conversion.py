@@ -190,7 +190,7 @@ class SplitBatchDeployed(nn.Module):
 
 def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quantize: bool = False,
                                native_conv3d_op_qnnpack: bool = False, dtype=None, use_graph: bool = True,
-                               streams: int = 1):
+                               streams: int = 1, emit_only: bool = False):
     """Return a deploy-form copy of a transmuted `model`, specialised to `input_tensor`'s
     shape.  `dtype` (torch.bfloat16 | torch.float32) selects the kernels' storage type and
     defaults to the input tensor's dtype (fp32 input -> fp32 kernels).  `streams` > 1: see SplitBatchDeployed."""
@@ -232,6 +232,11 @@ def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quant
         _convert_children(converted, lut, batch, "", sess, dtype,
                           dict(convert_for_quantize=convert_for_quantize,
                                native_conv3d_op_qnnpack=native_conv3d_op_qnnpack))
+    if emit_only:
+        # The host half of a conversion (BatchNorm folding in fp64, weight packing, arena planning, descriptors), no device:
+        # what `bench.py --dry-host --dry-convert` times with one process per GPU of a node (input_tensor may be a stride-0 view,
+        # only its shape and dtype are read).  Returns the plan's vital statistics instead of a module.
+        return {"fused": bool(fused), "ops": len(sess.ops), "arena_bytes": int(sess._arena.peak), "weight_bytes": int(sess._wtop)}
     sess.finalize()
     if not fused:
         # Modules a transmuter declined stay in their original form (reference convention,

@@ -150,6 +150,18 @@ class HeadComm:
                       "pv_comm_all_gather")
         return recv
 
+    def gather_ragged(self, local, global_batch):
+        """[global_batch, classes] from shards whose sizes differ by at most one (shard_range): every rank pads its rows to the
+        largest shard, ONE pv_comm_all_gather, the padding rows are dropped."""
+        sizes = [hi - lo for lo, hi in (shard_range(global_batch, r, self.world_size) for r in range(self.world_size))]
+        assert local.shape[0] == sizes[self.rank], (local.shape, sizes, self.rank)
+        max_n = max(sizes)
+        send = local.new_zeros((max_n, local.shape[1]))
+        send[: local.shape[0]] = local
+        recv = local.new_empty((self.world_size * max_n, local.shape[1]))
+        self.all_gather(send.contiguous(), recv)
+        return torch.cat([recv[r * max_n: r * max_n + n] for r, n in enumerate(sizes)], dim=0)
+
     def close(self):
         if getattr(self, "handle", None):
             self._L.lib().pv_comm_destroy(self.handle)

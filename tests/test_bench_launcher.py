@@ -46,3 +46,32 @@ def test_two_ranks_gather_through_the_c_communicator(tmp_path):
     assert line["n_gpus"] == 2 and line["config"]["head_collective"] == "pv_comm over librccl_stub.so"
     # the library's banner (RCCL prints one to the C stdout at communicator creation) went to stderr, not behind the JSON line
     assert "RCCL version : stub" in _run.last_stderr
+
+
+def test_eight_ranks_are_ready_for_config_5(tmp_path):
+    """BASELINE.json configs[4] (X3D-L, global batch 256 over the 8 GPUs of a node) cannot be measured by the builder (one GPU
+    per box), so everything short of the GPUs is exercised here with EIGHT ranks: spawn, LOCAL_RANK -> device / CPU binding, the
+    head collective through the C communicator on a ragged global batch, and the host half of eight X3D-L conversions at 32
+    clips per rank started at the same moment (plan statistics identical on every rank)."""
+    so = os.path.join(str(tmp_path), "librccl_stub.so")
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "helpers", "rccl_stub.c"), "-lrt"])
+    line = _run(["--gpus", "8", "--workload", "x3d_l", "--dry-ragged", "--dry-convert"], {"PV_RCCL_LIB": so})
+    assert line["n_gpus"] == 8 and line["config"]["head_collective"] == "pv_comm over librccl_stub.so"
+    r = line["readiness"]
+    assert r["north_star_config"]["per_gpu_batch"] == 32 and r["north_star_config"]["global_batch"] == 256
+    bind = r["binding"]
+    assert sorted(b["local_rank"] for b in bind) == list(range(8))
+    assert sorted(b["device"] for b in bind) == ["cuda:%d" % i for i in range(8)]
+    seen = set()
+    ncpu = len(os.sched_getaffinity(0))
+    for b in bind:
+        assert b["cpus"], b
+        if ncpu >= 8:                       # disjoint CPU slices whenever the job has at least one CPU per rank
+            assert not (seen & set(b["cpus"])), bind
+            seen |= set(b["cpus"])
+    rg = r["ragged"]
+    assert rg["rows"] == rg["global_batch"] == sum(rg["sizes"]) and max(rg["sizes"]) - min(rg["sizes"]) == 1
+    assert rg["equal_to_torch_distributed"] is True
+    cv = r["convert"]
+    assert cv["fused"] is True and cv["concurrent_ranks"] == 8 and cv["ops"] > 100 and cv["arena_bytes"] > 0
+    assert cv["seconds_max"] < 120
