@@ -53,7 +53,9 @@ constexpr int LDS9_ELEMS = 8 * UNIT9;   // 128 KB
 __device__ __forceinline__ constexpr int unit_a(int P, int a) { return (2 * P + a) * UNIT9; }
 __device__ __forceinline__ constexpr int unit_b(int P, int v) { return (4 + 2 * P + v) * UNIT9; }
 constexpr int kTab9 = LDS9_ELEMS * 2;       // byte offset of the epilogue tables: [tile parity][scale 256 f32 | shift 256 f32]
-constexpr int kLds9Bytes = kTab9 + 2 * 2048;
+constexpr int kMisc9 = kTab9 + 2 * 2048;    // one word for workgroup broadcasts (16 bytes)
+constexpr int kGeo9 = kMisc9 + 16;          // implicit-GEMM staging geometry: 32 bytes per thread
+constexpr int kLds9Bytes = kGeo9 + kThreads9 * 32;
 constexpr int kRegionB9 = 4 * UNIT9 * 2;   // byte offset of the voxel units (folded into the read base: immediates stay < 64 K)
 
 typedef const __attribute__((address_space(1))) void* gptr9_t;
@@ -67,12 +69,15 @@ __device__ __forceinline__ int chi9(int rho) {
 struct Geom9 {         // per-thread staging rows of one output tile (DMA j of a unit covers unit rows 64 j + 8 wave + lane / 8)
   unsigned a_row;      // BYTE offset in w of the weight row of (a = 0, j = 0); (a, j) is 64 a + 128 j rows further, clamped at use
   unsigned b_row;      // PW: byte offset in x of the voxel row of (v = 0, j = 0); (v, j) is 32 v + 128 j rows further, clamped at use
-  int b_off[4];        // !PW: [v*2 + j] element offset of the voxel row's window origin in x (negative: padding rows)
-  unsigned b_msk[4];   // !PW: window mask of the voxel row: bit dt | bit 8 + dh | bit 16 + dw set when that tap is inside
+  // !PW: the four voxel rows' window origins (element offsets in x, negative for padding rows) and window masks (bit dt | bit
+  // 8 + dh | bit 16 + dw set when that tap lies inside the image) do not fit the register budget next to 128 accumulators and
+  // 64 fragment registers: they live in 32 bytes of LDS per thread, [v][off j0, off j1, mask j0, mask j1], written per tile
+  // and fetched by one ds_read_b128 in the phase that issues the voxel half (each thread reads only what it wrote)
 };
 
 template <bool PW, bool YF32, int VAR>
-__global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles) {
+__global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles, int splits) {
+  // total_tiles counts WORK ITEMS: output tiles x K slices (splits = 1: the tiles themselves)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem9_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem9_raw);
 
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   const int S_out = d.To * d.Ho * d.Wo;
   const long M = (long)d.B * S_out;
   const int K = d.kt * d.kh * d.kw * d.cin;
-  const int nk = K >> 6;
+  const int nk = (K >> 6) / splits;   // K tiles per work item
   const int cout_p8 = pv_round_up(d.cout, 8);
   const int dil_t = d.dil_t > 1 ? d.dil_t : 1, dil_h = d.dil_h > 1 ? d.dil_h : 1, dil_w = d.dil_w > 1 ? d.dil_w : 1;
   const bf16_t* __restrict__ X = static_cast<const bf16_t*>(d.x);
@@ -91,10 +96,14 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   const unsigned long zaddr = (unsigned long)reinterpret_cast<const bf16_t*>(pv_zero_page9);
 
   // ---- staging rows of this thread (the same for every unit): DMA j covers unit rows 64 j + 8 wave + lane / 8 ----
-  auto tile_origin = [&](int it, long& m0, int& n0) __attribute__((always_inline)) {   // XCD-aware tile order (bijective for any tile count)
+  // work item -> (output tile, K slice), XCD-aware (bijective for any count; the slices of a tile are consecutive items: they run
+  // on one XCD, whose L2 then carries their partial tiles)
+  auto tile_origin = [&](int it, long& m0, int& n0, int& tile, int& slice) __attribute__((always_inline)) {
     const int xcd = it & 7, slot = it >> 3;
     const int qn = total_tiles >> 3, rn = total_tiles & 7;
-    const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+    const int idx = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+    tile = idx / splits;
+    slice = idx - tile * splits;
     m0 = (long)(tile / tiles_n) * BT9;
     n0 = (tile % tiles_n) * BT9;
   };
@@ -105,10 +114,21 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   // min and an add per DMA, no multiply (a 64-bit multiply-add per DMA cost the eight-phase loop 6-13 %: profiles/r5)
   const unsigned a_pitch = (unsigned)K * 2u, a_last = (unsigned)(d.cout - 1) * a_pitch;
   const unsigned b_pitch = (unsigned)d.ldx * 2u, b_last = (unsigned)(M - 1) * b_pitch;
+  int* geo = reinterpret_cast<int*>(smem9_raw + kGeo9) + tid * 8;   // (!PW) this thread's staging geometry
+  int iss_kt0 = 0;   // first K tile of the stream's work item (its slice of the reduction)
+  int iss_c0 = 0, iss_dt = 0, iss_dh = 0, iss_dw = 0;   // channel offset inside the tap, tap coordinates (wave-uniform)
   auto geom_of = [&](int it, Geom9& g) __attribute__((always_inline)) {
     long m0;
-    int n0;
-    tile_origin(it, m0, n0);
+    int n0, tile, slice;
+    tile_origin(it, m0, n0, tile, slice);
+    iss_kt0 = slice * nk;
+    if constexpr (!PW) {
+      const int tap = (iss_kt0 * 64) / d.cin;
+      iss_c0 = iss_kt0 * 64 - tap * d.cin;
+      iss_dw = tap % d.kw;
+      iss_dh = (tap / d.kw) % d.kh;
+      iss_dt = tap / (d.kw * d.kh);
+    }
     const int rho0 = 8 * wave + (lane >> 3);   // unit row of DMA 0 (< 64)
     g.a_row = (unsigned)(n0 + 32 * (rho0 >> 5) + chi9(rho0 & 31)) * a_pitch;
     if constexpr (PW) {
@@ -126,7 +146,7 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
           const unsigned r2 = sp - to * (unsigned)(d.Ho * d.Wo);
           const unsigned ho = r2 / (unsigned)d.Wo;
           const int t0 = (int)to * d.st - d.pt, h0 = (int)ho * d.sh - d.ph, w0 = (int)(r2 - ho * (unsigned)d.Wo) * d.sw - d.pw;
-          g.b_off[v * 2 + j] = (int)((long)b * d.x_bs + ((long)(t0 * d.Hi + h0) * d.Wi + w0) * d.ldx) + chunk8;
+          geo[v * 4 + j] = (int)((long)b * d.x_bs + ((long)(t0 * d.Hi + h0) * d.Wi + w0) * d.ldx) + chunk8;
           unsigned msk = 0u;
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
@@ -134,7 +154,7 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
             if (q < d.kh && (unsigned)(h0 + q * dil_h) < (unsigned)d.Hi) msk |= 1u << (8 + q);
             if (q < d.kw && (unsigned)(w0 + q * dil_w) < (unsigned)d.Wi) msk |= 1u << (16 + q);
           }
-          g.b_msk[v * 2 + j] = msk;
+          geo[v * 4 + 2 + j] = (int)msk;
         }
     }
   };
@@ -143,7 +163,6 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   Geom9 g;
   int iss_it = blockIdx.x, iss_ku = 0, iss_jt = 0;   // work item, K tile inside it, this workgroup's tile count
   bool iss_live = iss_it < total_tiles;
-  int iss_c0 = 0, iss_dt = 0, iss_dh = 0, iss_dw = 0;   // channel offset inside the tap, tap coordinates
   geom_of(iss_live ? iss_it : 0, g);
 
   // source selection with bit masks, not `?:` (a select between two pointers becomes two exec-masked DMAs)
@@ -153,7 +172,7 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   };
   // jsel: 0 / 1 = that DMA of the unit only, -1 = both
   auto issue_a = [&](int a, int unit, int jsel) __attribute__((always_inline)) {   // channel half a of the stream's K tile -> LDS unit `unit`
-    const unsigned kc = (unsigned)(iss_ku * 128 + chunk8 * 2);
+    const unsigned kc = (unsigned)((iss_kt0 + iss_ku) * 128 + chunk8 * 2);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (jsel >= 0 && jsel != j) continue;
@@ -163,9 +182,10 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
                                        (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
     }
   };
-  auto issue_b = [&](int v, int unit, int jsel) __attribute__((always_inline)) {   // voxel half v
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  auto issue_b = [&](int v, int unit, int jsel, const i32x4& gq) __attribute__((always_inline)) {   // voxel half v (gq: its geometry)
     if constexpr (PW) {
-      const unsigned kc = (unsigned)(iss_ku * 128 + chunk8 * 2);
+      const unsigned kc = (unsigned)((iss_kt0 + iss_ku) * 128 + chunk8 * 2);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (jsel >= 0 && jsel != j) continue;
@@ -175,17 +195,21 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
                                          (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
       }
     } else {
-      // element offset of the K tile's tap + channel block and the bits of b_msk that must be set for this tap (wave-uniform)
+      // element offset of the K tile's tap + channel block and the mask bits that must be set for this tap (wave-uniform)
       const int uni = ((iss_dt * dil_t * d.Hi + iss_dh * dil_h) * d.Wi + iss_dw * dil_w) * d.ldx + iss_c0;
       const unsigned sel = (1u << iss_dt) | (1u << (8 + iss_dh)) | (1u << (16 + iss_dw));
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (jsel >= 0 && jsel != j) continue;
-        const bool ok = iss_live && (g.b_msk[v * 2 + j] & sel) == sel;
-        __builtin_amdgcn_global_load_lds((gptr9_t)pick(ok, (unsigned long)(X + (long)(g.b_off[v * 2 + j] + uni))),
+        const bool ok = iss_live && ((unsigned)gq[2 + j] & sel) == sel;
+        __builtin_amdgcn_global_load_lds((gptr9_t)pick(ok, (unsigned long)(X + (long)(gq[j] + uni))),
                                          (lptr9_t)(smem + unit + (j * 8 + wave) * 512), 16, 0, 0);
       }
     }
+  };
+  auto load_geo = [&](int v) __attribute__((always_inline)) -> i32x4 {
+    if constexpr (PW) return i32x4{0, 0, 0, 0};
+    else return *reinterpret_cast<const i32x4*>(geo + v * 4);
   };
   // folded BatchNorm / bias tables of the stream's tile -> LDS, one 4-byte DMA per thread: wave w < 4 carries scale[64 w ..
   // 64 w + 63] of the tile's 256 channels, w >= 4 the shift (channels past cout read a clamped entry: zeroed in the epilogue).
@@ -195,8 +219,8 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     const float* tab = wave < 4 ? d.scale : d.shift;
     if (tab != nullptr && iss_live) {
       long m0;
-      int n0;
-      tile_origin(iss_it, m0, n0);
+      int n0, tile, slice;
+      tile_origin(iss_it, m0, n0, tile, slice);
       int n = n0 + 64 * (wave & 3) + lane;
       n = n < d.cout ? n : d.cout - 1;
       __builtin_amdgcn_global_load_lds((gptr9_t)(tab + n), (lptr9_t)(smem9_raw + kTab9 + (iss_jt & 1) * 2048 + wave * 256), 4, 0, 0);
@@ -216,7 +240,6 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     }
     if (iss_ku == nk) {
       iss_ku = 0;
-      iss_c0 = iss_dt = iss_dh = iss_dw = 0;
       iss_it += gridDim.x;
       ++iss_jt;
       iss_live = iss_it < total_tiles;
@@ -250,12 +273,12 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   // ---- prologue: the first tile's tables, AE BE BO AO of K tile 0, AE BE of K tile 1 ----
   issue_tables();
   issue_a(0, unit_a(0, 0), -1);
-  issue_b(0, unit_b(0, 0), -1);
-  issue_b(1, unit_b(0, 1), -1);
+  issue_b(0, unit_b(0, 0), -1, load_geo(0));
+  issue_b(1, unit_b(0, 1), -1, load_geo(1));
   issue_a(1, unit_a(0, 1), -1);
   advance();
   issue_a(0, unit_a(1, 0), -1);
-  issue_b(0, unit_b(1, 0), -1);
+  issue_b(0, unit_b(1, 0), -1, load_geo(0));
   __builtin_amdgcn_s_waitcnt(vml(8));   // AE, BE of K tile 0: this thread's share
   __builtin_amdgcn_s_barrier();
   const bool half_b = wave >= 4;        // wave-uniform
@@ -265,7 +288,8 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   bool stores_behind = false;   // the previous tile's stores sit behind the units the first K tile's waits cover (wave-uniform)
   int jt = 0;                   // tiles finished by this workgroup (table parity)
   f32x16 acc[4][2];
-  bf16x8 af0[4][2], af1[4][2], b0[4], b1[4];   // channel halves a0 / a1, voxel halves v0 / v1 of the K tile (4 K slices each)
+  bf16x8 af0[4][2], af1[4][2], b0[4], b1[4];
+  i32x4 gq;   // (!PW) staging geometry of the voxel half the current phase issues   // channel halves a0 / a1, voxel halves v0 / v1 of the K tile (4 K slices each)
 
   // one phase:  [reads] [DMA] wait | B1 | 8 MFMAs | B2.   FIRST: the K tile that follows an epilogue.
   // DM (variant bit 1): the phase's two DMAs are issued AMONG its MFMAs (after the 2nd and the 4th) instead of before B1 -- an
@@ -278,21 +302,34 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     __builtin_amdgcn_s_barrier();                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                              \
   } while (0)
-#define PV9_MM(AF, A0, V, BF, S)                                                                    \
-  _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                                  \
-    acc[(A0) + ta][V] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[S][ta], BF[S], acc[(A0) + ta][V], 0, 0, 0)
+#define PV9_M1(AF, A0, V, BF, S, TA)                                                                \
+  acc[(A0) + (TA)][V] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[S][TA], BF[S], acc[(A0) + (TA)][V], 0, 0, 0)
+  // DS (variant bit 2, with DM): every wave of a half issues its two DMAs behind a DIFFERENT MFMA (wave q of the half: DMA 0
+  // after MFMA q, DMA 1 after MFMA q + 4), so the four waves do not queue on the CU's one address path right after the barrier
+#define PV9_SLOT(N, ISS)                                                                             \
+  do {                                                                                              \
+    if (DM && DS) {                                                                                 \
+      if ((N) < 4 ? wq == (N) : wq + 4 == (N)) {                                                    \
+        __builtin_amdgcn_sched_barrier(0); ISS((N) < 4 ? 0 : 1); __builtin_amdgcn_sched_barrier(0);  \
+      }                                                                                             \
+    } else if (DM && ((N) == 1 || (N) == 3)) {                                                      \
+      __builtin_amdgcn_sched_barrier(0); ISS((N) == 1 ? 0 : 1); __builtin_amdgcn_sched_barrier(0);   \
+    }                                                                                               \
+  } while (0)
   // ISS(j): issue DMA j (0 / 1) of the phase's unit, ISS(-1): both
 #define PV9_PHASE(FIRST, ISS, AF, A0, V, BF)                                                        \
   do {                                                                                              \
     if (!DM) { ISS(-1); }                                                                           \
     PV9_WAIT_B1(FIRST);                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                                  \
-    PV9_MM(AF, A0, V, BF, 0);                                                                       \
-    if (DM) { __builtin_amdgcn_sched_barrier(0); ISS(0); __builtin_amdgcn_sched_barrier(0); }       \
-    PV9_MM(AF, A0, V, BF, 1);                                                                       \
-    if (DM) { __builtin_amdgcn_sched_barrier(0); ISS(1); __builtin_amdgcn_sched_barrier(0); }       \
-    PV9_MM(AF, A0, V, BF, 2);                                                                       \
-    PV9_MM(AF, A0, V, BF, 3);                                                                       \
+    PV9_M1(AF, A0, V, BF, 0, 0); PV9_SLOT(0, ISS);                                                  \
+    PV9_M1(AF, A0, V, BF, 0, 1); PV9_SLOT(1, ISS);                                                  \
+    PV9_M1(AF, A0, V, BF, 1, 0); PV9_SLOT(2, ISS);                                                  \
+    PV9_M1(AF, A0, V, BF, 1, 1); PV9_SLOT(3, ISS);                                                  \
+    PV9_M1(AF, A0, V, BF, 2, 0); PV9_SLOT(4, ISS);                                                  \
+    PV9_M1(AF, A0, V, BF, 2, 1); PV9_SLOT(5, ISS);                                                  \
+    PV9_M1(AF, A0, V, BF, 3, 0); PV9_SLOT(6, ISS);                                                  \
+    PV9_M1(AF, A0, V, BF, 3, 1); PV9_SLOT(7, ISS);                                                  \
     __builtin_amdgcn_s_setprio(0);                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                              \
     __builtin_amdgcn_s_barrier();                                                                   \
@@ -318,6 +355,7 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
 #define PV9_KTILE(P, FIRST, LAST)                                                                                         \
   do {                                                                                                                    \
     /* phase 0: (a0, v0); BO of the next K tile */                                                                        \
+    gq = load_geo(1);                                                                                                     \
     PV9_READ_B(b0, P, 0);                                                                                                 \
     if ((FIRST) || !RA) PV9_READ_A(af0, P, 0);                                                                            \
     PV9_PHASE(FIRST, ISS_P0_##P, af0, 0, 0, b0);                                                                          \
@@ -332,20 +370,23 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     PV9_READ_A(af1, P, 1);                                                                                                \
     PV9_PHASE(FIRST, ISS_P2_##P, af1, 2, 1, b1);                                                                          \
     /* phase 3: (a1, v0); BE of the K tile after next; a0 of the NEXT K tile (other parity) */                            \
+    gq = load_geo(0);                                                                                                     \
     if (RA && !(LAST)) PV9_READ_A(af0, 1 - (P), 0);                                                                       \
     PV9_PHASE(FIRST, ISS_P3_##P, af1, 2, 0, b0);                                                                          \
   } while (0)
-#define ISS_P0_0(J) issue_b(1, unit_b(1, 1), J)
+#define ISS_P0_0(J) issue_b(1, unit_b(1, 1), J, gq)
 #define ISS_P1_0(J) issue_a(1, unit_a(1, 1), J)
 #define ISS_P2_0(J) issue_a(0, unit_a(0, 0), J)
-#define ISS_P3_0(J) issue_b(0, unit_b(0, 0), J)
-#define ISS_P0_1(J) issue_b(1, unit_b(0, 1), J)
+#define ISS_P3_0(J) issue_b(0, unit_b(0, 0), J, gq)
+#define ISS_P0_1(J) issue_b(1, unit_b(0, 1), J, gq)
 #define ISS_P1_1(J) issue_a(1, unit_a(0, 1), J)
 #define ISS_P2_1(J) issue_a(0, unit_a(1, 0), J)
-#define ISS_P3_1(J) issue_b(0, unit_b(1, 0), J)
+#define ISS_P3_1(J) issue_b(0, unit_b(1, 0), J, gq)
 
   constexpr bool RA = PW && (VAR & 1);   // read-ahead of the next K tile's a0 fragments
   constexpr bool DM = (VAR & 2) != 0;     // DMAs among the MFMAs
+  constexpr bool DS = (VAR & 4) != 0;     // ... behind a different MFMA for every wave of a half
+  const int wq = wave & 3;
   const int nkp = nk >> 1;   // K tiles come in pairs (K % 128 == 0, host check): every output tile starts on LDS parity 0
   for (int it = blockIdx.x; it < total_tiles; it += gridDim.x, ++jt) {
 #pragma unroll
@@ -373,8 +414,72 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     const int wn = wave & 1, wm = wave >> 1;
     // ---- epilogue: lane owns channels cb..cb+15 of voxel m for every (channel tile a, voxel tile v) ----
     long m0;
-    int n0;
-    tile_origin(it, m0, n0);
+    int n0, tile, slice;
+    tile_origin(it, m0, n0, tile, slice);
+    bool finish_tile = true;   // workgroup-uniform: this workgroup writes the output tile
+    if (splits > 1) {
+      // ---- split K: the slices of a tile meet in d.ws; the LAST arriver adds the others' partial tiles to its accumulators ----
+      // Recipe of cdna_hip_programming.md 5 / 6 Guideline 16 (R1): partial tiles leave as write-through (sc1) 16-byte stores, every
+      // wave drains its stores, barrier, ONE relaxed agent-scope flag store; the reducer polls the flag relaxed, barrier, sc1 loads.
+      // Deadlock-free for any placement: a workgroup only ever waits for workgroups that have ALREADY drawn their ticket, i.e.
+      // that are past their K loop and busy publishing.  ws_flags per tile: [tickets, published(0) .. published(splits-2)], all
+      // zero at rest (the reducer re-arms them).
+      int* fl = d.ws_flags + (long)tile * splits;
+      int* s_misc = reinterpret_cast<int*>(smem9_raw + kMisc9);
+      if (tid == 0) *s_misc = __hip_atomic_fetch_add(fl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int ticket = __builtin_amdgcn_readfirstlane(*s_misc);
+      constexpr unsigned kSlabBytes = 256u * 256u * 4u;
+      // lane-linear image: store q of block (a, v) of wave w is 1 KB at ((w * 8 + a * 2 + v) * 4 + q) KB
+      const unsigned lane_off = (unsigned)(wave * 32) * 1024u + (unsigned)lane * 16u;
+      if (ticket < splits - 1) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            static_cast<char*>(d.ws) + ((long)tile * (splits - 1) + ticket) * kSlabBytes, 0, (int)kSlabBytes, 0x00020000);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              __builtin_amdgcn_raw_buffer_store_b128(
+                  u32x4{__float_as_uint(acc[a][v][4 * q + 0]), __float_as_uint(acc[a][v][4 * q + 1]),
+                        __float_as_uint(acc[a][v][4 * q + 2]), __float_as_uint(acc[a][v][4 * q + 3])},
+                  rs, (int)(lane_off + (unsigned)((a * 2 + v) * 4 + q) * 1024u), 0, /*sc1: write-through*/ 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(fl + 1 + ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        finish_tile = false;
+      } else {
+        for (int u = 0; u < splits - 1; ++u) {
+          if (tid == 0) {
+            int spins = 0;      // bounded: a lost partner must not hang the GPU (the result is then wrong and the tests say so)
+            while (__hip_atomic_load(fl + 1 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 20))
+              __builtin_amdgcn_s_sleep(4);
+          }
+          __syncthreads();
+          __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+              static_cast<char*>(d.ws) + ((long)tile * (splits - 1) + u) * kSlabBytes, 0, (int)kSlabBytes, 0x00020000);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+              u32x4 part[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                part[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane_off + (unsigned)((a * 2 + v) * 4 + q) * 1024u), 0, 16);
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[a][v][4 * q + e] += __uint_as_float(part[q][e]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        __syncthreads();
+        if (tid < splits) __hip_atomic_store(fl + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+      }
+    }
+    if (finish_tile) {
     long e_b[2], e_sp[2];
     bool e_ok[2];
 #pragma unroll
@@ -512,12 +617,16 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
       }
     }
     stores_behind = true;   // the four phases of the next K tile wait on units requested BEFORE these stores
+    } else {
+      stores_behind = false;  // (everything was drained before the flag went up)
+    }
     if (half_b) __builtin_amdgcn_s_barrier();   // (see above: matched by the first half's next B1)
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef PV9_KTILE
 #undef PV9_PHASE
-#undef PV9_MM
+#undef PV9_SLOT
+#undef PV9_M1
 #undef PV9_READ_A
 #undef PV9_READ_B
 #undef PV9_WAIT_B1
@@ -527,13 +636,13 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
 }
 
 template <bool PW, bool YF32, int VAR>
-int launch9(const pv_conv3d_desc& d, int tiles_n, long total, hipStream_t s) {
+int launch9(const pv_conv3d_desc& d, int tiles_n, long total, int splits, hipStream_t s) {
   const size_t lds = (size_t)kLds9Bytes;   // 128 KB of units + 4 KB of epilogue tables
   auto kern = gemm_quad_kernel<PW, YF32, VAR>;
   PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long resident = 256;   // one workgroup per CU
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads9);
-  PV_LAUNCH(kern, grid, block, lds, s, d, tiles_n, (int)total);
+  PV_LAUNCH(kern, grid, block, lds, s, d, tiles_n, (int)total, splits);
   pv_note_kernel("gemm_quad_kernel");   // (launched through a function pointer: PV_LAUNCH saw only the variable)
   PV_LAUNCH_CHECK();
   return PV_OK;
@@ -541,43 +650,77 @@ int launch9(const pv_conv3d_desc& d, int tiles_n, long total, hipStream_t s) {
 
 }  // namespace
 
+// Can this kernel run the geometry at all?  (pointers are not looked at)
+static bool gemm9_geometry_ok(const pv_conv3d_desc& d, long& M, long& K, long& tiles_m, int& tiles_n) {
+  if (d.dtype != PV_BF16 || d.a_gate != nullptr || d.a_act != PV_ACT_NONE || d.x2 != nullptr) return false;
+  if (d.kt > 8 || d.kh > 8 || d.kw > 8) return false;                                // 8-bit window masks per axis
+  const int taps = d.kt * d.kh * d.kw;
+  if (d.cin % 64 != 0 || ((long)taps * d.cin) % 128 != 0) return false;             // a K step of 64 inside one tap; K tiles in pairs
+  M = (long)d.B * d.To * d.Ho * d.Wo;
+  K = (long)taps * d.cin;
+  const int cout_p8 = pv_round_up(d.cout, 8);
+  if (K < 256) return false;                                                         // a first and a last pair of K tiles
+  // 31-bit element offsets into x, 32-bit byte offsets into w, 31-bit byte offsets in the store descriptor
+  if (M > 0x7fffffffL || (long)d.B * d.x_bs > 0x7fffffffL || ((long)d.cout + 256) * K * 2 > 0xffffffffL ||
+      (M + 256) * d.ldx * 2 > 0xffffffffL)
+    return false;
+  if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return false;
+  tiles_m = pv_ceil_div(M, BT9);
+  tiles_n = (int)pv_ceil_div(cout_p8, BT9);
+  return tiles_m * tiles_n > 0 && tiles_m * tiles_n < 0x3fffffffL;
+}
+
+// K slices per tile the library WOULD use for this geometry (1 = none): only where the tile list leaves at least half of the
+// CUs idle, the slices fill the chip at most once (every slice's workgroup is resident: the reducer's wait is short) and a
+// slice keeps >= 8 K tiles (the partial-tile exchange costs ~2 x 4 us per tile, profiles/r5)
+int pv_gemm9_splits(const pv_conv3d_desc& d) {
+  long M, K, tiles_m;
+  int tiles_n;
+  if (pv_tune("gemm9", 1) == 0 || pv_tune("gemm9_splitk", 1) == 0 || !gemm9_geometry_ok(d, M, K, tiles_m, tiles_n)) return 1;
+  const long tiles = tiles_m * tiles_n;
+  const int cout_p8 = pv_round_up(d.cout, 8);
+  if ((double)((long)tiles_n * BT9 - cout_p8) / (double)cout_p8 > 0.15) return 1;
+  if (tiles >= pv_tune("gemm9_min_tiles", 200) || tiles < 32) return 1;
+  int best = 1;
+  for (int sp = 2; sp <= 8; ++sp)
+    if (tiles * sp <= 256 && K % (128L * sp) == 0 && K / sp >= 512) best = sp;
+  return best;
+}
+
 // Returns PV_OK when this kernel took the op, PV_ERR_UNSUPPORTED to leave it to the older GEMM kernels.
 int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   const int mode = pv_tune("gemm9", 1);   // 0 off, 1 heuristic, 2 wherever the kernel can run
   if (mode == 0) return PV_ERR_UNSUPPORTED;
-  if (d.dtype != PV_BF16 || d.a_gate != nullptr || d.a_act != PV_ACT_NONE || d.x2 != nullptr) return PV_ERR_UNSUPPORTED;
-  if (d.kt > 8 || d.kh > 8 || d.kw > 8) return PV_ERR_UNSUPPORTED;                 // 8-bit window masks per axis
-  const int taps = d.kt * d.kh * d.kw;
-  if (d.cin % 64 != 0 || ((long)taps * d.cin) % 128 != 0) return PV_ERR_UNSUPPORTED;   // a K step of 64 inside one tap; K tiles in pairs
-  const long M = (long)d.B * d.To * d.Ho * d.Wo;
-  const long K = (long)taps * d.cin;
+  long M, K, tiles_m;
+  int tiles_n;
+  if (!gemm9_geometry_ok(d, M, K, tiles_m, tiles_n)) return PV_ERR_UNSUPPORTED;
   const int cout_p8 = pv_round_up(d.cout, 8);
-  if (K < 256) return PV_ERR_UNSUPPORTED;                                           // a first and a last pair of K tiles
-  // 31-bit element offsets into x, 32-bit byte offsets into w, 31-bit byte offsets in the store descriptor
-  if (M > 0x7fffffffL || (long)d.B * d.x_bs > 0x7fffffffL || ((long)d.cout + 256) * K * 2 > 0xffffffffL ||
-      (M + 256) * d.ldx * 2 > 0xffffffffL)
-    return PV_ERR_UNSUPPORTED;
-  if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
-  const long tiles_m = pv_ceil_div(M, BT9);
-  const int tiles_n = (int)pv_ceil_div(cout_p8, BT9);
-  const long total = tiles_m * tiles_n;
-  if (total <= 0 || total > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
+  const long tiles = tiles_m * tiles_n;
+  int splits = 1;
+  if (d.ws != nullptr && d.ws_flags != nullptr && d.ws_splits > 1) {   // a workspace sized by pv_conv3d_splitk for this geometry
+    splits = d.ws_splits;
+    if (splits > 8 || K % (128L * splits) != 0 || K / splits < 256) return PV_ERR_INVALID;
+  }
+  const long total = tiles * splits;
   if (mode == 1) {
-    // one workgroup per CU: the tile list must fill the chip, and a 256-channel tile must not be mostly padding
+    // one workgroup per CU: the work items must fill the chip, and a 256-channel tile must not be mostly padding
     const double waste = (double)((long)tiles_n * BT9 - cout_p8) / (double)cout_p8;
     const long min_tiles = pv_tune("gemm9_min_tiles", 200);
     if (total < min_tiles || waste > 0.15) return PV_ERR_UNSUPPORTED;
   }
   // the pointwise form addresses voxel row m at x + m * ldx: batch items must follow each other without a gap
   const bool rows = pw && d.x_bs == (long)d.To * d.Ho * d.Wo * d.ldx;
-  // variant (pv_tune "gemm9_var": bit 0 = fragment read-ahead in the pointwise form, bit 1 = DMAs among the MFMAs)
-  const int var = pv_tune("gemm9_var", 3) & 3;
+  // variant (pv_tune "gemm9_var"): 0 = DMAs before the phase's barrier; 2 = among the phase's MFMAs (default for K >= 1024: +5 %
+  // on long reductions, -10 % on four-K-tile layers); 6 = ... behind a different MFMA per wave.  (Bit 0, reading the next K
+  // tile's first channel half a phase early, measured 5-12 % SLOWER in every shape and is not instantiated any more:
+  // profiles/r5/bench_gemm_quad_v3_variants.txt.)
+  int var = pv_tune("gemm9_var", -1);
+  if (var < 0) var = K / splits >= 1024 ? 2 : 0;
 #define PV9_GO(PWv, YFv)                                                   \
   switch (var) {                                                           \
-    case 0: return launch9<PWv, YFv, 0>(d, tiles_n, total, s);             \
-    case 1: return launch9<PWv, YFv, 1>(d, tiles_n, total, s);             \
-    case 2: return launch9<PWv, YFv, 2>(d, tiles_n, total, s);             \
-    default: return launch9<PWv, YFv, 3>(d, tiles_n, total, s);            \
+    case 2: return launch9<PWv, YFv, 2>(d, tiles_n, total, splits, s);             \
+    case 6: return launch9<PWv, YFv, 6>(d, tiles_n, total, splits, s);             \
+    default: return launch9<PWv, YFv, 0>(d, tiles_n, total, splits, s);            \
   }
   if (d.y_f32) {
     if (rows) { PV9_GO(true, true) } else { PV9_GO(false, true) }

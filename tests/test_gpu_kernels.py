@@ -957,7 +957,7 @@ def _routed_kernel(op, d):
         lib.pv_plan_destroy(plan)
 
 
-def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm8"):
+def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm8", splitk=0):
     """pv_conv3d forced onto a large-tile kernel (pv_tune gemm8 = 2 | 4, or gemm9 = 2) vs torch on the same bf16-rounded data."""
     dtype = torch.bfloat16
     pad = tuple(kk // 2 for kk in k)
@@ -988,6 +988,14 @@ def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, k
     d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *stride, *pad)
     d.act, d.a_act, d.dtype, d.y_f32, d.r_f32 = act, L.ACT_NONE, L.PV_BF16, int(y_f32), int(y_f32 and res)
     L.tune(**{knob: ct})
+    wsb, flb = C.c_int64(0), C.c_int64(0)
+    sp = L.lib().pv_conv3d_splitk(C.byref(d), C.byref(wsb), C.byref(flb)) if (knob == "gemm9" and splitk) else 1
+    assert (sp > 1) == bool(splitk), (sp, splitk)
+    if sp > 1:       # the slices of a tile meet in this workspace; the tickets start at zero and the kernel re-arms them
+        ws = torch.empty(wsb.value, dtype=torch.uint8, device="cuda")
+        fl = torch.zeros(flb.value // 4, dtype=torch.int32, device="cuda")
+        d.ws, d.ws_flags, d.ws_splits = ws.data_ptr(), fl.data_ptr(), sp
+        assert sp == splitk
     try:
         call("pv_conv3d", d)
         routed = _routed_kernel(L.OP_CONV3D, d)
@@ -996,7 +1004,13 @@ def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, k
     finally:
         L.tune(**{knob: 1})
     assert routed == {"gemm8": "gemm8_kernel", "gemm9": "gemm_quad_kernel"}[knob], routed
-    assert torch.equal(got1, y)
+    if sp > 1:
+        torch.cuda.synchronize()
+        assert int(fl.abs().sum().item()) == 0          # tickets and flags re-armed by the last arriver of every tile
+        # (with K split over workgroups the fp32 summation ORDER depends on which slice arrives last: bits may differ between runs)
+        assert rel_err(got1.float(), y.float()) <= 2e-3
+    else:
+        assert torch.equal(got1, y)
     assert rel_err(y[..., :cout].permute(0, 4, 1, 2, 3), want) <= 1e-2
     if cp > cout:
         assert torch.all(y[..., cout:] == 0)       # padding channels are written as zeros
@@ -1080,6 +1094,18 @@ def test_temporal_conv_tap_rotation_and_uniform_tap_staging(B, T, H, W, cin, cou
 ])
 def test_quad_phase_gemm_kernel(B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine):
     _gemm8_case(2, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm9")
+
+
+@pytest.mark.parametrize("B,T,H,W,cin,cout,k,stride,act,res,y_f32,affine,splits", [
+    (16, 8, 16, 16, 1024, 256, (3, 1, 1), (1, 1, 1), L.ACT_RELU, False, False, True, 2),   # SlowFast res4 conv_a: 128 tiles
+    (16, 8, 16, 16, 256, 256, (1, 3, 3), (1, 1, 1), L.ACT_RELU, False, False, True, 2),    # res4 conv_b
+    (16, 8, 8, 8, 512, 512, (1, 3, 3), (1, 1, 1), L.ACT_RELU, True, False, True, 4),       # res5 conv_b: 64 tiles, residual
+    (1, 1, 1, 8192, 2048, 500, (1, 1, 1), (1, 1, 1), L.ACT_GELU, True, True, False, 4),    # pointwise form, fp32 stream, N tail
+    (1, 1, 1, 9000, 1536, 768, (1, 1, 1), (1, 1, 1), L.ACT_NONE, False, False, False, 2),  # 108 tiles, M tail; 3 does not divide
+])
+def test_quad_phase_gemm_kernel_with_the_reduction_split_over_workgroups(B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine,
+                                                                         splits):
+    _gemm8_case(1, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm9", splitk=splits)
 
 
 @pytest.mark.parametrize("B,T,H,W,cin,cout,k,stride", [
