@@ -359,7 +359,7 @@ extern "C" int pv_conv3d_splitk(const pv_conv3d_desc* d, int64_t* ws_bytes, int6
     const long M = (long)d->B * d->To * d->Ho * d->Wo;
     const long tiles = pv_ceil_div(M, 256) * pv_ceil_div(cout_p8, 256);
     if (ws_bytes) *ws_bytes = tiles * (sp - 1) * 256L * 256L * 4L;
-    if (flag_bytes) *flag_bytes = tiles * sp * 4L;
+    if (flag_bytes) *flag_bytes = tiles * (sp - 1) * 2L * 4L;     // [ticket, published] per pair group
   }
   return sp;
 }

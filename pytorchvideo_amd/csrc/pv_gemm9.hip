@@ -71,11 +71,12 @@ struct Geom9 {         // per-thread staging rows of one output tile (DMA j of a
   unsigned b_row;      // PW: byte offset in x of the voxel row of (v = 0, j = 0); (v, j) is 32 v + 128 j rows further, clamped at use
   // !PW: the four voxel rows' window origins (element offsets in x, negative for padding rows) and window masks (bit dt | bit
   // 8 + dh | bit 16 + dw set when that tap lies inside the image) do not fit the register budget next to 128 accumulators and
-  // 64 fragment registers: they live in 32 bytes of LDS per thread, [v][off j0, off j1, mask j0, mask j1], written per tile
-  // and fetched by one ds_read_b128 in the phase that issues the voxel half (each thread reads only what it wrote)
+  // 64 fragment registers (the compiler spilled accumulators in the loop header): they live in 32 bytes of LDS per thread,
+  // [v][off j0, off j1, mask j0, mask j1], written per tile and fetched by one ds_read_b128 in the phase that issues the voxel
+  // half (each thread reads only what it wrote: no synchronisation)
 };
 
-template <bool PW, bool YF32, int VAR>
+template <bool PW, bool YF32, int VAR, bool SPLIT>
 __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles, int splits) {
   // total_tiles counts WORK ITEMS: output tiles x K slices (splits = 1: the tiles themselves)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem9_raw[];
@@ -288,8 +289,6 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   bool stores_behind = false;   // the previous tile's stores sit behind the units the first K tile's waits cover (wave-uniform)
   int jt = 0;                   // tiles finished by this workgroup (table parity)
   f32x16 acc[4][2];
-  bf16x8 af0[4][2], af1[4][2], b0[4], b1[4];
-  i32x4 gq;   // (!PW) staging geometry of the voxel half the current phase issues   // channel halves a0 / a1, voxel halves v0 / v1 of the K tile (4 K slices each)
 
   // one phase:  [reads] [DMA] wait | B1 | 8 MFMAs | B2.   FIRST: the K tile that follows an epilogue.
   // DM (variant bit 1): the phase's two DMAs are issued AMONG its MFMAs (after the 2nd and the 4th) instead of before B1 -- an
@@ -304,15 +303,9 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   } while (0)
 #define PV9_M1(AF, A0, V, BF, S, TA)                                                                \
   acc[(A0) + (TA)][V] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[S][TA], BF[S], acc[(A0) + (TA)][V], 0, 0, 0)
-  // DS (variant bit 2, with DM): every wave of a half issues its two DMAs behind a DIFFERENT MFMA (wave q of the half: DMA 0
-  // after MFMA q, DMA 1 after MFMA q + 4), so the four waves do not queue on the CU's one address path right after the barrier
 #define PV9_SLOT(N, ISS)                                                                             \
   do {                                                                                              \
-    if (DM && DS) {                                                                                 \
-      if ((N) < 4 ? wq == (N) : wq + 4 == (N)) {                                                    \
-        __builtin_amdgcn_sched_barrier(0); ISS((N) < 4 ? 0 : 1); __builtin_amdgcn_sched_barrier(0);  \
-      }                                                                                             \
-    } else if (DM && ((N) == 1 || (N) == 3)) {                                                      \
+    if (DM && ((N) == 1 || (N) == 3)) {                                                             \
       __builtin_amdgcn_sched_barrier(0); ISS((N) == 1 ? 0 : 1); __builtin_amdgcn_sched_barrier(0);   \
     }                                                                                               \
   } while (0)
@@ -346,33 +339,31 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     asm volatile("" : "+v"(rd_b0));                                                                                       \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) BF[s] = PV9_RD(rd_b0, s, unit_b(P, V) * 2 - kRegionB9);                 \
   } while (0)
-  // One K tile of LDS parity P (compile-time: every LDS address is a per-lane base + an immediate).  The fragment reads are
-  // spread 4 / 4 / 8 / 8 over the phases: the channel half a0 of the NEXT K tile is read in phase 3 (its unit was requested
-  // six phases ago and is covered by phase 2's wait), so no phase carries more than 8 reads beside its two DMAs.
-  // FIRST: follows an epilogue (a0 was not read ahead: its 32 registers belong to the epilogue); LAST: no read-ahead.
-  // The implicit-GEMM form carries 8 more staging registers per thread (offsets + window masks) and has no room for the second
-  // channel-half fragment set: it reads a0 in phase 0 (12 / 4 / 8 / 0 reads).
-#define PV9_KTILE(P, FIRST, LAST)                                                                                         \
+  // One K tile of LDS parity P (compile-time: every LDS address is a per-lane base + an immediate).  Fragment reads per phase:
+  // 12 / 4 / 8 / 0 (reading the next K tile's first channel half one phase early, 4 / 4 / 8 / 8, needs a second 32-register
+  // fragment set and measured 5-12 % SLOWER in every shape: profiles/r5/bench_gemm_quad_v3_variants.txt).
+  // FIRST: the K tile that follows an epilogue (its waits have the previous tile's stores behind the units they cover).
+#define PV9_KTILE(P, FIRST)                                                                                               \
   do {                                                                                                                    \
+    bf16x8 af[4][2], b0[4], b1[4];   /* a channel half, voxel halves v0 / v1 of the K tile (4 K slices each) */           \
     /* phase 0: (a0, v0); BO of the next K tile */                                                                        \
-    gq = load_geo(1);                                                                                                     \
+    i32x4 gq = load_geo(1);                                                                                               \
     PV9_READ_B(b0, P, 0);                                                                                                 \
-    if ((FIRST) || !RA) PV9_READ_A(af0, P, 0);                                                                            \
-    PV9_PHASE(FIRST, ISS_P0_##P, af0, 0, 0, b0);                                                                          \
+    PV9_READ_A(af, P, 0);                                                                                                 \
+    PV9_PHASE(FIRST, ISS_P0_##P, af, 0, 0, b0);                                                                           \
     /* phase 1: (a0, v1); AO of the next K tile */                                                                        \
     PV9_READ_B(b1, P, 1);                                                                                                 \
-    PV9_PHASE(FIRST, ISS_P1_##P, af0, 0, 1, b1);                                                                          \
+    PV9_PHASE(FIRST, ISS_P1_##P, af, 0, 1, b1);                                                                           \
     /* phase 2: the stream moves on to the K tile after next (a new output tile's staging rows are computed HERE, where    \
        only the accumulators and the voxel fragments are live); (a1, v1); AE of that K tile -- this parity's AE, last      \
-       read a K tile ago */                                                                                               \
+       read two phases ago */                                                                                             \
     advance();                                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
-    PV9_READ_A(af1, P, 1);                                                                                                \
-    PV9_PHASE(FIRST, ISS_P2_##P, af1, 2, 1, b1);                                                                          \
-    /* phase 3: (a1, v0); BE of the K tile after next; a0 of the NEXT K tile (other parity) */                            \
+    PV9_READ_A(af, P, 1);                                                                                                 \
+    PV9_PHASE(FIRST, ISS_P2_##P, af, 2, 1, b1);                                                                           \
+    /* phase 3: (a1, v0); BE of the K tile after next */                                                                  \
     gq = load_geo(0);                                                                                                     \
-    if (RA && !(LAST)) PV9_READ_A(af0, 1 - (P), 0);                                                                       \
-    PV9_PHASE(FIRST, ISS_P3_##P, af1, 2, 0, b0);                                                                          \
+    PV9_PHASE(FIRST, ISS_P3_##P, af, 2, 0, b0);                                                                           \
   } while (0)
 #define ISS_P0_0(J) issue_b(1, unit_b(1, 1), J, gq)
 #define ISS_P1_0(J) issue_a(1, unit_a(1, 1), J)
@@ -383,10 +374,7 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
 #define ISS_P2_1(J) issue_a(0, unit_a(1, 0), J)
 #define ISS_P3_1(J) issue_b(0, unit_b(1, 0), J, gq)
 
-  constexpr bool RA = PW && (VAR & 1);   // read-ahead of the next K tile's a0 fragments
   constexpr bool DM = (VAR & 2) != 0;     // DMAs among the MFMAs
-  constexpr bool DS = (VAR & 4) != 0;     // ... behind a different MFMA for every wave of a half
-  const int wq = wave & 3;
   const int nkp = nk >> 1;   // K tiles come in pairs (K % 128 == 0, host check): every output tile starts on LDS parity 0
   for (int it = blockIdx.x; it < total_tiles; it += gridDim.x, ++jt) {
 #pragma unroll
@@ -396,14 +384,12 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][v][r] = 0.f;
 
-    PV9_KTILE(0, true, false);
-    PV9_KTILE(1, false, false);
-    for (int kp = 2; kp < nkp; ++kp) {
-      PV9_KTILE(0, false, false);
-      PV9_KTILE(1, false, false);
+    PV9_KTILE(0, true);
+    PV9_KTILE(1, false);
+    for (int kp = 1; kp < nkp; ++kp) {
+      PV9_KTILE(0, false);
+      PV9_KTILE(1, false);
     }
-    PV9_KTILE(0, false, false);
-    PV9_KTILE(1, false, true);
 
     // The first half has just passed its last B2; the second half is still multiplying its last quadrant.  One extra barrier
     // here (matched by that half's last B2) and one at the END of the second half's epilogue (matched by the first half's next
@@ -417,66 +403,68 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     int n0, tile, slice;
     tile_origin(it, m0, n0, tile, slice);
     bool finish_tile = true;   // workgroup-uniform: this workgroup writes the output tile
-    if (splits > 1) {
-      // ---- split K: the slices of a tile meet in d.ws; the LAST arriver adds the others' partial tiles to its accumulators ----
-      // Recipe of cdna_hip_programming.md 5 / 6 Guideline 16 (R1): partial tiles leave as write-through (sc1) 16-byte stores, every
-      // wave drains its stores, barrier, ONE relaxed agent-scope flag store; the reducer polls the flag relaxed, barrier, sc1 loads.
-      // Deadlock-free for any placement: a workgroup only ever waits for workgroups that have ALREADY drawn their ticket, i.e.
-      // that are past their K loop and busy publishing.  ws_flags per tile: [tickets, published(0) .. published(splits-2)], all
-      // zero at rest (the reducer re-arms them).
-      int* fl = d.ws_flags + (long)tile * splits;
-      int* s_misc = reinterpret_cast<int*>(smem9_raw + kMisc9);
-      if (tid == 0) *s_misc = __hip_atomic_fetch_add(fl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      const int ticket = __builtin_amdgcn_readfirstlane(*s_misc);
+    if constexpr (SPLIT) {
+      // ---- split K: a tile's `splits` = 2^L slices are summed PAIRWISE in L levels (slices s and s ^ 1, then the pair sums, ...):
+      // of the two workgroups of a group the one that arrives FIRST parks its partial tile in d.ws and is done, the second adds
+      // it to its accumulators and goes on to the next level; the last level's second arriver runs the epilogue.  Every
+      // addition has exactly two fixed operands and fp32 addition commutes, so the result does not depend on who arrives
+      // first: bit-identical from run to run (hipGraph replays are compared bit for bit by the tests).
+      // Hand-off recipe of cdna_hip_programming.md 5 / 6 Guideline 16 (R1): the partial tile leaves as write-through (sc1)
+      // 16-byte stores, every wave drains its stores, barrier, ONE relaxed agent-scope flag store; the other side polls the
+      // flag relaxed, barrier, sc1 loads.  Deadlock-free for any placement: a workgroup only waits for a partner that has
+      // ALREADY drawn its ticket, i.e. that is past its K loop and busy publishing.  ws_flags per tile and group: [ticket,
+      // published], all zero at rest (the second arriver re-arms them: graph replays need no memset).
       constexpr unsigned kSlabBytes = 256u * 256u * 4u;
-      // lane-linear image: store q of block (a, v) of wave w is 1 KB at ((w * 8 + a * 2 + v) * 4 + q) KB
+      int* s_misc = reinterpret_cast<int*>(smem9_raw + kMisc9);
+      // lane-linear image: piece q of accumulator block (a, v) of wave w is the 1 KB at ((w * 8 + a * 2 + v) * 4 + q) KB
       const unsigned lane_off = (unsigned)(wave * 32) * 1024u + (unsigned)lane * 16u;
-      if (ticket < splits - 1) {
+      for (int lvl = 0; (1 << lvl) < splits; ++lvl) {
+        const int gi = (splits - (splits >> lvl)) + (slice >> (lvl + 1));     // group index inside the tile, 0 .. splits - 2
+        int* fl = d.ws_flags + ((long)tile * (splits - 1) + gi) * 2;
+        if (tid == 0) s_misc[lvl] = __hip_atomic_fetch_add(fl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int ticket = __builtin_amdgcn_readfirstlane(s_misc[lvl]);
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            static_cast<char*>(d.ws) + ((long)tile * (splits - 1) + ticket) * kSlabBytes, 0, (int)kSlabBytes, 0x00020000);
+            static_cast<char*>(d.ws) + ((long)tile * (splits - 1) + gi) * kSlabBytes, 0, (int)kSlabBytes, 0x00020000);
+        if (ticket == 0) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    u32x4{__float_as_uint(acc[a][v][4 * q + 0]), __float_as_uint(acc[a][v][4 * q + 1]),
+                          __float_as_uint(acc[a][v][4 * q + 2]), __float_as_uint(acc[a][v][4 * q + 3])},
+                    rs, (int)(lane_off + (unsigned)((a * 2 + v) * 4 + q) * 1024u), 0, /*sc1: write-through*/ 16);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0) __hip_atomic_store(fl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          finish_tile = false;
+          break;
+        }
+        if (tid == 0) {
+          int spins = 0;      // bounded: a lost partner must not hang the GPU (the result is then wrong and the tests say so)
+          while (__hip_atomic_load(fl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 20))
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int v = 0; v < 2; ++v)
+          for (int v = 0; v < 2; ++v) {
+            u32x4 part[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              __builtin_amdgcn_raw_buffer_store_b128(
-                  u32x4{__float_as_uint(acc[a][v][4 * q + 0]), __float_as_uint(acc[a][v][4 * q + 1]),
-                        __float_as_uint(acc[a][v][4 * q + 2]), __float_as_uint(acc[a][v][4 * q + 3])},
-                  rs, (int)(lane_off + (unsigned)((a * 2 + v) * 4 + q) * 1024u), 0, /*sc1: write-through*/ 16);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(fl + 1 + ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        finish_tile = false;
-      } else {
-        for (int u = 0; u < splits - 1; ++u) {
-          if (tid == 0) {
-            int spins = 0;      // bounded: a lost partner must not hang the GPU (the result is then wrong and the tests say so)
-            while (__hip_atomic_load(fl + 1 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 20))
-              __builtin_amdgcn_s_sleep(4);
-          }
-          __syncthreads();
-          __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-              static_cast<char*>(d.ws) + ((long)tile * (splits - 1) + u) * kSlabBytes, 0, (int)kSlabBytes, 0x00020000);
+              part[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane_off + (unsigned)((a * 2 + v) * 4 + q) * 1024u), 0, 16);
 #pragma unroll
-          for (int a = 0; a < 4; ++a) {
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
-              u32x4 part[4];
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                part[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane_off + (unsigned)((a * 2 + v) * 4 + q) * 1024u), 0, 16);
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[a][v][4 * q + e] += __uint_as_float(part[q][e]);
-            }
+              for (int e = 0; e < 4; ++e) acc[a][v][4 * q + e] += __uint_as_float(part[q][e]);
             __builtin_amdgcn_sched_barrier(0);
           }
-        }
         __syncthreads();
-        if (tid < splits) __hip_atomic_store(fl + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+        if (tid < 2) __hip_atomic_store(fl + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
       }
     }
     if (finish_tile) {
@@ -573,19 +561,20 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
       }
       __builtin_amdgcn_sched_barrier(0);
     };
-    // the residual rows of channel tile a + 1 are requested before tile a is finished (two register sets); every load of the
-    // epilogue is consumed before the first store is issued
+    // (requesting the residual rows of tile a + 1 before tile a is finished -- a second 32-register set -- measured nothing and
+    // pushed the epilogue into scratch: one set)
+    // (literal channel-tile indices: inside a loop the lambdas' `a` is a run-time index when the accumulators are first split
+    // into registers, and half of them then live in scratch for the whole kernel)
     {
-      res_t r0, r1;
+      res_t r0;
       load_res(0, r0);
-      __builtin_amdgcn_sched_barrier(0);
-      load_res(1, r1);
       finish(0, r0);
+      load_res(1, r0);
+      finish(1, r0);
       load_res(2, r0);
-      finish(1, r1);
-      load_res(3, r1);
       finish(2, r0);
-      finish(3, r1);
+      load_res(3, r0);
+      finish(3, r0);
     }
     // ... then nothing but stores (E_BF16 / E_F32 of them, whatever is masked)
 #pragma unroll
@@ -635,10 +624,10 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   __builtin_amdgcn_s_waitcnt(vml(0));          // the stream's trailing (zero-page) DMAs land before the LDS is released
 }
 
-template <bool PW, bool YF32, int VAR>
+template <bool PW, bool YF32, int VAR, bool SPLIT>
 int launch9(const pv_conv3d_desc& d, int tiles_n, long total, int splits, hipStream_t s) {
   const size_t lds = (size_t)kLds9Bytes;   // 128 KB of units + 4 KB of epilogue tables
-  auto kern = gemm_quad_kernel<PW, YF32, VAR>;
+  auto kern = gemm_quad_kernel<PW, YF32, VAR, SPLIT>;
   PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long resident = 256;   // one workgroup per CU
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads9);
@@ -682,7 +671,7 @@ int pv_gemm9_splits(const pv_conv3d_desc& d) {
   if ((double)((long)tiles_n * BT9 - cout_p8) / (double)cout_p8 > 0.15) return 1;
   if (tiles >= pv_tune("gemm9_min_tiles", 200) || tiles < 32) return 1;
   int best = 1;
-  for (int sp = 2; sp <= 8; ++sp)
+  for (int sp = 2; sp <= 8; sp *= 2)     // powers of two: the slices are summed pairwise
     if (tiles * sp <= 256 && K % (128L * sp) == 0 && K / sp >= 512) best = sp;
   return best;
 }
@@ -699,7 +688,9 @@ int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   int splits = 1;
   if (d.ws != nullptr && d.ws_flags != nullptr && d.ws_splits > 1) {   // a workspace sized by pv_conv3d_splitk for this geometry
     splits = d.ws_splits;
-    if (splits > 8 || K % (128L * splits) != 0 || K / splits < 256) return PV_ERR_INVALID;
+    // pairwise sum: a power of two; every slice's workgroup resident at once (a waiting workgroup's partner is always running)
+    if ((splits != 2 && splits != 4 && splits != 8) || K % (128L * splits) != 0 || K / splits < 256 || tiles * splits > 256)
+      return PV_ERR_INVALID;
   }
   const long total = tiles * splits;
   if (mode == 1) {
@@ -711,17 +702,19 @@ int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   // the pointwise form addresses voxel row m at x + m * ldx: batch items must follow each other without a gap
   const bool rows = pw && d.x_bs == (long)d.To * d.Ho * d.Wo * d.ldx;
   // variant (pv_tune "gemm9_var"): 0 = DMAs before the phase's barrier; 2 = among the phase's MFMAs (default for K >= 1024: +5 %
-  // on long reductions, -10 % on four-K-tile layers); 6 = ... behind a different MFMA per wave.  (Bit 0, reading the next K
+  // on long reductions, -10 % on four-K-tile layers); (bit 2, every wave of a half issuing
+  // behind a different MFMA, measured 8x slower -- its branches spill inside the loop -- and is gone).  (Bit 0, reading the next K
   // tile's first channel half a phase early, measured 5-12 % SLOWER in every shape and is not instantiated any more:
   // profiles/r5/bench_gemm_quad_v3_variants.txt.)
   int var = pv_tune("gemm9_var", -1);
   if (var < 0) var = K / splits >= 1024 ? 2 : 0;
-#define PV9_GO(PWv, YFv)                                                   \
-  switch (var) {                                                           \
-    case 2: return launch9<PWv, YFv, 2>(d, tiles_n, total, splits, s);             \
-    case 6: return launch9<PWv, YFv, 6>(d, tiles_n, total, splits, s);             \
-    default: return launch9<PWv, YFv, 0>(d, tiles_n, total, splits, s);            \
-  }
+#define PV9_GO(PWv, YFv)                                                                            \
+  if (splits > 1) {                                                                                 \
+    if (var == 2) return launch9<PWv, YFv, 2, true>(d, tiles_n, total, splits, s);                  \
+    return launch9<PWv, YFv, 0, true>(d, tiles_n, total, splits, s);                                \
+  }                                                                                                 \
+  if (var == 2) return launch9<PWv, YFv, 2, false>(d, tiles_n, total, splits, s);                   \
+  return launch9<PWv, YFv, 0, false>(d, tiles_n, total, splits, s);
   if (d.y_f32) {
     if (rows) { PV9_GO(true, true) } else { PV9_GO(false, true) }
   } else {
