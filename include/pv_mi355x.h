@@ -125,23 +125,8 @@ typedef struct pv_conv3d_desc {
   const float* x2_scale;     /* [cout] or NULL (=1) */
   int64_t x2_bs;
   int32_t x2_ld, x2_cin, x2_Hi, x2_Wi, x2_st, x2_sh, x2_sw;
-  /* Optional split-K workspace (round 5, csrc/pv_gemm9.hip): a dense layer whose 256 x 256 output tiles are too few to give
-   * every CU one (SlowFast res4 / res5 conv_a and conv_b, models/resnet.py:98-132: 128 and 64 tiles on 256 CUs) has its
-   * reduction cut into ws_splits slices per tile, one workgroup each; the slices of a tile meet in `ws` (fp32 partial tiles,
-   * written and consumed inside the launch) and the workgroup that arrives LAST adds them up and runs the epilogue -- same
-   * result as the unsplit sum up to fp32 summation order.  pv_conv3d_splitk(d) says how many slices the library would use for
-   * a geometry and how many bytes it needs; ws_splits <= 1 or ws == NULL: no split.
-   *   ws        ws_bytes of scratch (any content; private to this op while it runs)
-   *   ws_flags  flag_bytes of int32, ZERO when first used and never written by anyone else: the arrival tickets (the last
-   *             arriver of a tile re-arms them, so graph replays need no memset) */
-  void* ws;
-  int32_t* ws_flags;
-  int32_t ws_splits;
 } pv_conv3d_desc;
 int pv_conv3d(const pv_conv3d_desc* d, pv_stream_t stream);
-/* number of K slices pv_conv3d would cut this geometry into if given a workspace (pointers are ignored; 0 or 1 = none), and
- * the sizes that workspace needs */
-int pv_conv3d_splitk(const pv_conv3d_desc* d, int64_t* ws_bytes, int64_t* flag_bytes);
 /* 1 if this geometry (pointers are ignored) can run with the fused temporal conv, else 0 */
 int pv_conv3d_dwt_supported(const pv_conv3d_desc* d);
 /* 1 if this geometry (pointers are ignored; x2_cin > 0) can run with the second K operand, else 0 */
@@ -506,12 +491,6 @@ typedef struct pv_ln_linear_desc {
   int32_t act;
   int32_t dtype;         /* PV_BF16 */
   float ln_eps;
-  /* Residual mode (round 4): residual != NULL (and ln_gamma == ln_beta == NULL, act = none) ->
-   *     y[m][:] (fp32 [M][ldy]) = residual[m][:] (fp32 [M][ldr]) + b + W . x[m][:],   x a bf16 operand tensor [M][ldx]
-   * -- MultiScaleAttention's output projection with the block's residual join (layers/attention.py:541-544,745-749) where
-   * the tiled GEMM is latency-bound; same `wb` image.  pv_ln_linear_rows_supported: (C, N) = (384, 384) or (192, 192). */
-  const float* residual;
-  int32_t ldr;
 } pv_ln_linear_desc;
 int pv_ln_linear_rows(const pv_ln_linear_desc* d, pv_stream_t stream);
 int pv_ln_linear_rows_supported(const pv_ln_linear_desc* d);

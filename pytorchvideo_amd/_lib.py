@@ -39,8 +39,7 @@ Conv3dDesc = _struct("Conv3dDesc", [
             "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "act", "a_act", "dtype", "y_f32", "r_f32")
     + [("dwt_w", _p)] + _ints("dwt_k", "c4_wpair") + [("pos_spatial", _p), ("pos_temporal", _p)]
     + _ints("dil_t", "dil_h", "dil_w")
-    + [("x2", _p), ("x2_scale", _p), ("x2_bs", _i64)] + _ints("x2_ld", "x2_cin", "x2_Hi", "x2_Wi", "x2_st", "x2_sh", "x2_sw")
-    + [("ws", _p), ("ws_flags", _p)] + _ints("ws_splits"))
+    + [("x2", _p), ("x2_scale", _p), ("x2_bs", _i64)] + _ints("x2_ld", "x2_cin", "x2_Hi", "x2_Wi", "x2_st", "x2_sh", "x2_sw"))
 
 DwConv3dDesc = _struct("DwConv3dDesc", [
     ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("psum", _p),
@@ -110,7 +109,7 @@ MlpDesc = _struct("MlpDesc", [
 
 LnLinearDesc = _struct("LnLinearDesc", [
     ("x", _p), ("wb", _p), ("y", _p), ("ln_gamma", _p), ("ln_beta", _p), ("M", _i64)]
-    + _ints("C", "N", "ldx", "ldy", "act", "dtype") + [("ln_eps", _f32), ("residual", _p)] + _ints("ldr"))
+    + _ints("C", "N", "ldx", "ldy", "act", "dtype") + [("ln_eps", _f32)])
 
 GatherSrc = _struct("GatherSrc", [("ptr", _p), ("row_bytes", C.c_size_t), ("row_pitch", C.c_size_t), ("rows", _i64)])
 
@@ -130,7 +129,6 @@ _SYMBOLS = [
     ("pv_conv3d", C.c_int, [C.POINTER(Conv3dDesc), _p]),
     ("pv_conv3d_dwt_supported", C.c_int, [C.POINTER(Conv3dDesc)]),
     ("pv_conv3d_x2_supported", C.c_int, [C.POINTER(Conv3dDesc)]),
-    ("pv_conv3d_splitk", C.c_int, [C.POINTER(Conv3dDesc), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("pv_dwconv3d", C.c_int, [C.POINTER(DwConv3dDesc), _p]),
     ("pv_dwconv3d_psum_blocks", C.c_int, [C.POINTER(DwConv3dDesc)]),
     ("pv_dwconv3d_pw_supported", C.c_int, [C.POINTER(DwConv3dDesc)]),

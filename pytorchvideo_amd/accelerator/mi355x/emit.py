@@ -285,33 +285,8 @@ def emit_conv(sess, conv, x, norm=None, act=L.ACT_NONE, residual=None, a_gate=No
         alg += sess.itemsize * (vox_out * pad8(x2.C) + cout * x2.C)
         flops += 2 * vox_out * cout * x2.C
         detail += " +shortcut c%d" % x2.C
-    ws = _splitk_workspace(sess, f) if (sess.itemsize == 2 and not f32_op and x2 is None and not c4 and dwt is None) else None
-    if ws is not None:
-        detail += " splitK%d" % f["ws_splits"]
     sess.add_op(L.OP_CONV3D, f, label=label + detail, alg_bytes=alg, flops=flops)
-    if ws is not None:
-        sess.release(ws)            # written and consumed inside the launch
     return y
-
-
-def _splitk_workspace(sess, f):
-    """Dense layers whose 256 x 256 tile list leaves most CUs idle (SlowFast res4 / res5 conv_a, conv_b): the library says how
-    many K slices it would use for the geometry (pv_conv3d_splitk) and how much scratch the slices' partial tiles need; the
-    arrival tickets live beside the weights (zero at upload, re-armed by the kernel).  Sets f's ws fields; returns the scratch
-    pointer to release after the op, or None."""
-    d = L.Conv3dDesc()
-    for k in ("B", "Ti", "Hi", "Wi", "cin", "To", "Ho", "Wo", "cout", "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw",
-              "dtype", "y_f32", "ldx", "ldy", "x_bs", "y_bs", "dil_t", "dil_h", "dil_w", "a_act"):
-        setattr(d, k, int(f.get(k) or 0))
-    if f.get("a_gate") is not None:
-        return None
-    wsb, flb = C.c_int64(0), C.c_int64(0)
-    sp = L.lib().pv_conv3d_splitk(C.byref(d), C.byref(wsb), C.byref(flb))
-    if sp <= 1 or wsb.value <= 0:
-        return None
-    ws = sess.alloc_raw(int(wsb.value))
-    f.update(ws=ws, ws_flags=sess.add_weight(torch.zeros(int(flb.value) // 4, dtype=torch.int32)), ws_splits=int(sp))
-    return ws
 
 
 def _pointwise_producer_fields(sess, producer, x, Cc):

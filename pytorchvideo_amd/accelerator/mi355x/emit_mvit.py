@@ -454,36 +454,6 @@ def emit_ln_linear(sess, norm, lin, x, label):
     return y
 
 
-def emit_linear_residual_rows(sess, lin, x, residual, label):
-    """y (fp32 stream) = residual + b + W . x for a bf16 operand x on the row-resident kernel (pv_ln_linear_rows, residual
-    mode; csrc/pv_mlp.hip linear_res_rows_kernel) -- or None where it does not apply (the caller emits the tiled GEMM).
-    Taken for the widths whose 128 x 128-tile GEMM is latency-bound (K = N = 384 on 25 k rows: 31 us for 7.4 GFLOP)."""
-    if not tuning.get("proj_rows") or sess.pv_dtype != L.PV_BF16 or not isinstance(lin, nn.Linear):
-        return None
-    if residual is None or not residual.f32 or x.f32 or lin.in_features != x.C:
-        return None
-    if x.bs != x.voxels * x.ld or residual.bs != residual.voxels * residual.ld or residual.C != lin.out_features \
-            or residual.voxels != x.voxels or residual.B != x.B:
-        return None
-    M = x.B * x.voxels
-    if M > tuning.get("proj_rows_max_m"):      # (hundreds of thousands of rows: the GEMM streams at the HBM rate there)
-        return None
-    d = L.LnLinearDesc()
-    d.x = d.wb = d.y = d.residual = 1
-    d.M, d.C, d.N, d.ldx, d.ldy, d.ldr, d.act, d.dtype = M, x.C, lin.out_features, x.ld, pad8(lin.out_features), residual.ld, L.ACT_NONE, L.PV_BF16
-    if L.lib().pv_ln_linear_rows_supported(C.byref(d)) != 1:
-        return None
-    y = sess.alloc_act(x.B, 1, 1, x.voxels, lin.out_features, f32=True)
-    y.thw, y.has_cls = x.thw, x.has_cls
-    f = dict(x=x.ptr, wb=sess.add_weight(pack_ln_linear_weights(lin.weight, lin.bias)), y=y.ptr, ln_gamma=None, ln_beta=None,
-             M=M, C=x.C, N=lin.out_features, ldx=x.ld, ldy=y.ld, act=L.ACT_NONE, dtype=L.PV_BF16, ln_eps=0.0,
-             residual=residual.ptr, ldr=residual.ld)
-    sess.add_op(L.OP_LN_LINEAR, f, label="%s|%dx%d c%d->%d rows" % (label, x.B, x.voxels, x.C, lin.out_features),
-                alg_bytes=M * (2 * pad8(x.C) + 8 * pad8(lin.out_features)) + 2 * x.C * lin.out_features,
-                flops=2 * M * x.C * lin.out_features)
-    return y
-
-
 def can_fuse_mlp(sess, blk, x1):
     """norm2 -> fc1 -> act -> fc2 -> + residual of a MultiScaleBlock as ONE pv_mlp_rows launch (csrc/pv_mlp.hip)?"""
     if not tuning.get("fuse_mlp") or sess.pv_dtype != L.PV_BF16 or not x1.f32:
@@ -649,9 +619,7 @@ def emit_multiscale_attention(sess, attn, xn, residual, label="attn", qkv=None):
     q_thw = q.thw
     for t in owned:
         sess.release(t)
-    y = emit_linear_residual_rows(sess, attn.proj, o, residual, label=label + ".proj")
-    if y is None:
-        y = emit_linear(sess, attn.proj, o, residual=residual, y_f32=True, label=label + ".proj")
+    y = emit_linear(sess, attn.proj, o, residual=residual, y_f32=True, label=label + ".proj")
     sess.release(o)
     y.thw = q_thw
     return y

@@ -19,9 +19,6 @@ OPTIONS = {
     "fuse_se_gate": False,       # X3D squeeze-excitation gate computed by the last workgroup of the depthwise launch (emit.emit_dwconv):
                                  # correct and tested, but SLOWER than the 15 gate launches it removes (round 4, profiles/r4/dropped/)
     "fuse_next_norm": True,      # MViT: norm1 of block i+1 written by block i's fused MLP from the rows it holds (emit_mvit.emit_mlp_fused)
-    "proj_rows": False,          # MViT attention output projection + residual on the row-resident kernel (emit_mvit.emit_linear_residual_rows):
-                                 # correct and tested, 4 % SLOWER on the whole model than the tiled GEMM (round 4, profiles/r4/dropped/)
-    "proj_rows_max_m": 60000,    # ... for at most this many token rows (MViT-B: the 25 096-row blocks; 100 k+ rows stream at the HBM rate on the GEMM)
     "fuse_mlp": True,            # MViT norm2 + fc1 + GELU + fc2 + residual as ONE launch (pv_mlp_rows)  (emit_mvit)
     "arena_guards": 0,           # debug build of the launch plan: every arena buffer gets its own memory (no re-use) followed
                                  # by this many bytes of canary; Session.check_guards() names the buffers a kernel wrote past

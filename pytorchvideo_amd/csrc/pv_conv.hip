@@ -22,7 +22,6 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);  // pv_ge
 int pv_head_rows_try(const pv_conv3d_desc& d, hipStream_t s);              // pv_headgemm.hip
 int pv_gemm8_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);      // pv_gemm8.hip
 int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);      // pv_gemm9.hip
-int pv_gemm9_splits(const pv_conv3d_desc& d);                              // pv_gemm9.hip
 int pv_tapstream_try(const pv_conv3d_desc& d, hipStream_t s);           // pv_lateral.hip
 int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s);                 // pv_stem.hip
 int pv_stem_dwt_supported(const pv_conv3d_desc& d);                     // pv_stem.hip
@@ -341,27 +340,6 @@ extern "C" int pv_conv3d_x2_supported(const pv_conv3d_desc* d) {
   if (!d || d->B <= 0 || d->cout <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
   if (d->kt * d->kh * d->kw != 1 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt || d->ph || d->pw) return 0;
   return pv_pwconv_x2_supported(*d);
-}
-
-extern "C" int pv_conv3d_splitk(const pv_conv3d_desc* d, int64_t* ws_bytes, int64_t* flag_bytes) {
-  if (ws_bytes) *ws_bytes = 0;
-  if (flag_bytes) *flag_bytes = 0;
-  if (!d || d->B <= 0 || d->cin <= 0 || d->cout <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
-  if (d->kt < 1 || d->kh < 1 || d->kw < 1 || d->dwt_w || d->pos_spatial || d->pos_temporal || (d->cin == 4 && d->ldx == 4)) return 1;
-  // the same routing conditions pv_conv3d applies ahead of the large-tile GEMM (below): wide dense layers only
-  const int taps = d->kt * d->kh * d->kw;
-  const bool pw = taps == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0;
-  const int cout_p8 = pv_round_up(d->cout, 8);
-  if (pv_tune("conv_route", 0) == 3 || (pw && d->cin <= pv_tune("conv_small_cin", 128))) return 1;
-  if (!(pw || (cout_p8 >= 64 && d->cin >= 64))) return 1;
-  const int sp = pv_gemm9_splits(*d);
-  if (sp > 1) {
-    const long M = (long)d->B * d->To * d->Ho * d->Wo;
-    const long tiles = pv_ceil_div(M, 256) * pv_ceil_div(cout_p8, 256);
-    if (ws_bytes) *ws_bytes = tiles * (sp - 1) * 256L * 256L * 4L;
-    if (flag_bytes) *flag_bytes = tiles * (sp - 1) * 2L * 4L;     // [ticket, published] per pair group
-  }
-  return sp;
 }
 
 extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {

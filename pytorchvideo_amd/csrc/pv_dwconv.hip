@@ -233,15 +233,14 @@ __global__ void dw_prefix_kernel(const pv_dwconv3d_desc d) {
 constexpr int kPlaneThreads = 256;  // 4 waves = 4 output rows
 constexpr int kPR = kPlaneThreads / 64;
 
-// OCC4 (round 4; stride 1, narrow tile, no ReLU): compiled for FOUR waves per SIMD (<= 128 registers) without the second
-// plane in flight.  The narrow-tile variant needs 134 registers = three waves per SIMD = 768 workgroup slots; X3D-M's res4
-// conv_b is 1792 workgroups (2.33 rounds -> 3) and res5's 896 (1.17 -> 2).  With 1024 slots they are 2 rounds and 1.
-template <int S, int NW, int ACT, bool OCC4 = false>
-__global__ __launch_bounds__(kPlaneThreads, OCC4 ? 4 : 1) void dw3_plane_kernel(const pv_dwconv3d_desc d, int ntiles, int ngroups) {
+// (A four-waves-per-SIMD build of the narrow tile -- <= 128 registers, no second plane in flight, so that res4's 1792
+// workgroups are 2 rounds instead of 3 -- measured -1.8 % on X3D-M in the two-branch form in round 4 and is gone.)
+template <int S, int NW, int ACT>
+__global__ __launch_bounds__(kPlaneThreads, 1) void dw3_plane_kernel(const pv_dwconv3d_desc d, int ntiles, int ngroups) {
   constexpr int TW = 4 * NW;               // tile width (outputs)
   constexpr int IH = (kPR - 1) * S + 3;
   constexpr int IW = (TW - 1) * S + 3;
-  constexpr bool kDeep = S == 1 && !OCC4;   // small planes: keep two of them in flight (OCC4: occupancy hides the latency instead)
+  constexpr bool kDeep = S == 1;   // small planes: keep two of them in flight
   constexpr int IWP = (IW + 1) & ~1;       // LDS row pitch (even: columns are pair-swapped)
   constexpr int NVOX = IH * IW;
   constexpr int NITEM = NVOX * 4;          // 16-byte items per plane
@@ -483,14 +482,6 @@ template <int S, int NW> int launch_plane(const pv_dwconv3d_desc& d, hipStream_t
     const int total = d.B * d.n_prefix * (c_p / 8);
     PV_LAUNCH(dw_prefix_kernel<bf16_t>, dim3((unsigned)pv_ceil_div(total, kThreads)), dim3(kThreads), 0, s, d);
     PV_LAUNCH_CHECK();
-  }
-  if constexpr (S == 1 && NW == 2) {
-    if (d.act != PV_ACT_RELU && pv_tune("dw_occ4", 0)) {     // off: measured -1.8 % on X3D-M (profiles/r4/dropped/)
-      if (d.act == PV_ACT_NONE) PV_LAUNCH((dw3_plane_kernel<S, NW, PV_ACT_NONE, true>), grid, block, 0, s, d, ntiles, ngroups);
-      else PV_LAUNCH((dw3_plane_kernel<S, NW, PV_ACT_SWISH, true>), grid, block, 0, s, d, ntiles, ngroups);
-      PV_LAUNCH_CHECK();
-      return PV_OK;
-    }
   }
   if (d.act == PV_ACT_NONE) PV_LAUNCH((dw3_plane_kernel<S, NW, PV_ACT_NONE>), grid, block, 0, s, d, ntiles, ngroups);
   else if (d.act == PV_ACT_RELU) PV_LAUNCH((dw3_plane_kernel<S, NW, PV_ACT_RELU>), grid, block, 0, s, d, ntiles, ngroups);

@@ -482,12 +482,8 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   // tile for half the MFMA work); this rule gains SlowFast-R50 1.4 % and MViT-B 0.7 %.
   const long t128 = pv_ceil_div(M, 128) * tiles_n;
   const int force_vt = pv_tune("gemm_vt", 0);
-  // ... and (round 4, pv_tune "gemm_vt_tail", A/B'd in profiles/r4/) where the LAST round of 128-row tiles would be less
-  // than tail_pct % full (MViT-B's 384 x 384 projections: 588 tiles on 512 slots = a second round for 76 tiles): half-height
-  // tiles pack 1179 of them into 2.3 half-rounds.
-  const int tail_pct = pv_tune("gemm_vt_tail", 0);
-  const bool thin_tail = tail_pct > 0 && t128 > resident && (t128 % resident) * 100 < (long)tail_pct * resident && (t128 % resident) != 0;
-  const int vt = force_vt ? force_vt : ((2 * t128 <= resident || thin_tail) ? 1 : 2);
+  // (half-height tiles where only the LAST round of 128-row tiles is thin measured -0.7 % on MViT-B in round 4 and are gone)
+  const int vt = force_vt ? force_vt : (2 * t128 <= resident ? 1 : 2);
   const long tiles_m = pv_ceil_div(M, 64 * vt);
   const long total = tiles_m * tiles_n;
   if (total <= 0 || total > 0x7fffffffL || M > 0x7fffffffL) return PV_ERR_UNSUPPORTED;

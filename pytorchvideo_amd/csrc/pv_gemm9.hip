@@ -53,8 +53,7 @@ constexpr int LDS9_ELEMS = 8 * UNIT9;   // 128 KB
 __device__ __forceinline__ constexpr int unit_a(int P, int a) { return (2 * P + a) * UNIT9; }
 __device__ __forceinline__ constexpr int unit_b(int P, int v) { return (4 + 2 * P + v) * UNIT9; }
 constexpr int kTab9 = LDS9_ELEMS * 2;       // byte offset of the epilogue tables: [tile parity][scale 256 f32 | shift 256 f32]
-constexpr int kMisc9 = kTab9 + 2 * 2048;    // one word for workgroup broadcasts (16 bytes)
-constexpr int kGeo9 = kMisc9 + 16;          // implicit-GEMM staging geometry: 32 bytes per thread
+constexpr int kGeo9 = kTab9 + 2 * 2048;          // implicit-GEMM staging geometry: 32 bytes per thread
 constexpr int kLds9Bytes = kGeo9 + kThreads9 * 32;
 constexpr int kRegionB9 = 4 * UNIT9 * 2;   // byte offset of the voxel units (folded into the read base: immediates stay < 64 K)
 
@@ -76,9 +75,8 @@ struct Geom9 {         // per-thread staging rows of one output tile (DMA j of a
   // half (each thread reads only what it wrote: no synchronisation)
 };
 
-template <bool PW, bool YF32, int VAR, bool SPLIT>
-__global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles, int splits) {
-  // total_tiles counts WORK ITEMS: output tiles x K slices (splits = 1: the tiles themselves)
+template <bool PW, bool YF32, int VAR>
+__global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem9_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem9_raw);
 
@@ -89,7 +87,7 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   const int S_out = d.To * d.Ho * d.Wo;
   const long M = (long)d.B * S_out;
   const int K = d.kt * d.kh * d.kw * d.cin;
-  const int nk = (K >> 6) / splits;   // K tiles per work item
+  const int nk = K >> 6;
   const int cout_p8 = pv_round_up(d.cout, 8);
   const int dil_t = d.dil_t > 1 ? d.dil_t : 1, dil_h = d.dil_h > 1 ? d.dil_h : 1, dil_w = d.dil_w > 1 ? d.dil_w : 1;
   const bf16_t* __restrict__ X = static_cast<const bf16_t*>(d.x);
@@ -97,14 +95,10 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   const unsigned long zaddr = (unsigned long)reinterpret_cast<const bf16_t*>(pv_zero_page9);
 
   // ---- staging rows of this thread (the same for every unit): DMA j covers unit rows 64 j + 8 wave + lane / 8 ----
-  // work item -> (output tile, K slice), XCD-aware (bijective for any count; the slices of a tile are consecutive items: they run
-  // on one XCD, whose L2 then carries their partial tiles)
-  auto tile_origin = [&](int it, long& m0, int& n0, int& tile, int& slice) __attribute__((always_inline)) {
+  auto tile_origin = [&](int it, long& m0, int& n0) __attribute__((always_inline)) {   // XCD-aware tile order (bijective for any tile count)
     const int xcd = it & 7, slot = it >> 3;
     const int qn = total_tiles >> 3, rn = total_tiles & 7;
-    const int idx = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
-    tile = idx / splits;
-    slice = idx - tile * splits;
+    const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
     m0 = (long)(tile / tiles_n) * BT9;
     n0 = (tile % tiles_n) * BT9;
   };
@@ -116,20 +110,12 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   const unsigned a_pitch = (unsigned)K * 2u, a_last = (unsigned)(d.cout - 1) * a_pitch;
   const unsigned b_pitch = (unsigned)d.ldx * 2u, b_last = (unsigned)(M - 1) * b_pitch;
   int* geo = reinterpret_cast<int*>(smem9_raw + kGeo9) + tid * 8;   // (!PW) this thread's staging geometry
-  int iss_kt0 = 0;   // first K tile of the stream's work item (its slice of the reduction)
   int iss_c0 = 0, iss_dt = 0, iss_dh = 0, iss_dw = 0;   // channel offset inside the tap, tap coordinates (wave-uniform)
   auto geom_of = [&](int it, Geom9& g) __attribute__((always_inline)) {
     long m0;
-    int n0, tile, slice;
-    tile_origin(it, m0, n0, tile, slice);
-    iss_kt0 = slice * nk;
-    if constexpr (!PW) {
-      const int tap = (iss_kt0 * 64) / d.cin;
-      iss_c0 = iss_kt0 * 64 - tap * d.cin;
-      iss_dw = tap % d.kw;
-      iss_dh = (tap / d.kw) % d.kh;
-      iss_dt = tap / (d.kw * d.kh);
-    }
+    int n0;
+    tile_origin(it, m0, n0);
+    iss_c0 = iss_dt = iss_dh = iss_dw = 0;
     const int rho0 = 8 * wave + (lane >> 3);   // unit row of DMA 0 (< 64)
     g.a_row = (unsigned)(n0 + 32 * (rho0 >> 5) + chi9(rho0 & 31)) * a_pitch;
     if constexpr (PW) {
@@ -173,7 +159,7 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   };
   // jsel: 0 / 1 = that DMA of the unit only, -1 = both
   auto issue_a = [&](int a, int unit, int jsel) __attribute__((always_inline)) {   // channel half a of the stream's K tile -> LDS unit `unit`
-    const unsigned kc = (unsigned)((iss_kt0 + iss_ku) * 128 + chunk8 * 2);
+    const unsigned kc = (unsigned)(iss_ku * 128 + chunk8 * 2);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (jsel >= 0 && jsel != j) continue;
@@ -186,7 +172,7 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   auto issue_b = [&](int v, int unit, int jsel, const i32x4& gq) __attribute__((always_inline)) {   // voxel half v (gq: its geometry)
     if constexpr (PW) {
-      const unsigned kc = (unsigned)((iss_kt0 + iss_ku) * 128 + chunk8 * 2);
+      const unsigned kc = (unsigned)(iss_ku * 128 + chunk8 * 2);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (jsel >= 0 && jsel != j) continue;
@@ -209,8 +195,15 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     }
   };
   auto load_geo = [&](int v) __attribute__((always_inline)) -> i32x4 {
-    if constexpr (PW) return i32x4{0, 0, 0, 0};
-    else return *reinterpret_cast<const i32x4*>(geo + v * 4);
+    if constexpr (PW) {
+      return i32x4{0, 0, 0, 0};
+    } else {
+      // (the address is rebuilt from the thread index behind an empty asm: as a loop-invariant register it was the one value the
+      // compiler spilled, and its reload -- a scratch load + vmcnt(0) in the loop header -- drained the DMA pipeline every K-tile pair)
+      unsigned t = threadIdx.x;
+      asm volatile("" : "+v"(t));
+      return *reinterpret_cast<const i32x4*>(smem9_raw + kGeo9 + t * 32u + (unsigned)v * 16u);
+    }
   };
   // folded BatchNorm / bias tables of the stream's tile -> LDS, one 4-byte DMA per thread: wave w < 4 carries scale[64 w ..
   // 64 w + 63] of the tile's 256 channels, w >= 4 the shift (channels past cout read a clamped entry: zeroed in the epilogue).
@@ -220,8 +213,8 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     const float* tab = wave < 4 ? d.scale : d.shift;
     if (tab != nullptr && iss_live) {
       long m0;
-      int n0, tile, slice;
-      tile_origin(iss_it, m0, n0, tile, slice);
+      int n0;
+      tile_origin(iss_it, m0, n0);
       int n = n0 + 64 * (wave & 3) + lane;
       n = n < d.cout ? n : d.cout - 1;
       __builtin_amdgcn_global_load_lds((gptr9_t)(tab + n), (lptr9_t)(smem9_raw + kTab9 + (iss_jt & 1) * 2048 + wave * 256), 4, 0, 0);
@@ -400,74 +393,8 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
     const int wn = wave & 1, wm = wave >> 1;
     // ---- epilogue: lane owns channels cb..cb+15 of voxel m for every (channel tile a, voxel tile v) ----
     long m0;
-    int n0, tile, slice;
-    tile_origin(it, m0, n0, tile, slice);
-    bool finish_tile = true;   // workgroup-uniform: this workgroup writes the output tile
-    if constexpr (SPLIT) {
-      // ---- split K: a tile's `splits` = 2^L slices are summed PAIRWISE in L levels (slices s and s ^ 1, then the pair sums, ...):
-      // of the two workgroups of a group the one that arrives FIRST parks its partial tile in d.ws and is done, the second adds
-      // it to its accumulators and goes on to the next level; the last level's second arriver runs the epilogue.  Every
-      // addition has exactly two fixed operands and fp32 addition commutes, so the result does not depend on who arrives
-      // first: bit-identical from run to run (hipGraph replays are compared bit for bit by the tests).
-      // Hand-off recipe of cdna_hip_programming.md 5 / 6 Guideline 16 (R1): the partial tile leaves as write-through (sc1)
-      // 16-byte stores, every wave drains its stores, barrier, ONE relaxed agent-scope flag store; the other side polls the
-      // flag relaxed, barrier, sc1 loads.  Deadlock-free for any placement: a workgroup only waits for a partner that has
-      // ALREADY drawn its ticket, i.e. that is past its K loop and busy publishing.  ws_flags per tile and group: [ticket,
-      // published], all zero at rest (the second arriver re-arms them: graph replays need no memset).
-      constexpr unsigned kSlabBytes = 256u * 256u * 4u;
-      int* s_misc = reinterpret_cast<int*>(smem9_raw + kMisc9);
-      // lane-linear image: piece q of accumulator block (a, v) of wave w is the 1 KB at ((w * 8 + a * 2 + v) * 4 + q) KB
-      const unsigned lane_off = (unsigned)(wave * 32) * 1024u + (unsigned)lane * 16u;
-      for (int lvl = 0; (1 << lvl) < splits; ++lvl) {
-        const int gi = (splits - (splits >> lvl)) + (slice >> (lvl + 1));     // group index inside the tile, 0 .. splits - 2
-        int* fl = d.ws_flags + ((long)tile * (splits - 1) + gi) * 2;
-        if (tid == 0) s_misc[lvl] = __hip_atomic_fetch_add(fl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const int ticket = __builtin_amdgcn_readfirstlane(s_misc[lvl]);
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            static_cast<char*>(d.ws) + ((long)tile * (splits - 1) + gi) * kSlabBytes, 0, (int)kSlabBytes, 0x00020000);
-        if (ticket == 0) {
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int v = 0; v < 2; ++v)
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                __builtin_amdgcn_raw_buffer_store_b128(
-                    u32x4{__float_as_uint(acc[a][v][4 * q + 0]), __float_as_uint(acc[a][v][4 * q + 1]),
-                          __float_as_uint(acc[a][v][4 * q + 2]), __float_as_uint(acc[a][v][4 * q + 3])},
-                    rs, (int)(lane_off + (unsigned)((a * 2 + v) * 4 + q) * 1024u), 0, /*sc1: write-through*/ 16);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          if (tid == 0) __hip_atomic_store(fl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          finish_tile = false;
-          break;
-        }
-        if (tid == 0) {
-          int spins = 0;      // bounded: a lost partner must not hang the GPU (the result is then wrong and the tests say so)
-          while (__hip_atomic_load(fl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 20))
-            __builtin_amdgcn_s_sleep(4);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int v = 0; v < 2; ++v) {
-            u32x4 part[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              part[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane_off + (unsigned)((a * 2 + v) * 4 + q) * 1024u), 0, 16);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[a][v][4 * q + e] += __uint_as_float(part[q][e]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        __syncthreads();
-        if (tid < 2) __hip_atomic_store(fl + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
-      }
-    }
-    if (finish_tile) {
+    int n0;
+    tile_origin(it, m0, n0);
     long e_b[2], e_sp[2];
     bool e_ok[2];
 #pragma unroll
@@ -606,9 +533,6 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
       }
     }
     stores_behind = true;   // the four phases of the next K tile wait on units requested BEFORE these stores
-    } else {
-      stores_behind = false;  // (everything was drained before the flag went up)
-    }
     if (half_b) __builtin_amdgcn_s_barrier();   // (see above: matched by the first half's next B1)
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -624,14 +548,14 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   __builtin_amdgcn_s_waitcnt(vml(0));          // the stream's trailing (zero-page) DMAs land before the LDS is released
 }
 
-template <bool PW, bool YF32, int VAR, bool SPLIT>
-int launch9(const pv_conv3d_desc& d, int tiles_n, long total, int splits, hipStream_t s) {
+template <bool PW, bool YF32, int VAR>
+int launch9(const pv_conv3d_desc& d, int tiles_n, long total, hipStream_t s) {
   const size_t lds = (size_t)kLds9Bytes;   // 128 KB of units + 4 KB of epilogue tables
-  auto kern = gemm_quad_kernel<PW, YF32, VAR, SPLIT>;
+  auto kern = gemm_quad_kernel<PW, YF32, VAR>;
   PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long resident = 256;   // one workgroup per CU
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads9);
-  PV_LAUNCH(kern, grid, block, lds, s, d, tiles_n, (int)total, splits);
+  PV_LAUNCH(kern, grid, block, lds, s, d, tiles_n, (int)total);
   pv_note_kernel("gemm_quad_kernel");   // (launched through a function pointer: PV_LAUNCH saw only the variable)
   PV_LAUNCH_CHECK();
   return PV_OK;
@@ -659,23 +583,6 @@ static bool gemm9_geometry_ok(const pv_conv3d_desc& d, long& M, long& K, long& t
   return tiles_m * tiles_n > 0 && tiles_m * tiles_n < 0x3fffffffL;
 }
 
-// K slices per tile the library WOULD use for this geometry (1 = none): only where the tile list leaves at least half of the
-// CUs idle, the slices fill the chip at most once (every slice's workgroup is resident: the reducer's wait is short) and a
-// slice keeps >= 8 K tiles (the partial-tile exchange costs ~2 x 4 us per tile, profiles/r5)
-int pv_gemm9_splits(const pv_conv3d_desc& d) {
-  long M, K, tiles_m;
-  int tiles_n;
-  if (pv_tune("gemm9", 1) == 0 || pv_tune("gemm9_splitk", 1) == 0 || !gemm9_geometry_ok(d, M, K, tiles_m, tiles_n)) return 1;
-  const long tiles = tiles_m * tiles_n;
-  const int cout_p8 = pv_round_up(d.cout, 8);
-  if ((double)((long)tiles_n * BT9 - cout_p8) / (double)cout_p8 > 0.15) return 1;
-  if (tiles >= pv_tune("gemm9_min_tiles", 200) || tiles < 32) return 1;
-  int best = 1;
-  for (int sp = 2; sp <= 8; sp *= 2)     // powers of two: the slices are summed pairwise
-    if (tiles * sp <= 256 && K % (128L * sp) == 0 && K / sp >= 512) best = sp;
-  return best;
-}
-
 // Returns PV_OK when this kernel took the op, PV_ERR_UNSUPPORTED to leave it to the older GEMM kernels.
 int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   const int mode = pv_tune("gemm9", 1);   // 0 off, 1 heuristic, 2 wherever the kernel can run
@@ -685,14 +592,7 @@ int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   if (!gemm9_geometry_ok(d, M, K, tiles_m, tiles_n)) return PV_ERR_UNSUPPORTED;
   const int cout_p8 = pv_round_up(d.cout, 8);
   const long tiles = tiles_m * tiles_n;
-  int splits = 1;
-  if (d.ws != nullptr && d.ws_flags != nullptr && d.ws_splits > 1) {   // a workspace sized by pv_conv3d_splitk for this geometry
-    splits = d.ws_splits;
-    // pairwise sum: a power of two; every slice's workgroup resident at once (a waiting workgroup's partner is always running)
-    if ((splits != 2 && splits != 4 && splits != 8) || K % (128L * splits) != 0 || K / splits < 256 || tiles * splits > 256)
-      return PV_ERR_INVALID;
-  }
-  const long total = tiles * splits;
+  const long total = tiles;
   if (mode == 1) {
     // one workgroup per CU: the work items must fill the chip, and a 256-channel tile must not be mostly padding
     const double waste = (double)((long)tiles_n * BT9 - cout_p8) / (double)cout_p8;
@@ -701,20 +601,17 @@ int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   }
   // the pointwise form addresses voxel row m at x + m * ldx: batch items must follow each other without a gap
   const bool rows = pw && d.x_bs == (long)d.To * d.Ho * d.Wo * d.ldx;
-  // variant (pv_tune "gemm9_var"): 0 = DMAs before the phase's barrier; 2 = among the phase's MFMAs (default for K >= 1024: +5 %
-  // on long reductions, -10 % on four-K-tile layers); (bit 2, every wave of a half issuing
-  // behind a different MFMA, measured 8x slower -- its branches spill inside the loop -- and is gone).  (Bit 0, reading the next K
-  // tile's first channel half a phase early, measured 5-12 % SLOWER in every shape and is not instantiated any more:
-  // profiles/r5/bench_gemm_quad_v3_variants.txt.)
+  // variant (pv_tune "gemm9_var"): 0 = a phase's two DMAs before its first barrier; 2 = among its MFMAs (default from six K
+  // tiles on: +5 ... 12 % on long reductions, -6 % on four-K-tile layers).  Measured and removed in round 5 (profiles/r5/):
+  // reading the next K tile's first channel half a phase early (bit 0: 5-12 % slower everywhere), every wave of a half issuing
+  // behind a different MFMA (bit 2: spills inside the loop), and the reduction split over workgroups for layers with fewer
+  // than 200 tiles (pairwise sums through L2 with tickets: correct and bit-reproducible, but 20-45 % SLOWER than the 128 x 128
+  // kernel on SlowFast's res4 / res5 shapes -- the implicit-GEMM form of it kept an accumulator block in scratch).
   int var = pv_tune("gemm9_var", -1);
-  if (var < 0) var = K / splits >= 1024 ? 2 : 0;
-#define PV9_GO(PWv, YFv)                                                                            \
-  if (splits > 1) {                                                                                 \
-    if (var == 2) return launch9<PWv, YFv, 2, true>(d, tiles_n, total, splits, s);                  \
-    return launch9<PWv, YFv, 0, true>(d, tiles_n, total, splits, s);                                \
-  }                                                                                                 \
-  if (var == 2) return launch9<PWv, YFv, 2, false>(d, tiles_n, total, splits, s);                   \
-  return launch9<PWv, YFv, 0, false>(d, tiles_n, total, splits, s);
+  if (var < 0) var = K >= 384 ? 2 : 0;
+#define PV9_GO(PWv, YFv)                                                  \
+  if (var == 2) return launch9<PWv, YFv, 2>(d, tiles_n, total, s);        \
+  return launch9<PWv, YFv, 0>(d, tiles_n, total, s);
   if (d.y_f32) {
     if (rows) { PV9_GO(true, true) } else { PV9_GO(false, true) }
   } else {

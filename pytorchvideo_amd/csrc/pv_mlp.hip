@@ -626,328 +626,11 @@ __global__ __launch_bounds__(256, MINW) void ln_linear_rows_kernel(const pv_ln_l
   __builtin_amdgcn_s_waitcnt(vm(0));        // the padding block's LDS-DMA must not outlive the workgroup
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// ln_linear_rows_kernel with TWO row sets per wave (round 4, pv_tune "ln_linear_rs" = 2): a workgroup covers 256 rows, a wave
-// the rows w*32.. of both 128-row halves, and every weight fragment read from LDS feeds two MFMAs (four accumulator chains
-// instead of two).  The narrow layers this kernel serves (MViT-B blocks 0-2: 96 / 192 channels, 400 k / 100 k rows) are not
-// MFMA-bound: a workgroup streams the whole filter through LDS for its rows, 12 MFMAs per staged block and barrier -- per
-// row this halves the L2 -> LDS weight traffic, the barriers and the counted waits.  Same arithmetic per row, same bits.
-template <int KS, int MINW>
-__global__ __launch_bounds__(256, MINW) void ln_linear_rows2_kernel(const pv_ln_linear_desc d) {
-  constexpr int RS = 2;
-  constexpr int STAGE = KS * 1024 + kB1Bytes;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi = lane >> 5;
-  long m[RS], mm[RS];
-  bool ok[RS];
-#pragma unroll
-  for (int rs = 0; rs < RS; ++rs) {
-    m[rs] = (long)blockIdx.x * (128 * RS) + rs * 128 + wave * 32 + l31;
-    ok[rs] = m[rs] < d.M;
-    mm[rs] = ok[rs] ? m[rs] : 0;
-  }
-  const int NB = d.N >> 5;
-  constexpr auto vm = [](int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); };
-
-  const unsigned char* wsrc = static_cast<const unsigned char*>(d.wb);
-  auto stage = [&](int nb, int buf) {
-    const unsigned char* src = wsrc + (long)nb * STAGE;
-    unsigned char* dst = smem + buf * STAGE;
-#pragma unroll
-    for (int p0 = 0; p0 < KS; p0 += 4) {
-      const int p = p0 + wave < KS ? p0 + wave : KS - 1;
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + p * 1024 + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
-    }
-    if (wave == (KS & 3))
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + KS * 1024 + lane * 4), (lptr_t)(dst + KS * 1024), 4, 0, 0);
-  };
-
-  // ---- LayerNorm of this lane's half rows -> MFMA B fragments, one row set after the other (see ln_linear_rows_kernel)
-  bf16x8 bx[RS][KS];
-#pragma unroll
-  for (int rs = 0; rs < RS; ++rs) {
-    const float* xr = static_cast<const float*>(d.x) + mm[rs] * d.ldx + 16 * hi;
-    const float shift0 = static_cast<const float*>(d.x)[mm[rs] * d.ldx];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < KS / 2; ++q) {
-      const f32x4* p4 = reinterpret_cast<const f32x4*>(xr + 32 * q);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = p4[g];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float t = v[e] - shift0; s1 += t; s2 += t * t; }
-      }
-      if ((q & 3) == 3) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-    }
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    const float inv_c = 1.0f / (float)(16 * KS);
-    const float mu_s = s1 * inv_c;
-    const float mean = shift0 + mu_s;
-    const float rstd = rsqrtf(fmaxf(s2 * inv_c - mu_s * mu_s, 0.f) + d.ln_eps);
-    constexpr int NQ = KS / 2;
-    constexpr int GQ2 = (NQ % 2 == 0) ? NQ / 2 : 1;
-    static_assert(NQ % GQ2 == 0 && 4 * GQ2 * 2048 <= 2 * STAGE, "LayerNorm staging does not fit");
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const f32x4* g4 = reinterpret_cast<const f32x4*>(d.ln_gamma + 32 * q + 16 * hi);
-      const f32x4* b4 = reinterpret_cast<const f32x4*>(d.ln_beta + 32 * q + 16 * hi);
-      const f32x4* p4 = reinterpret_cast<const f32x4*>(xr + 32 * q);
-      float xn[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = p4[g], gg = g4[g], bb = b4[g];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xn[4 * g + e] = (v[e] - mean) * rstd * gg[e] + bb[e];
-      }
-      bf16x8 t0, t1;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { t0[j] = (bf16_t)xn[j]; t1[j] = (bf16_t)xn[8 + j]; }
-      unsigned char* lp = smem + wave * (GQ2 * 2048) + (q % GQ2) * 2048 + lane * 32;
-      *reinterpret_cast<bf16x8*>(lp) = t0;
-      *reinterpret_cast<bf16x8*>(lp + 16) = t1;
-      if (q % GQ2 == GQ2 - 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int qq = q - (GQ2 - 1); qq <= q; ++qq) {
-          const unsigned char* rp = smem + wave * (GQ2 * 2048) + (qq % GQ2) * 2048 + lane * 32;
-          bx[rs][2 * qq] = *reinterpret_cast<const bf16x8*>(rp);
-          bx[rs][2 * qq + 1] = *reinterpret_cast<const bf16x8*>(rp + 16);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-
-  __builtin_amdgcn_s_barrier();     // every wave is done with its LayerNorm staging area: the weight stream may use the buffers
-  stage(0, 0);
-  stage(1, 1);
-  bf16_t* yr[RS];
-#pragma unroll
-  for (int rs = 0; rs < RS; ++rs) yr[rs] = static_cast<bf16_t*>(d.y) + m[rs] * d.ldy + 16 * hi;
-  // stores this wave issues per output block: two per row set that has a row in range (see ln_linear_rows_kernel)
-  const int nst = (__builtin_amdgcn_ballot_w64(ok[0]) != 0ul ? 2 : 0) + (__builtin_amdgcn_ballot_w64(ok[1]) != 0ul ? 2 : 0);
-  const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_offset(smem));
-  constexpr int PF = KS < 8 ? KS : 8;
-  constexpr int NPW = (KS + 3) / 4;
-  int cur = 0;
-  for (int nb = 0; nb < NB; ++nb) {
-    {
-      const int dma_next = (wave == (KS & 3)) ? NPW + 1 : NPW;
-      const int allow = dma_next + (nb >= 1 ? nst : 0) + (nb >= 2 ? nst : 0);
-      switch (allow - NPW) {          // (s_waitcnt takes an immediate)
-        case 0: __builtin_amdgcn_s_waitcnt(vm(NPW)); break;
-        case 1: __builtin_amdgcn_s_waitcnt(vm(NPW + 1)); break;
-        case 2: __builtin_amdgcn_s_waitcnt(vm(NPW + 2)); break;
-        case 3: __builtin_amdgcn_s_waitcnt(vm(NPW + 3)); break;
-        case 4: __builtin_amdgcn_s_waitcnt(vm(NPW + 4)); break;
-        case 5: __builtin_amdgcn_s_waitcnt(vm(NPW + 5)); break;
-        case 6: __builtin_amdgcn_s_waitcnt(vm(NPW + 6)); break;
-        case 7: __builtin_amdgcn_s_waitcnt(vm(NPW + 7)); break;
-        case 8: __builtin_amdgcn_s_waitcnt(vm(NPW + 8)); break;
-        default: __builtin_amdgcn_s_waitcnt(vm(NPW + 9)); break;
-      }
-    }
-    __builtin_amdgcn_s_barrier();
-    const int nxt = cur == 0 ? 2 : cur - 1;                          // (nb + 2) % 3
-    const unsigned char* nsrc = wsrc + (long)(nb + 2) * STAGE;      // (two blocks of padding behind the last: no branch)
-    const unsigned ndst_lds = smem_lds + nxt * STAGE;
-    const unsigned char* ws = smem + cur * STAGE + lane * 16;
-    const float* bs = reinterpret_cast<const float*>(smem + cur * STAGE + KS * 1024) + 16 * hi;
-    cur = cur == 2 ? 0 : cur + 1;
-    bf16x8 ring[PF];
-#pragma unroll
-    for (int f = 0; f < PF; ++f) ring[f] = *reinterpret_cast<const bf16x8*>(ws + f * 1024);
-    f32x4 bb[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bb[g] = *reinterpret_cast<const f32x4*>(bs + 4 * g);
-    f32x16 D0[RS], D1[RS];
-#pragma unroll
-    for (int rs = 0; rs < RS; ++rs)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { D0[rs][r] = 0.f; D1[rs][r] = 0.f; }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int f = 0; f < KS; ++f) {
-      const bf16x8 afrag = ring[f % PF];
-      if (f + PF < KS) ring[f % PF] = *reinterpret_cast<const bf16x8*>(ws + (f + PF) * 1024);
-#pragma unroll
-      for (int rs = 0; rs < RS; ++rs) {
-        if (f & 1) D1[rs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[rs][f], D1[rs], 0, 0, 0);
-        else D0[rs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[rs][f], D0[rs], 0, 0, 0);
-      }
-      if (f % (KS / NPW) == 0 && f / (KS / NPW) < NPW) {
-        const int pc = 4 * (f / (KS / NPW)) + wave;
-        const int pq = (KS % 4 == 0 || pc < KS) ? pc : KS - 1;      // every wave issues NPW pieces (counted waits)
-        dma16_asm(nsrc + pq * 1024 + lane * 16, ndst_lds + pq * 1024);
-      }
-      if (f == KS - 1 && wave == (KS & 3)) dma4_asm(nsrc + KS * 1024 + lane * 4, ndst_lds + KS * 1024);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int rs = 0; rs < RS; ++rs) {
-      float h[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[4 * g + e] = D0[rs][4 * g + e] + D1[rs][4 * g + e] + bb[g][e];
-      if (d.act != PV_ACT_NONE) pv_apply_act_n<true, 16>(h, d.act);
-      bf16x8 o0, o1;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { o0[j] = (bf16_t)h[j]; o1[j] = (bf16_t)h[8 + j]; }
-      if (ok[rs]) {
-        *reinterpret_cast<bf16x8*>(yr[rs] + 32 * nb) = o0;
-        *reinterpret_cast<bf16x8*>(yr[rs] + 32 * nb + 8) = o1;
-      }
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(vm(0));        // the padding block's LDS-DMA must not outlive the workgroup
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Linear + residual on token rows:  y[m][:] (fp32) = R[m][:] + b + W . x[m][:],  x a bf16 operand tensor -- the output
-// projection of MultiScaleAttention with the block's residual join (layers/attention.py:541-544, :745-749) for the widths
-// where the 128 x 128-tile GEMM is latency-bound (K = N = 384: six K-steps per tile, 588 tiles on 512 slots: 31 us for
-// 7.4 GFLOP).  Same row-resident mapping as ln_linear_rows_kernel: the wave's 32 rows are MFMA B operands in registers
-// for the whole kernel, W streams through the three-stage LDS ring one 32-channel output block at a time.  The residual
-// rows are loaded into registers BEFORE the loop (16 fp32 per lane and output block) and are the C operand of each block's
-// first MFMA, so the loop issues no load the compiler would wait for behind the LDS-DMA stream; the output-block loop is
-// fully unrolled (the residual array must be indexed statically).  196 workgroups of 128 rows for MViT-B's 25 096 tokens:
-// one round.
-template <int KS, int NOB>
-__global__ __launch_bounds__(256, 1) void linear_res_rows_kernel(const pv_ln_linear_desc d) {
-  constexpr int STAGE = KS * 1024 + kB1Bytes;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi = lane >> 5;
-  const long m = (long)blockIdx.x * 128 + wave * 32 + l31;
-  const bool ok = m < d.M;
-  const long mm = ok ? m : 0;
-  constexpr auto vm = [](int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); };
-
-  const unsigned char* wsrc = static_cast<const unsigned char*>(d.wb);
-  auto stage = [&](int nb, int buf) {
-    const unsigned char* src = wsrc + (long)nb * STAGE;
-    unsigned char* dst = smem + buf * STAGE;
-#pragma unroll
-    for (int p0 = 0; p0 < KS; p0 += 4) {
-      const int p = p0 + wave < KS ? p0 + wave : KS - 1;
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + p * 1024 + lane * 16), (lptr_t)(dst + p * 1024), 16, 0, 0);
-    }
-    if (wave == (KS & 3))
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + KS * 1024 + lane * 4), (lptr_t)(dst + KS * 1024), 4, 0, 0);
-  };
-  stage(0, 0);
-  stage(1, 1);
-
-  bf16x8 bx[KS];
-  {
-    const bf16_t* xr = static_cast<const bf16_t*>(d.x) + mm * d.ldx + 16 * hi;
-#pragma unroll
-    for (int q = 0; q < KS / 2; ++q) {
-      bx[2 * q] = *reinterpret_cast<const bf16x8*>(xr + 32 * q);
-      bx[2 * q + 1] = *reinterpret_cast<const bf16x8*>(xr + 32 * q + 8);
-    }
-  }
-  f32x16 R[NOB];
-  {
-    const float* rr = d.residual + mm * d.ldr + 16 * hi;
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-      const f32x4* p4 = reinterpret_cast<const f32x4*>(rr + 32 * ob);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = p4[g];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) R[ob][4 * g + e] = v[e];
-      }
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(vm(0));        // operands, residual rows and the first two weight blocks: nothing is in flight at the loop
-  float* yr = static_cast<float*>(d.y) + m * d.ldy + 16 * hi;
-  const bool wave_stores = __builtin_amdgcn_ballot_w64(ok) != 0ul;     // see ln_linear_rows_kernel
-  const unsigned smem_lds = __builtin_amdgcn_readfirstlane(lds_offset(smem));
-  constexpr int PF = KS < 8 ? KS : 8;
-  constexpr int NPW = (KS + 3) / 4;
-  const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int nb = 0; nb < NOB; ++nb) {
-    // Issue order of this wave's vector-memory operations: ... DMA(nb), stores(nb - 2), DMA(nb + 1), stores(nb - 1); four
-    // 16-byte stores per block.  Block nb has landed once at most the operations issued after its pieces are in flight.
-    {
-      const int dma_next = (wave == (KS & 3)) ? NPW + 1 : NPW;
-      const int st = wave_stores ? 4 : 0;
-      const int allow = dma_next + (nb >= 1 ? st : 0) + (nb >= 2 ? st : 0);
-      switch (allow - NPW) {          // (s_waitcnt takes an immediate)
-        case 0: __builtin_amdgcn_s_waitcnt(vm(NPW)); break;
-        case 1: __builtin_amdgcn_s_waitcnt(vm(NPW + 1)); break;
-        case 4: __builtin_amdgcn_s_waitcnt(vm(NPW + 4)); break;
-        case 5: __builtin_amdgcn_s_waitcnt(vm(NPW + 5)); break;
-        case 8: __builtin_amdgcn_s_waitcnt(vm(NPW + 8)); break;
-        default: __builtin_amdgcn_s_waitcnt(vm(NPW + 9)); break;
-      }
-    }
-    __builtin_amdgcn_s_barrier();
-    const int cur = nb % 3, nxt = (nb + 2) % 3;      // (compile-time: the loop is unrolled)
-    const unsigned char* nsrc = wsrc + (long)(nb + 2) * STAGE;      // (two blocks of padding behind the last: no branch)
-    const unsigned ndst_lds = smem_lds + nxt * STAGE;
-    const unsigned char* ws = smem + cur * STAGE + lane * 16;
-    const float* bs = reinterpret_cast<const float*>(smem + cur * STAGE + KS * 1024) + 16 * hi;
-    bf16x8 ring[PF];
-#pragma unroll
-    for (int f = 0; f < PF; ++f) ring[f] = *reinterpret_cast<const bf16x8*>(ws + f * 1024);
-    f32x4 bb[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bb[g] = *reinterpret_cast<const f32x4*>(bs + 4 * g);
-    f32x16 D0 = R[nb], D1 = kZero16;
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int f = 0; f < KS; ++f) {
-      const bf16x8 afrag = ring[f % PF];
-      if (f + PF < KS) ring[f % PF] = *reinterpret_cast<const bf16x8*>(ws + (f + PF) * 1024);
-      if (f & 1) D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[f], D1, 0, 0, 0);
-      else D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bx[f], D0, 0, 0, 0);
-      if (f % (KS / NPW) == 0 && f / (KS / NPW) < NPW) {
-        const int pc = 4 * (f / (KS / NPW)) + wave;
-        const int pq = (KS % 4 == 0 || pc < KS) ? pc : KS - 1;
-        dma16_asm(nsrc + pq * 1024 + lane * 16, ndst_lds + pq * 1024);
-      }
-      if (f == KS - 1 && wave == (KS & 3)) dma4_asm(nsrc + KS * 1024 + lane * 4, ndst_lds + KS * 1024);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (ok) {
-      f32x4* p4 = reinterpret_cast<f32x4*>(yr + 32 * nb);
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        p4[g] = f32x4{D0[4 * g] + D1[4 * g] + bb[g][0], D0[4 * g + 1] + D1[4 * g + 1] + bb[g][1],
-                      D0[4 * g + 2] + D1[4 * g + 2] + bb[g][2], D0[4 * g + 3] + D1[4 * g + 3] + bb[g][3]};
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(vm(0));        // the padding block's LDS-DMA must not outlive the workgroup
-}
-
-template <int KS, int NOB> int launch_linear_res(const pv_ln_linear_desc& d, hipStream_t s) {
-  PV_LAUNCH((linear_res_rows_kernel<KS, NOB>), dim3((unsigned)pv_ceil_div(d.M, 128)), dim3(256), 0, s, d);
-  PV_LAUNCH_CHECK();
-  return PV_OK;
-}
+// (Round 4's two variants of this kernel -- two row sets per wave, +-0 on MViT-B, and the attention output projection +
+// residual join on a row-resident kernel, -4 % against the tiled GEMM -- were measured, documented in DESIGN 7 and removed
+// in round 5: the product library carries no switched-off kernels.)
 
 template <int KS, int MINW> int launch_ln_linear(const pv_ln_linear_desc& d, hipStream_t s) {
-  if constexpr (KS <= 12) {
-    if (pv_tune("ln_linear_rs", 1) >= 2) {
-      PV_LAUNCH((ln_linear_rows2_kernel<KS, MINW>), dim3((unsigned)pv_ceil_div(d.M, 256)), dim3(256), 0, s, d);
-      PV_LAUNCH_CHECK();
-      return PV_OK;
-    }
-  }
   PV_LAUNCH((ln_linear_rows_kernel<KS, MINW>), dim3((unsigned)pv_ceil_div(d.M, 128)), dim3(256), 0, s, d);
   PV_LAUNCH_CHECK();
   return PV_OK;
@@ -957,11 +640,6 @@ int check_ln_linear(const pv_ln_linear_desc& d) {
   if (!d.x || !d.wb || !d.y || d.M <= 0 || d.M > 0x7fffffffL) return PV_ERR_INVALID;
   if (d.dtype != PV_BF16) return PV_ERR_UNSUPPORTED;
   if (d.C <= 0 || d.C % 32 || d.N <= 0 || d.N % 32) return PV_ERR_UNSUPPORTED;
-  if (d.residual != nullptr) {      // residual mode: bf16 operand in, fp32 stream out, no LayerNorm, no activation
-    if (d.ln_gamma || d.ln_beta || d.act != PV_ACT_NONE) return PV_ERR_INVALID;
-    if (d.ldx < d.C || d.ldx % 8 || d.ldy < d.N || d.ldy % 4 || d.ldr < d.N || d.ldr % 4) return PV_ERR_INVALID;
-    return PV_OK;
-  }
   if (!d.ln_gamma || !d.ln_beta) return PV_ERR_INVALID;
   if (d.ldx < d.C || d.ldx % 4 || d.ldy < d.N || d.ldy % 8) return PV_ERR_INVALID;
   return PV_OK;
@@ -1042,7 +720,6 @@ extern "C" int pv_mlp_rows(const pv_mlp_desc* dp, pv_stream_t stream) {
 
 extern "C" int pv_ln_linear_rows_supported(const pv_ln_linear_desc* d) {
   if (!d || check_ln_linear(*d) != PV_OK) return 0;
-  if (d->residual != nullptr) return (d->C == 384 && d->N == 384) || (d->C == 192 && d->N == 192);
   return d->C == 96 || d->C == 192 || d->C == 384 || d->C == 768;
 }
 
@@ -1051,11 +728,6 @@ extern "C" int pv_ln_linear_rows(const pv_ln_linear_desc* dp, pv_stream_t stream
   const int rc = check_ln_linear(*dp);
   if (rc != PV_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dp->residual != nullptr) {
-    if (dp->C == 384 && dp->N == 384) return launch_linear_res<24, 12>(*dp, s);
-    if (dp->C == 192 && dp->N == 192) return launch_linear_res<12, 6>(*dp, s);
-    return PV_ERR_UNSUPPORTED;
-  }
   switch (dp->C) {
     case 96: return launch_ln_linear<6, 2>(*dp, s);
     case 192: return launch_ln_linear<12, 2>(*dp, s);

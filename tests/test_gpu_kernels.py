@@ -957,7 +957,7 @@ def _routed_kernel(op, d):
         lib.pv_plan_destroy(plan)
 
 
-def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm8", splitk=0):
+def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm8"):
     """pv_conv3d forced onto a large-tile kernel (pv_tune gemm8 = 2 | 4, or gemm9 = 2) vs torch on the same bf16-rounded data."""
     dtype = torch.bfloat16
     pad = tuple(kk // 2 for kk in k)
@@ -988,14 +988,6 @@ def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, k
     d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *stride, *pad)
     d.act, d.a_act, d.dtype, d.y_f32, d.r_f32 = act, L.ACT_NONE, L.PV_BF16, int(y_f32), int(y_f32 and res)
     L.tune(**{knob: ct})
-    wsb, flb = C.c_int64(0), C.c_int64(0)
-    sp = L.lib().pv_conv3d_splitk(C.byref(d), C.byref(wsb), C.byref(flb)) if (knob == "gemm9" and splitk) else 1
-    assert (sp > 1) == bool(splitk), (sp, splitk)
-    if sp > 1:       # the slices of a tile meet in this workspace; the tickets start at zero and the kernel re-arms them
-        ws = torch.empty(wsb.value, dtype=torch.uint8, device="cuda")
-        fl = torch.zeros(flb.value // 4, dtype=torch.int32, device="cuda")
-        d.ws, d.ws_flags, d.ws_splits = ws.data_ptr(), fl.data_ptr(), sp
-        assert sp == splitk
     try:
         call("pv_conv3d", d)
         routed = _routed_kernel(L.OP_CONV3D, d)
@@ -1004,10 +996,7 @@ def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, k
     finally:
         L.tune(**{knob: 1})
     assert routed == {"gemm8": "gemm8_kernel", "gemm9": "gemm_quad_kernel"}[knob], routed
-    if sp > 1:
-        torch.cuda.synchronize()
-        assert int(fl.abs().sum().item()) == 0          # tickets and flags re-armed by the second arriver of every pair
-    assert torch.equal(got1, y)                         # (split-K included: pairwise sums of fixed operands, fp32 addition commutes)
+    assert torch.equal(got1, y)
     assert rel_err(y[..., :cout].permute(0, 4, 1, 2, 3), want) <= 1e-2
     if cp > cout:
         assert torch.all(y[..., cout:] == 0)       # padding channels are written as zeros
@@ -1093,17 +1082,6 @@ def test_quad_phase_gemm_kernel(B, T, H, W, cin, cout, k, stride, act, res, y_f3
     _gemm8_case(2, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm9")
 
 
-@pytest.mark.parametrize("B,T,H,W,cin,cout,k,stride,act,res,y_f32,affine,splits", [
-    (16, 8, 16, 16, 1024, 256, (3, 1, 1), (1, 1, 1), L.ACT_RELU, False, False, True, 2),   # SlowFast res4 conv_a: 128 tiles
-    (16, 8, 16, 16, 256, 256, (1, 3, 3), (1, 1, 1), L.ACT_RELU, False, False, True, 2),    # res4 conv_b
-    (16, 8, 8, 8, 512, 512, (1, 3, 3), (1, 1, 1), L.ACT_RELU, True, False, True, 4),       # res5 conv_b: 64 tiles, residual
-    (1, 1, 1, 8192, 2048, 500, (1, 1, 1), (1, 1, 1), L.ACT_GELU, True, True, False, 4),    # pointwise form, fp32 stream, N tail
-    (1, 1, 1, 9000, 1536, 768, (1, 1, 1), (1, 1, 1), L.ACT_NONE, False, False, False, 2),  # 108 tiles, M tail
-    (2, 8, 16, 16, 1024, 512, (3, 1, 1), (1, 1, 1), L.ACT_RELU, False, False, True, 8),    # 32 tiles: three levels of pair sums
-])
-def test_quad_phase_gemm_kernel_with_the_reduction_split_over_workgroups(B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine,
-                                                                         splits):
-    _gemm8_case(1, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm9", splitk=splits)
 
 
 @pytest.mark.parametrize("B,T,H,W,cin,cout,k,stride", [
@@ -1220,44 +1198,6 @@ def test_fused_mlp_rows(M, Cin, H, Cout, ln, res):
     assert L.lib().pv_mlp_rows_supported(C.byref(d)) == 0
 
 
-@pytest.mark.parametrize("M,Cw", [(6274, 384), (25096, 384), (129, 384), (31, 384), (1001, 192), (513, 192)])
-def test_linear_plus_residual_on_token_rows(M, Cw):
-    """pv_ln_linear_rows, residual mode (round 4): y (fp32) = residual + b + W . x for a bf16 operand x -- the attention output
-    projection with the block's residual join (layers/attention.py:541-544,745-749) on the row-resident kernel -- against
-    fp32 torch on the same bf16-rounded operands; ragged last tile, a last workgroup whose trailing waves hold no row, row
-    strides wider than the widths; bitwise reproducible."""
-    from pytorchvideo_amd.accelerator.mi355x.emit_mvit import pack_ln_linear_weights
-    g = torch.Generator().manual_seed(178)
-    w = (torch.randn(Cw, Cw, generator=g) * Cw ** -0.5).bfloat16().float()
-    b = torch.randn(Cw, generator=g) * 0.3
-    x = (torch.randn(M, Cw, generator=g) * 1.5).bfloat16()
-    r = torch.randn(M, Cw, generator=g) * 2.0 + 3.0 * torch.randn(M, 1, generator=g)
-    want = r + F.linear(x.float(), w, b)
-    img = pack_ln_linear_weights(w, b).cuda()
-    ldx, ldr, ldy = Cw + 8, Cw + 4, Cw + 12
-    xd = torch.zeros(M, ldx, dtype=torch.bfloat16, device="cuda")
-    xd[:, :Cw] = x.cuda()
-    rd = torch.zeros(M, ldr, device="cuda")
-    rd[:, :Cw] = r.cuda()
-    y = torch.full((M, ldy), 7.0, device="cuda")
-    d = L.LnLinearDesc()
-    d.x, d.wb, d.y, d.residual = xd.data_ptr(), img.data_ptr(), y.data_ptr(), rd.data_ptr()
-    d.M, d.C, d.N, d.ldx, d.ldy, d.ldr, d.act, d.dtype = M, Cw, Cw, ldx, ldy, ldr, L.ACT_NONE, L.PV_BF16
-    assert L.lib().pv_ln_linear_rows_supported(C.byref(d)) == 1
-    call("pv_ln_linear_rows", d)
-    assert rel_err(y[:, :Cw], want) <= 2e-3          # fp32 accumulation of exact bf16 products: only the summation order differs
-    assert torch.all(y[:, Cw:] == 7.0)               # nothing written past the row
-    y2 = torch.zeros_like(y)
-    d.y = y2.data_ptr()
-    call("pv_ln_linear_rows", d)
-    assert torch.equal(y2[:, :Cw], y[:, :Cw])
-    # descriptors the mode does not take
-    d.act = L.ACT_RELU
-    assert L.lib().pv_ln_linear_rows_supported(C.byref(d)) == 0
-    d.act, d.N = L.ACT_NONE, 2 * Cw
-    assert L.lib().pv_ln_linear_rows_supported(C.byref(d)) == 0
-
-
 @pytest.mark.parametrize("M,Cin,N", [(300, 96, 288), (1001, 192, 576), (6274, 384, 1152), (129, 384, 96), (785 * 2, 768, 2304),
                                      (31, 96, 32)])
 def test_layernorm_fused_into_the_qkv_linear(M, Cin, N):
@@ -1284,12 +1224,3 @@ def test_layernorm_fused_into_the_qkv_linear(M, Cin, N):
     d.y = y2.data_ptr()
     call("pv_ln_linear_rows", d)
     assert torch.equal(y, y2)
-    # the two-row-set variant (pv_tune "ln_linear_rs" = 2; narrow widths): the same arithmetic per row, the same bits
-    L.tune(ln_linear_rs=2)
-    try:
-        y3 = torch.full((M, N), 3.0, dtype=torch.bfloat16, device="cuda")
-        d.y = y3.data_ptr()
-        call("pv_ln_linear_rows", d)
-        assert torch.equal(y, y3)
-    finally:
-        L.tune(ln_linear_rs=1)

@@ -259,17 +259,7 @@ def test_mvit_plan_fuses_kv_pooling_and_position_tables():
     assert labels.count("attn.qkv") == 16 and labels.count("attn.core") == 16            # one fused q|k|v GEMM per block
     assert labels.count("attn.pool_k") + labels.count("attn.pool_v") <= 2 * 16
     # every stream-producing GEMM keeps the residual stream in fp32
-    # (round 4: the projections of the 384- / 192-wide blocks run on the row-resident kernel, residual mode: fp32 by construction)
-    assert all(f["y_f32"] == 1 if "y_f32" in f else f["residual"] is not None
-               for l, f in ops if l.split("|")[0] in ("attn.proj", "mlp.fc2"))
-    from pytorchvideo_amd.accelerator.mi355x import tuning
-    tuning.OPTIONS["proj_rows"] = True          # (off by default: measured 4 % slower on the whole model)
-    try:
-        cfg2 = dict(mvit_video_base_config, temporal_size=8, spatial_size=112, head_num_classes=5)
-        ops2 = _plan_labels_and_fields(create(**cfg2).eval(), None, mvit_input=torch.zeros(2, 3, 8, 112, 112, dtype=torch.bfloat16))
-        assert any(l.startswith("attn.proj") and l.endswith(" rows") for l, _ in ops2)
-    finally:
-        tuning.OPTIONS["proj_rows"] = False
+    assert all(f["y_f32"] == 1 for l, f in ops if l.split("|")[0] in ("attn.proj", "mlp.fc2"))
     # small token grids: q, k and v of a block are pooled (conv + cls + LayerNorm) by ONE launch
     assert labels.count("attn.pool_qkv") >= 14 and not any(l.endswith(".norm") and "pool" in l for l in labels)
 

@@ -2,9 +2,10 @@
 
 The row-resident kernels order their LDS-DMA weight stream with vmcnt immediates that COUNT the vector-memory operations
 a wave issues per block: the DMA pieces (inline asm, invisible to the compiler's own waitcnt pass) and the stores of the
-epilogue.  The counts are written in the source as "two stores per block" (ln_linear_rows_kernel) / "four stores per
-block" (linear_res_rows_kernel); a compiler that merged, split or re-ordered those stores would make the waits too lax and
-MFMAs would read half-landed weights with no signal but numeric drift.  This test compiles the file to gfx950 assembly
+epilogue.  The counts are written in the source as "two stores per block" (ln_linear_rows_kernel); a compiler that merged,
+split or re-ordered those stores would make the waits too lax and MFMAs would read half-landed weights with no signal but
+numeric drift.  Round 5 adds the eight-phase GEMM (csrc/pv_gemm9.hip): its main loop must carry the counted waits as written
+and no scratch traffic (a spilled register's reload is a `vmcnt(0)` that drains the LDS-DMA pipeline).  This test compiles the file to gfx950 assembly
 (hipcc cross-compiles without a GPU) and counts what the compiler actually emitted.  ROCm 7.2 / hipcc of this image."""
 import os
 import re
@@ -39,19 +40,6 @@ def _meta(asm, mangled_fragment):
     return {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)\n", m.group(2))}
 
 
-def test_linear_res_rows_issues_exactly_four_stores_and_twentyfour_mfmas_per_block(mlp_asm):
-    body = _body(mlp_asm, "linear_res_rows_kernelILi24ELi12EE")
-    assert body.count("v_mfma_f32_32x32x16_bf16") == 12 * 24
-    assert len(re.findall(r"global_store_dwordx4", body)) == 12 * 4          # the counted waits say: 4 per block
-    assert len(re.findall(r"global_store_dword(x2|x3)? ", body)) == 0        # ... and nothing narrower beside them
-    # the DMA pieces: 6 per wave and block + the two prologue stages (the bias pieces are 4-byte DMAs)
-    assert len(re.findall(r"global_load_lds_dwordx4", body)) == 12 * 6 + 2 * 6
-    # no compiler-made full drain inside the block loop: vmcnt(0) only before the loop and at the very end
-    assert len(re.findall(r"s_waitcnt vmcnt\(0\)", body)) <= 2
-    meta = _meta(mlp_asm, "linear_res_rows_kernelILi24ELi12EE")
-    assert meta["private_segment_fixed_size"] == 0 and meta["vgpr_spill_count"] == 0
-
-
 def test_ln_linear_rows_issues_two_stores_per_block(mlp_asm):
     body = _body(mlp_asm, "ln_linear_rows_kernelILi24ELi2EE")
     # one output block per loop iteration (runtime trip count): the loop body holds the 24 MFMAs once and two 16-byte stores
@@ -66,3 +54,53 @@ def test_fused_mlp_main_variant_has_no_scratch_and_streams_its_weights_by_dma(ml
     assert meta["private_segment_fixed_size"] == 0 and meta["vgpr_spill_count"] == 0
     body = _body(mlp_asm, "mlp_rows_kernelILi24ELi12ELb1ELi1ELi3ELi0EE")
     assert "global_load_lds_dwordx4" in body
+
+
+@pytest.fixture(scope="module")
+def gemm9_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not present")
+    out = str(tmp_path_factory.mktemp("isa9") / "pv_gemm9.s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "pytorchvideo_amd", "csrc"), "-S", "--cuda-device-only", "-o", out,
+                           os.path.join(ROOT, "pytorchvideo_amd", "csrc", "pv_gemm9.hip")], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _inner_loop(asm, mangled_fragment):
+    """The innermost loop that holds MFMAs (the K-tile-pair loop): the basic blocks LLVM's comments attribute to it."""
+    m = re.search(r"^(_ZN\S*%s\S*):[^\n]*\n(.*?)^\s*\.size\s" % re.escape(mangled_fragment), asm, re.S | re.M)
+    assert m, "kernel %s not found" % mangled_fragment
+    lines = m.group(2).split("\n")
+    best = None
+    for i, l in enumerate(lines):
+        if "Inner Loop Header" in l:
+            lab = lines[i - 1].split(":")[0].strip()
+            key = "Header=" + lab[2:] + " "
+            idx = [j for j, x in enumerate(lines) if key in x]
+            end = (idx[-1] if idx else i) + 1
+            while end < len(lines) and not re.match(r"^\.LBB\d+_\d+:", lines[end]):
+                end += 1
+            body = lines[i - 1:end]
+            if sum("v_mfma" in x for x in body) > 0:
+                best = body
+    assert best is not None
+    return best
+
+
+@pytest.mark.parametrize("frag,wait", [("gemm_quad_kernelILb1ELb0ELi2EE", 6), ("gemm_quad_kernelILb1ELb0ELi0EE", 8),
+                                       ("gemm_quad_kernelILb0ELb0ELi2EE", 6), ("gemm_quad_kernelILb1ELb1ELi2EE", 6)])
+def test_eight_phase_gemm_main_loop_carries_the_counted_waits_and_no_scratch(gemm9_asm, frag, wait):
+    body = _inner_loop(gemm9_asm, frag)
+    # the loop header block up to the tile-crossing branch is the common path: 8 phases = 2 K tiles
+    text = "\n".join(body)
+    assert len(re.findall(r"s_waitcnt vmcnt\(%d\) lgkmcnt\(0\)" % wait, text)) >= 6      # one counted wait per phase (LLVM rotates the loop by up to two phases)
+    assert len(re.findall(r"v_mfma_f32_32x32x16_bf16", text)) >= 64 - 16                  # (LLVM rotates the loop by a phase or two)
+    # scratch (spill reloads: a vmcnt(0) each) only in the rarely taken tile-crossing blocks, never in the loop header's path
+    header = []
+    for l in body[1:]:
+        if re.match(r"^\.LBB", l) or "s_cbranch" in l:
+            break
+        header.append(l)
+    assert not any("scratch_" in l for l in header)
+    assert sum("scratch_" in l for l in body) <= 24

@@ -75,13 +75,6 @@ def run(label, B, T, H, W, cin, cout, k, s, p, iters=20):
     d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *s, *p)
     d.act, d.a_act, d.dtype = ACT, L.ACT_NONE, L.PV_BF16
     lib = L.lib()
-    wsb, flb = C.c_int64(0), C.c_int64(0)
-    sp = lib.pv_conv3d_splitk(C.byref(d), C.byref(wsb), C.byref(flb))     # split-K workspace where the library would use one
-    if sp > 1:
-        ws = torch.empty(wsb.value, dtype=torch.uint8, device="cuda")
-        fl = torch.zeros(flb.value // 4, dtype=torch.int32, device="cuda")
-        d.ws, d.ws_flags, d.ws_splits = ws.data_ptr(), fl.data_ptr(), sp
-        label = label + " [splitK%d]" % sp
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
         L.check(lib.pv_conv3d(C.byref(d), st))
