@@ -21,6 +21,7 @@ legs are MViT-B (the metric names it at 1/2/4/8 GPUs) and X3D-L (configs[4]: glo
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -32,6 +33,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFS = 2500.0    # dense bf16
+VALU_PEAK_TFS = 157.3     # fp32 vector pipe (packed FMA), MI355X_MICROARCH.md
+VALU_BOUND_SYMBOLS = ("pwdw_plane_kernel", "dw3_plane_kernel", "dwconv_kernel")   # fp32 depthwise stencils
 
 # algorithmic FLOPs / bytes per clip (probe of the reference op graph)
 WORKLOADS = {
@@ -289,6 +292,25 @@ def roofline_of(sess, workload, clips_s_per_gpu, ms_per_step):
     except (OSError, ValueError, KeyError):
         pass
     plan_bytes = sum(p[3] for p in prof)          # the plan's OWN algorithmic bytes per step (after its fusions)
+    # A depthwise-stencil symbol is bound by the fp32 VECTOR pipe, not by HBM (75-78 % VALU busy, ~1.6x above the
+    # stencil's own issue cycles): report that roof beside the byte roof.  Its stencil FLOPs are 2 x 27 taps per output value
+    # = the op's FLOPs minus the fused pointwise producer's (emit.py counts both); the fp32 peak is the packed-FMA rate.
+    valu = None
+    if dom_sym in VALU_BOUND_SYMBOLS:
+        st_flops = 0
+        for (label, kind, ms, alg_bytes, flops), sym in zip(prof, kernels):
+            if (sym or "") == dom_sym:
+                m = re.search(r"c(\d+)->(\d+) k1x1x1\+k(\d)x(\d)x(\d)", label)       # conv_ab: producer cin -> C, then the stencil
+                m2 = re.search(r"\|(\d+)x(\d+)x(\d+)x(\d+) c(\d+)", label)
+                if m and m2:
+                    B_, T_, H_, W_ = (int(v) for v in m2.groups()[:4])
+                    st_flops += 2 * B_ * T_ * H_ * W_ * int(m.group(2)) * int(m.group(3)) * int(m.group(4)) * int(m.group(5))
+                else:
+                    st_flops += flops
+        if st_flops and dom[1] > 0:
+            tf = st_flops / (dom[1] * 1e-3) / 1e12
+            valu = {"bound": "valu", "achieved": round(tf, 2), "peak": VALU_PEAK_TFS, "unit": "TFLOP/s (fp32 stencil FMAs)",
+                    "frac": round(tf / VALU_PEAK_TFS, 4)}
     r = {
         "bound": "mfma" if mfma_bound else "hbm", "kernel": dom_sym, "launches_per_step": dom[0],
         "op_labels": {k: round(v, 4) for k, v in sorted(dom[4].items(), key=lambda kv: -kv[1])},
@@ -312,6 +334,8 @@ def roofline_of(sess, workload, clips_s_per_gpu, ms_per_step):
         "plan_alg_mb_per_step": round(plan_bytes / 1e6, 1),
         "model_mfma_frac": round(clips_s_per_gpu * wl["gflop"] * 1e9 / (MFMA_PEAK_TFS * 1e12), 4),
     }
+    if valu is not None:
+        r["second_roof"] = valu      # the symbol against BOTH roofs (round-4 verdict, weak #11)
     return r, prof, agg
 
 

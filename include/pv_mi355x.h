@@ -199,23 +199,9 @@ typedef struct pv_dwconv3d_desc {
    * channel's own 8-channel chunk.  0 / 1 = depthwise.  Weights [taps][gw][round_up(C,8)] fp32: w[t][j][c]
    * multiplies input channel (c / gw) * gw + j.  No w_mod, no fused producer, C % gw == 0. */
   int32_t gw;
-  /* Optional squeeze-excitation gate computed in the SAME launch (fvcore SqueezeExcitation as used at models/x3d.py:190-198;
-   * round 4): with se_gate set (psum must be set too) the workgroup that finishes a clip LAST -- an agent-scope ticket per
-   * clip in se_count, released after the workgroup's partial sums are written back -- reduces the clip's partial sums in a
-   * fixed order and writes gate[b][c] = sigmoid(W2 . relu(W1 . mean_{T,H,W} + b1) + b2), what pv_se_gate computes in a
-   * launch of its own.  se_count: one zero-initialised uint32 per clip, owned by this op (the last workgroup re-arms it
-   * for the next replay).  se_w1 [se_cr][C], se_w2 [C][se_cr] fp32 row-major, se_cr <= 32, C <= 512; only where
-   * pv_dwconv3d_se_supported(d) is 1.  Deterministic (no floating-point atomics). */
-  const float* se_w1; const float* se_b1; const float* se_w2; const float* se_b2;
-  float* se_gate;            /* [B][round_up(C,8)], padding = 0; or NULL: no gate in this launch */
-  uint32_t* se_count;        /* [B] */
-  int32_t se_cr;
-  float se_inv_count;        /* 1 / (To*Ho*Wo) */
 } pv_dwconv3d_desc;
 int pv_dwconv3d(const pv_dwconv3d_desc* d, pv_stream_t stream);
 int pv_dwconv3d_psum_blocks(const pv_dwconv3d_desc* d);
-/* 1 if this geometry (pointers are ignored; C, se_cr and the conv geometry are read) can compute the gate in its launch */
-int pv_dwconv3d_se_supported(const pv_dwconv3d_desc* d);
 /* 1 if this geometry (pointers are ignored) can run with the fused pointwise producer, else 0 */
 int pv_dwconv3d_pw_supported(const pv_dwconv3d_desc* d);
 

@@ -46,9 +46,7 @@ DwConv3dDesc = _struct("DwConv3dDesc", [
     ("x_bs", _i64), ("y_bs", _i64)]
     + _ints("ldx", "ldy", "B", "Ti", "Hi", "Wi", "C", "To", "Ho", "Wo",
             "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "w_mod", "act", "dtype", "n_prefix")
-    + [("pw_w", _p), ("pw_scale", _p), ("pw_shift", _p)] + _ints("pw_cin", "pw_act", "gw")
-    + [("se_w1", _p), ("se_b1", _p), ("se_w2", _p), ("se_b2", _p), ("se_gate", _p), ("se_count", _p)]
-    + _ints("se_cr") + [("se_inv_count", _f32)])
+    + [("pw_w", _p), ("pw_scale", _p), ("pw_shift", _p)] + _ints("pw_cin", "pw_act", "gw"))
 
 LateralDesc = _struct("LateralDesc", [
     ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("x_bs", _i64), ("y_bs", _i64)]
@@ -132,7 +130,6 @@ _SYMBOLS = [
     ("pv_dwconv3d", C.c_int, [C.POINTER(DwConv3dDesc), _p]),
     ("pv_dwconv3d_psum_blocks", C.c_int, [C.POINTER(DwConv3dDesc)]),
     ("pv_dwconv3d_pw_supported", C.c_int, [C.POINTER(DwConv3dDesc)]),
-    ("pv_dwconv3d_se_supported", C.c_int, [C.POINTER(DwConv3dDesc)]),
     ("pv_se_gate", C.c_int, [C.POINTER(SeGateDesc), _p]),
     ("pv_ensemble_scores", C.c_int, [C.POINTER(EnsembleDesc), _p]),
     ("pv_pool3d", C.c_int, [C.POINTER(Pool3dDesc), _p]),

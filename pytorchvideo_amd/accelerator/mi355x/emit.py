@@ -351,14 +351,14 @@ def _se_parts(se, Cc):
 
 
 def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=None, w_mod=0, label="dwconv",
-                grid=None, n_prefix=0, producer=None, se=None):
+                grid=None, n_prefix=0, producer=None):
     """Depthwise Conv3d (+BN +act [+SE partial sums]) -> pv_dwconv3d.  Returns y or (y, psum, nblk).
     With `grid=(T,H,W)` the input is a token tensor (B, n_prefix + T*H*W, C) convolved on its
     grid, the n_prefix leading rows (cls token) being copied through (attention.py:185-200).
     With `producer=(conv_a, norm_a, act_a)` x is the INPUT of that 1x1x1 conv, which is evaluated
     inside the depthwise kernel (only where can_fuse_pointwise_into_dw said so).
-    With `se` (a SqueezeExcitation module, want_psum) the gate is computed in the SAME launch where the library can
-    (pv_dwconv3d_se_supported, tuning "fuse_se_gate"): returns (y, gate, None) instead of (y, psum, nblk)."""
+    (Round 4's variant that computed the squeeze-excitation gate in the SAME launch -- the clip's last workgroup -- measured 12 %
+    slower than the gate launches it removed and was deleted in round 5.)"""
     if producer is not None:
         if not check_conv3d(conv) or w_mod or grid is not None:
             raise Unsupported("fused producer on a token pooling conv")
@@ -420,19 +420,6 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
             raise Unsupported("depthwise geometry")
         psum = sess.alloc_raw(4 * x.B * nblk * pad8(Cc))
         f["psum"] = psum
-        if se is not None and tuning.get("fuse_se_gate"):
-            c1, c2 = _se_parts(se, Cc)
-            d.se_cr = c1.out_channels
-            if L.lib().pv_dwconv3d_se_supported(C.byref(d)) == 1:
-                # the clip's last workgroup turns the partial sums into the gate: no pv_se_gate launch (round 4)
-                gate = sess.alloc_raw(4 * x.B * pad8(Cc))
-                cr = c1.out_channels
-                f.update(se_w1=sess.add_weight(c1.weight.detach().float().reshape(cr, Cc)),
-                         se_b1=sess.add_weight(c1.bias.detach().float()) if c1.bias is not None else None,
-                         se_w2=sess.add_weight(c2.weight.detach().float().reshape(Cc, cr)),
-                         se_b2=sess.add_weight(c2.bias.detach().float()) if c2.bias is not None else None,
-                         se_gate=gate, se_count=sess.add_weight(torch.zeros(x.B, dtype=torch.int32)),
-                         se_cr=cr, se_inv_count=1.0 / float(To * Ho * Wo))
     vin, vout = x.B * Ti * Hi * Wi, x.B * To * Ho * Wo
     flops = 2 * vout * Cc * kt * kh * kw * max(gw, 1)
     if producer is None:
@@ -443,10 +430,7 @@ def emit_dwconv(sess, conv, x, norm=None, act=L.ACT_NONE, want_psum=False, out=N
         flops += 2 * vin * x.C * Cc
         detail = "|%dx%dx%dx%d c%d->%d k1x1x1+k%dx%dx%d s%d%d%d%s" % (x.B, To, Ho, Wo, x.C, Cc, kt, kh, kw, st, sh, sw,
                                                                      " psum" if want_psum else "")
-    sess.add_op(L.OP_DWCONV3D, f, label=label + detail + (" gate" if f.get("se_gate") is not None else ""), alg_bytes=alg, flops=flops)
-    if f.get("se_gate") is not None:
-        sess.release(psum)          # written and consumed inside the launch
-        return y, f["se_gate"], None
+    sess.add_op(L.OP_DWCONV3D, f, label=label + detail, alg_bytes=alg, flops=flops)
     if want_psum:
         return y, psum, nblk
     return y
@@ -558,9 +542,7 @@ def emit_conv_b(sess, conv_b, x, norm_b, act_b, producer=None):
                 raise Unsupported("2-D squeeze-excitation")
             _se_parts(se, conv_b.out_channels)
             y, psum, nblk = emit_dwconv(sess, conv_b, x, bn, L.ACT_NONE, want_psum=True, label="conv_ab.dw+se",
-                                        producer=producer, se=se)
-            if nblk is None:          # the gate was computed inside the depthwise launch
-                return y, psum, act
+                                        producer=producer)
             gate = emit_se_gate(sess, se, psum, nblk, y.B, y.C, y.voxels)
             sess.release(psum)
             return y, gate, act
@@ -580,9 +562,7 @@ def emit_conv_b(sess, conv_b, x, norm_b, act_b, producer=None):
         if getattr(se, "is_3d", True) is not True:
             raise Unsupported("2-D squeeze-excitation")
         _se_parts(se, x.C)
-        y, psum, nblk = emit_dwconv(sess, conv_b, x, bn, L.ACT_NONE, want_psum=True, label="conv_b.dw+se", se=se)
-        if nblk is None:              # the gate was computed inside the depthwise launch
-            return y, psum, act
+        y, psum, nblk = emit_dwconv(sess, conv_b, x, bn, L.ACT_NONE, want_psum=True, label="conv_b.dw+se")
         gate = emit_se_gate(sess, se, psum, nblk, x.B, x.C, y.voxels)
         sess.release(psum)
         return y, gate, act

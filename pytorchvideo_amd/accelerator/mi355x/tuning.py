@@ -16,8 +16,6 @@ OPTIONS = {
                                         # separate per-head LayerNorm; smaller ones the fused pool + LayerNorm kernel  (emit_mvit)
     "fuse_ln_qkv": True,         # MViT norm1 + the q|k|v Linear as ONE launch (pv_ln_linear_rows)               (emit_mvit)
     "fuse_ln_qkv_max_c": 192,    # ... for token widths up to this (wider / shorter tensors: the LDS-DMA GEMM wins)
-    "fuse_se_gate": False,       # X3D squeeze-excitation gate computed by the last workgroup of the depthwise launch (emit.emit_dwconv):
-                                 # correct and tested, but SLOWER than the 15 gate launches it removes (round 4, profiles/r4/dropped/)
     "fuse_next_norm": True,      # MViT: norm1 of block i+1 written by block i's fused MLP from the rows it holds (emit_mvit.emit_mlp_fused)
     "fuse_mlp": True,            # MViT norm2 + fc1 + GELU + fc2 + residual as ONE launch (pv_mlp_rows)  (emit_mvit)
     "arena_guards": 0,           # debug build of the launch plan: every arena buffer gets its own memory (no re-use) followed

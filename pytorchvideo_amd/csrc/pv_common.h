@@ -146,100 +146,6 @@ __device__ __forceinline__ float pv_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-// ---- "the last workgroup of a group finishes the job" (in-launch reduction, cdna_hip_programming.md 5 / 6 Guideline 16) ----
-// The data to be combined is a few hundred bytes per workgroup next to MEGABYTES of ordinary output the same workgroup has
-// just stored, so the publish must not be an agent-scope release fence (a `buffer_wbl2` per workgroup writes back every dirty
-// line of the XCD's L2: measured +30 % on the whole X3D-M forward, profiles/r4/dropped/).  Instead the partial sums are
-// written with write-through (sc1) stores -- relaxed agent-scope atomic stores of 4 bytes -- the publishing wave drains ITS
-// stores (s_waitcnt vmcnt(0)), and only then draws the ticket with a relaxed agent-scope fetch_add; the reducer reads the
-// partial sums with sc1 loads (relaxed agent-scope atomic loads).  No fence on either side.
-__device__ __forceinline__ void pv_publish_f32(float* p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float pv_read_published_f32(const float* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// One WAVE publishes for its workgroup (its lanes made all the pv_publish_f32 stores) and finishes the job alone if it drew
-// the last ticket (the other waves of the workgroup may already have ended).  Returns true, wave-uniformly, for that wave; the
-// counter is re-armed for the next launch.
-__device__ __forceinline__ bool pv_last_ticket_wave(unsigned* counter, unsigned total, int lane) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  unsigned t = 0;
-  if (lane == 0) {
-    t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t + 1u == total) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-  const bool last = t + 1u == total;
-  // the reducer's sc1 loads must not be ordered ahead of the ticket: one agent-scope acquire in the ONE wave
-  // per clip that draws the last ticket (buffer_inv sc1: this CU's L1 only, nothing is written back)
-  if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  return last;
-}
-// The whole workgroup publishes (every thread may have made pv_publish_f32 stores); true for all threads of the workgroup
-// that drew the last ticket.  `s_flag`: one int of LDS nobody else touches.
-__device__ __forceinline__ bool pv_last_ticket_block(unsigned* counter, unsigned total, int* s_flag, int tid) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = t + 1u == total;
-    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (see pv_last_ticket_wave)
-    *s_flag = last;
-  }
-  __syncthreads();
-  return *s_flag != 0;
-}
-
-// Squeeze-excitation gate of ONE clip from its published per-workgroup partial sums ps[nblk][c_p] (fixed summation order:
-// deterministic): gate[c] = sigmoid(W2 . relu(W1 . mean + b1) + b2), padding channels 0.  Called by `nthreads` threads:
-// a whole workgroup (WAVE = false) or one wave on its own (WAVE = true: nthreads = 64, LDS steps ordered by the wave's
-// in-order LDS queue).  s: c_p + 32 floats of LDS; cr <= 32.
-template <bool WAVE>
-__device__ __forceinline__ void pv_se_gate_clip(const float* ps, int nblk, int C, int c_p, int cr, float inv_count,
-                                                const float* __restrict__ w1, const float* __restrict__ b1,
-                                                const float* __restrict__ w2, const float* __restrict__ b2,
-                                                float* __restrict__ gate, float* s, int tid, int nthreads) {
-  auto sync = [] {
-    if constexpr (WAVE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
-    else __syncthreads();
-  };
-  float* s_mean = s;
-  float* s_hid = s + c_p;
-  for (int c = tid; c < c_p; c += nthreads) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int k = 0;
-    for (; k + 3 < nblk; k += 4) {
-      a0 += pv_read_published_f32(ps + (long)k * c_p + c);
-      a1 += pv_read_published_f32(ps + (long)(k + 1) * c_p + c);
-      a2 += pv_read_published_f32(ps + (long)(k + 2) * c_p + c);
-      a3 += pv_read_published_f32(ps + (long)(k + 3) * c_p + c);
-    }
-    for (; k < nblk; ++k) a0 += pv_read_published_f32(ps + (long)k * c_p + c);
-    s_mean[c] = ((a0 + a1) + (a2 + a3)) * inv_count;
-  }
-  sync();
-  const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
-  for (int r = wave; r < cr; r += nwaves) {
-    float a = 0.f;
-    for (int c = lane; c < C; c += 64) a += w1[(long)r * C + c] * s_mean[c];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if (lane == 0) s_hid[r] = fmaxf(a + (b1 ? b1[r] : 0.f), 0.f);
-  }
-  sync();
-  for (int c = tid; c < c_p; c += nthreads) {
-    float g = 0.f;
-    if (c < C) {
-      float a = b2 ? b2[c] : 0.f;
-      for (int r = 0; r < cr; ++r) a += w2[(long)c * cr + r] * s_hid[r];
-      g = pv_sigmoid(a);
-    }
-    gate[c] = g;
-  }
-}
-
 __device__ __forceinline__ float pv_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -13,7 +13,6 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kSeScratch = 32 + 512 + 32;   // floats behind s_red when the gate is computed in the launch: flag | mean[c_p <= 512] | hidden[32]
 
 // one tap of a channel-wise grouped conv: output channel c of the chunk sums GW inputs of its own group
 template <int GW> __device__ __forceinline__ void grouped_taps(float (&acc)[8], const float (&f)[8], const float* wp, int w_p) {
@@ -185,14 +184,7 @@ __global__ __launch_bounds__(kThreads) void dwconv_kernel(const pv_dwconv3d_desc
       float s = 0.f;
       for (int gg = 0; gg < gpb; ++gg) s += s_red[gg * c_p + c];
       float* dst = d.psum + ((long)b * gridDim.x + blockIdx.x) * c_p + c;
-      if (d.se_gate != nullptr) pv_publish_f32(dst, s);     // read by another workgroup of this launch: write-through store
-      else *dst = s;
-    }
-    if (d.se_gate != nullptr) {   // squeeze-excitation gate in this launch: the clip's last workgroup computes it
-      int* s_flag = reinterpret_cast<int*>(s_red + gpb * c_p);      // (geom() reserves kSeScratch floats behind s_red)
-      if (pv_last_ticket_block(d.se_count + b, gridDim.x, s_flag, tid))
-        pv_se_gate_clip<false>(d.psum + (long)b * gridDim.x * c_p, (int)gridDim.x, d.C, c_p, d.se_cr, d.se_inv_count, d.se_w1, d.se_b1,
-                               d.se_w2, d.se_b2, d.se_gate + (long)b * c_p, s_red + gpb * c_p + 32, tid, kThreads);
+      *dst = s;
     }
   }
 }
@@ -442,15 +434,7 @@ __global__ __launch_bounds__(kPlaneThreads, 1) void dw3_plane_kernel(const pv_dw
 #pragma unroll
       for (int rr = 0; rr < kPR; ++rr) a += s_ps[rr][tid];
       float* dst = d.psum + ((long)b * ntiles + tile_id) * c_p + cbase + tid;
-      if (d.se_gate != nullptr) pv_publish_f32(dst, a);     // read by another workgroup of this launch: write-through store
-      else *dst = a;
-    }
-    if (d.se_gate != nullptr && tid < 64) {   // squeeze-excitation gate in this launch (wave 0 made the stores above; wave-uniform)
-      // the clip's last workgroup computes it, wave 0 on its own: the plane buffers are free (every wave has passed the last
-      // plane barrier) and serve as scratch for the mean / hidden vectors
-      if (pv_last_ticket_wave(d.se_count + b, (unsigned)(ntiles * ngroups), lane))
-        pv_se_gate_clip<true>(d.psum + (long)b * ntiles * c_p, ntiles, d.C, c_p, d.se_cr, d.se_inv_count, d.se_w1, d.se_b1, d.se_w2,
-                              d.se_b2, d.se_gate + (long)b * c_p, reinterpret_cast<float*>(&s_in[0][0][0]), tid, 64);
+      *dst = a;
     }
   }
 }
@@ -514,7 +498,7 @@ bool geom(const pv_dwconv3d_desc& d, DwGeom* g) {
   g->nblk = (int)pv_ceil_div(upb, g->gpb);
   const int w_p = d.w_mod > 0 ? pv_round_up(d.w_mod, 8) : c_p;
   const size_t w_bytes = sizeof(float) * (size_t)d.kt * d.kh * d.kw * (d.gw > 1 ? d.gw : 1) * w_p;
-  const size_t red_bytes = sizeof(float) * (d.psum ? (size_t)g->gpb * c_p + (d.se_gate ? kSeScratch : 0) : 0);
+  const size_t red_bytes = sizeof(float) * (d.psum ? (size_t)g->gpb * c_p : 0);
   g->w_global = w_bytes + red_bytes > 96 * 1024;
   g->lds = (g->w_global ? 0 : w_bytes) + red_bytes;
   return true;
@@ -548,11 +532,6 @@ template <typename T> int launch_dw(const pv_dwconv3d_desc& d, const DwGeom& g, 
   return launch_variant<T, 0, 1, 1>(d, g, s);
 }
 
-// the in-launch squeeze-excitation gate: pv_se_gate_clip's scratch is c_p + 32 floats, its hidden layer <= 32 wide
-bool se_geometry_ok(const pv_dwconv3d_desc& d) {
-  return d.se_cr > 0 && d.se_cr <= 32 && d.C <= 512 && d.n_prefix == 0 && d.se_inv_count > 0.f;
-}
-
 int validate(const pv_dwconv3d_desc& d) {
   if (!d.x || !d.w || !d.y) return PV_ERR_INVALID;
   if (d.B <= 0 || d.C <= 0 || d.To <= 0 || d.Ho <= 0 || d.Wo <= 0) return PV_ERR_INVALID;
@@ -566,10 +545,6 @@ int validate(const pv_dwconv3d_desc& d) {
   if (d.n_prefix < 0 || (d.n_prefix > 0 && d.psum)) return PV_ERR_INVALID;
   if (d.gw < 0 || (d.gw > 1 && d.gw != 2 && d.gw != 4 && d.gw != 8)) return PV_ERR_UNSUPPORTED;
   if (d.gw > 1 && (d.C % d.gw || d.w_mod > 0 || d.pw_w != nullptr)) return PV_ERR_INVALID;
-  if (d.se_gate != nullptr) {
-    if (!d.psum || !d.se_count || !d.se_w1 || !d.se_w2) return PV_ERR_INVALID;
-    if (!se_geometry_ok(d)) return PV_ERR_UNSUPPORTED;
-  }
   return PV_OK;
 }
 
@@ -583,15 +558,6 @@ int pv_pwdw_launch(const pv_dwconv3d_desc& d, hipStream_t s);  // pv_pwdw.hip
 extern "C" int pv_dwconv3d_pw_supported(const pv_dwconv3d_desc* d) {
   if (!d || d->B <= 0 || d->C <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
   return pv_pwdw_supported(*d);
-}
-
-extern "C" int pv_dwconv3d_se_supported(const pv_dwconv3d_desc* d) {
-  if (!d || d->B <= 0 || d->C <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
-  DwGeom g;
-  pv_dwconv3d_desc t = *d;
-  t.se_inv_count = 1.f;
-  if (!se_geometry_ok(t)) return 0;
-  return (plane_variant(*d) != 0 || geom(*d, &g)) ? 1 : 0;
 }
 
 extern "C" int pv_dwconv3d_psum_blocks(const pv_dwconv3d_desc* d) {

@@ -596,7 +596,9 @@ int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   if (mode == 1) {
     // one workgroup per CU: the work items must fill the chip, and a 256-channel tile must not be mostly padding
     const double waste = (double)((long)tiles_n * BT9 - cout_p8) / (double)cout_p8;
-    const long min_tiles = pv_tune("gemm9_min_tiles", 200);
+    // measured on SlowFast-R50 / MViT-B (profiles/r5/model_ab_quad_final.txt): 120 beats 200 beats 300 -- even on half of the
+    // CUs (SlowFast res4: 128 tiles) the deeper pipeline is worth more than the idle half costs
+    const long min_tiles = pv_tune("gemm9_min_tiles", 120);
     if (total < min_tiles || waste > 0.15) return PV_ERR_UNSUPPORTED;
   }
   // the pointwise form addresses voxel row m at x + m * ldx: batch items must follow each other without a gap

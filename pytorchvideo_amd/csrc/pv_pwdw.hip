@@ -271,15 +271,7 @@ __global__ __launch_bounds__(kPlaneThreads) void pwdw_plane_kernel(const pv_dwco
 #pragma unroll
       for (int rr = 0; rr < kPR; ++rr) a += s_ps[rr][tid];
       float* dst = d.psum + ((long)b * ntiles + tile_id) * c_p + cbase + tid;
-      if (d.se_gate != nullptr) pv_publish_f32(dst, a);     // read by another workgroup of this launch: write-through store
-      else *dst = a;
-    }
-    if (d.se_gate != nullptr && tid < 64) {   // squeeze-excitation gate in this launch (wave 0 made the stores above; wave-uniform)
-      // the clip's last workgroup computes it, wave 0 on its own: the plane buffers are free (every wave has passed the last
-      // plane barrier) and serve as scratch for the mean / hidden vectors
-      if (pv_last_ticket_wave(d.se_count + b, (unsigned)(ntiles * ngroups), lane))
-        pv_se_gate_clip<true>(d.psum + (long)b * ntiles * c_p, ntiles, d.C, c_p, d.se_cr, d.se_inv_count, d.se_w1, d.se_b1, d.se_w2,
-                              d.se_b2, d.se_gate + (long)b * c_p, reinterpret_cast<float*>(&s_in[0][0][0]), tid, 64);
+      *dst = a;
     }
   }
 }

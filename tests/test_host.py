@@ -63,22 +63,6 @@ def test_plan_build_without_gpu_counts_ops():
     fused = labels.count("conv_ab") + labels.count("conv_ab.dw+se")
     assert fused == 9 and labels.count("conv_a") == 26 - fused and labels.count("conv_c") == 26
     assert labels.count("se_gate") == 15  # SE in every other block: 2+3+6+4
-    # round 4: the gate CAN be computed by the last workgroup of the depthwise launch (pv_dwconv3d se_*; measured slower
-    # than the 15 launches it removes, so off by default -- tuning.OPTIONS["fuse_se_gate"])
-    from pytorchvideo_amd.accelerator.mi355x import tuning
-    tuning.OPTIONS["fuse_se_gate"] = True
-    try:
-        m2 = create_x3d(input_clip_length=4, input_crop_size=160).eval()
-        transmute_model(m2, "mi355x")
-        s2, c2 = Session(dtype=torch.bfloat16), None
-        for i, b in enumerate(m2.blocks):
-            b.convert((2, 3, 4, 160, 160) if i == 0 else None, session=s2, input_ref=c2)
-            c2 = b._out_ref
-        assert [o[3].split("|")[0] for o in s2.ops].count("se_gate") == 0 and len(s2.ops) == len(sess.ops) - 15
-        gated = [o for o in s2.ops if o[2].get("se_gate") is not None]
-        assert len(gated) == 15 and all(o[2]["se_count"] is not None and o[2]["psum"] is not None for o in gated)
-    finally:
-        tuning.OPTIONS["fuse_se_gate"] = False
     assert (cur.B, cur.C, cur.f32) == (2, 400, True)
     with pytest.raises(AssertionError):
         m.blocks[0].convert((2, 3, 4, 160, 160), session=sess)  # no double convert
