@@ -583,10 +583,21 @@ static bool gemm9_geometry_ok(const pv_conv3d_desc& d, long& M, long& K, long& t
   return tiles_m * tiles_n > 0 && tiles_m * tiles_n < 0x3fffffffL;
 }
 
+int pv_gemm9h_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);   // pv_gemm9h.hip: the same loop on 128 x 256 tiles
+
 // Returns PV_OK when this kernel took the op, PV_ERR_UNSUPPORTED to leave it to the older GEMM kernels.
 int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   const int mode = pv_tune("gemm9", 1);   // 0 off, 1 heuristic, 2 wherever the kernel can run
   if (mode == 0) return PV_ERR_UNSUPPORTED;
+  {
+    // layers whose 256 x 256 tiles do not spread over the chip (SlowFast res4 / res5: 128 / 64 of them) go to the half-height
+    // form first; it declines what it cannot run (K % 192, tile count, padding)
+    const long t256 = pv_ceil_div((long)d.B * d.To * d.Ho * d.Wo, BT9) * pv_ceil_div((long)pv_round_up(d.cout, 8), BT9);
+    if (mode != 2 && (t256 < pv_tune("gemm9h_below", 200) || pv_tune("gemm9h", 1) == 2)) {
+      const int r = pv_gemm9h_try(d, pw, s);
+      if (r != PV_ERR_UNSUPPORTED) return r;
+    }
+  }
   long M, K, tiles_m;
   int tiles_n;
   if (!gemm9_geometry_ok(d, M, K, tiles_m, tiles_n)) return PV_ERR_UNSUPPORTED;

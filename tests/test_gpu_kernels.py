@@ -913,8 +913,8 @@ def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, k
         call("pv_conv3d", d)                       # a second launch gives the same bits
     finally:
         L.tune(**{knob: 1})
-    if knob == "gemm9":      # (the 256-wide ring kernel declines short reductions: its cases need not all reach it)
-        assert routed == "gemm_quad_kernel", routed
+    if knob in ("gemm9", "gemm9h"):      # (the 256-wide ring kernel declines short reductions: its cases need not all reach it)
+        assert routed == {"gemm9": "gemm_quad_kernel", "gemm9h": "gemm_quad_half_kernel"}[knob], routed
     assert torch.equal(got1, y)
     assert rel_err(y[..., :cout].permute(0, 4, 1, 2, 3), want) <= 1e-2
     if cp > cout:
@@ -999,6 +999,28 @@ def test_temporal_conv_tap_rotation_and_uniform_tap_staging(B, T, H, W, cin, cou
 ])
 def test_quad_phase_gemm_kernel(B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine):
     _gemm8_case(2, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm9")
+
+
+# ------------------------------------------------------------------ the same loop on 128 x 256 tiles, three LDS buffers (pv_gemm9h.hip)
+@pytest.mark.parametrize("B,T,H,W,cin,cout,k,stride,act,res,y_f32,affine", [
+    (1, 1, 1, 1000, 384, 200, (1, 1, 1), (1, 1, 1), L.ACT_RELU, True, False, True),     # ragged M and N tails, 2 K-tile triples
+    (1, 1, 1, 100, 576, 72, (1, 1, 1), (1, 1, 1), L.ACT_NONE, False, False, False),     # less than one tile in M and N
+    (8, 1, 1, 785, 768, 768, (1, 1, 1), (1, 1, 1), L.ACT_NONE, True, True, False),      # MViT proj: fp32 stream in / out
+    (2, 1, 1, 3137, 384, 1536, (1, 1, 1), (1, 1, 1), L.ACT_GELU, False, False, False),  # MViT fc1
+    (1, 1, 1, 70000, 384, 520, (1, 1, 1), (1, 1, 1), L.ACT_NONE, True, False, True),    # 1641 tiles: several per workgroup (the
+                                                                                         # DMA stream crosses tiles behind stores)
+    (1, 1, 1, 40000, 384, 300, (1, 1, 1), (1, 1, 1), L.ACT_RELU, True, True, True),     # the same with fp32 stores (16 per tile)
+    (2, 8, 10, 10, 128, 96, (3, 1, 1), (1, 1, 1), L.ACT_RELU, False, False, True),      # SlowFast conv_a (3,1,1): temporal padding
+    (16, 8, 16, 16, 256, 256, (3, 1, 1), (1, 1, 1), L.ACT_RELU, False, False, True),    # ... at res4's grid, 256 tiles
+    (2, 4, 17, 13, 64, 136, (1, 3, 3), (1, 2, 2), L.ACT_RELU, True, False, True),       # conv_b (1,3,3), stride 2, odd grid
+    (3, 4, 16, 16, 128, 256, (1, 3, 3), (1, 1, 1), L.ACT_RELU, False, False, True),     # conv_b (1,3,3): spatial padding
+    (16, 8, 8, 8, 512, 512, (1, 3, 3), (1, 1, 1), L.ACT_RELU, False, False, True),      # res5 conv_b: 72 K tiles, 128 tiles
+    (2, 3, 9, 11, 64, 264, (3, 3, 3), (1, 1, 1), L.ACT_NONE, False, False, False),      # all three axes padded, 27 taps
+    (1, 32, 6, 6, 192, 256, (7, 1, 1), (4, 1, 1), L.ACT_RELU, False, False, True),      # lateral-shaped (7,1,1) / stride 4
+    (2, 4, 16, 16, 384, 512, (1, 1, 1), (1, 2, 2), L.ACT_NONE, False, False, True),     # projection shortcut: strided 1x1x1
+])
+def test_quad_phase_gemm_kernel_on_half_height_tiles(B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine):
+    _gemm8_case(2, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm9h")
 
 
 

@@ -104,3 +104,29 @@ def test_eight_phase_gemm_main_loop_carries_the_counted_waits_and_no_scratch(gem
         header.append(l)
     assert not any("scratch_" in l for l in header)
     assert sum("scratch_" in l for l in body) <= 24
+
+
+@pytest.fixture(scope="module")
+def gemm9h_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not present")
+    out = str(tmp_path_factory.mktemp("isa9h") / "pv_gemm9h.s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "pytorchvideo_amd", "csrc"), "-S", "--cuda-device-only", "-o", out,
+                           os.path.join(ROOT, "pytorchvideo_amd", "csrc", "pv_gemm9h.hip")], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+@pytest.mark.parametrize("frag", ["gemm_quad_half_kernelILb1ELb0EE", "gemm_quad_half_kernelILb0ELb0EE",
+                                  "gemm_quad_half_kernelILb1ELb1EE"])
+def test_half_height_gemm_main_loop_carries_the_counted_waits_and_no_scratch(gemm9h_asm, frag):
+    """csrc/pv_gemm9h.hip: three K tiles per loop trip, two phases each: vmcnt(6) in phase 0, vmcnt(5) in phase 1, 16 MFMAs
+    and 6 LDS-DMAs per K tile, and no scratch anywhere in the kernel (64 accumulator registers leave room)."""
+    body = _inner_loop(gemm9h_asm, frag)
+    text = "\n".join(body)
+    assert len(re.findall(r"s_waitcnt vmcnt\(6\) lgkmcnt\(0\)", text)) >= 2
+    assert len(re.findall(r"s_waitcnt vmcnt\(5\) lgkmcnt\(0\)", text)) >= 2
+    assert len(re.findall(r"v_mfma_f32_32x32x16_bf16", text)) >= 48 - 16
+    assert len(re.findall(r"global_load_lds_dwordx4", text)) >= 18 - 6
+    m = re.search(r"^(_ZN\S*%s\S*):[^\n]*\n(.*?)^\s*\.size\s" % re.escape(frag), gemm9h_asm, re.S | re.M)
+    assert "scratch_" not in m.group(2)

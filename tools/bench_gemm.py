@@ -42,6 +42,13 @@ SHAPES = [  # (label, B, T,H,W in, cin, cout, k(t,h,w), s(t,h,w), p)
     ("sf conv_a res4 first 3x1x1 640->256", 16, 8, 32, 32, 640, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
     ("mvit proj b4  M25k  K384 N384", 8, 1, 1, 3137, 384, 384, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("mvit qkv b14  M25k  K768 N2304", 8, 1, 1, 3137, 768, 2304, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("hb mvit qkv b4   M12k K384 N1152", 4, 1, 1, 3137, 384, 1152, (1, 1, 1), (1, 1, 1), (0, 0, 0)),   # hb: one of the two sub-batch branches
+    ("hb mvit proj b4  M12k K384 N384", 4, 1, 1, 3137, 384, 384, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("hb mvit qkv b14  M12k K768 N2304", 4, 1, 1, 3137, 768, 2304, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("hb mvit qkv b15  M3k  K768 N2304", 4, 1, 1, 785, 768, 2304, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("hb mvit proj b15 M3k  K768 N768", 4, 1, 1, 785, 768, 768, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("hb mvit fc1 b15  M3k  K768 N3072", 4, 1, 1, 785, 768, 3072, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("hb mvit fc2 b15  M3k  K3072 N768", 4, 1, 1, 785, 3072, 768, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("sf stem slow 1x7x7 3->64", 16, 8, 256, 256, 8, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
     ("sf stem fast 5x7x7 3->8", 16, 32, 256, 256, 8, 8, (5, 7, 7), (1, 2, 2), (2, 3, 3)),
     ("x3d stem 1x3x3 3->24", 32, 16, 224, 224, 8, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
