@@ -591,9 +591,13 @@ int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   if (mode == 0) return PV_ERR_UNSUPPORTED;
   {
     // layers whose 256 x 256 tiles do not spread over the chip (SlowFast res4 / res5: 128 / 64 of them) go to the half-height
-    // form first; it declines what it cannot run (K % 192, tile count, padding)
-    const long t256 = pv_ceil_div((long)d.B * d.To * d.Ho * d.Wo, BT9) * pv_ceil_div((long)pv_round_up(d.cout, 8), BT9);
-    if (mode != 2 && (t256 < pv_tune("gemm9h_below", 200) || pv_tune("gemm9h", 1) == 2)) {
+    // form first; it declines what it cannot run (K % 192, tile count, padding).  Not where this kernel has one round of >= 120
+    // tiles and the half-height tiles would need a second, mostly empty one (MViT-B fc1 of the 768-wide blocks: 156 tiles here,
+    // 300 there: measured 27 vs 28 us)
+    const long Mv = (long)d.B * d.To * d.Ho * d.Wo, tn = pv_ceil_div((long)pv_round_up(d.cout, 8), BT9);
+    const long t256 = pv_ceil_div(Mv, BT9) * tn, th = pv_ceil_div(Mv, BT9 / 2) * tn;
+    const bool one_round_here = t256 >= pv_tune("gemm9_min_tiles", 120) && th > 256;
+    if (mode != 2 && ((t256 < pv_tune("gemm9h_below", 200) && !one_round_here) || pv_tune("gemm9h", 1) == 2)) {
       const int r = pv_gemm9h_try(d, pw, s);
       if (r != PV_ERR_UNSUPPORTED) return r;
     }

@@ -261,6 +261,9 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
     _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                         \
       _Pragma("unroll") for (int v = 0; v < 2; ++v) bf[s][v] = PVH_RD(bb, s, v * 4096);                                   \
   } while (0)
+  // (order of a K tile's six DMAs: A0 A0 B | B A1 A1.  The voxel rows first -- B B A0 | A0 A1 A1 -- and 4 + 2 -- B B A0 A0 |
+  // A1 A1 -- measured the same to 0.3 % on every SlowFast shape, profiles/r5/bench_gemm_half_dma_order_call11.txt: the loop is
+  // not waiting for data, it pays for issuing the DMAs and for the LDS port.)
   // One K tile on LDS buffer Q (compile-time); the stream writes buffer (Q + 2) % 3.  A phase's fragments were guaranteed by the
   // PREVIOUS phase's wait + barrier; its own wait (before its DMAs are issued) covers what the next phase reads: phase 0 waits
   // for A1 of this K tile (younger: the next K tile's six DMAs), phase 1 for A0 and B of the next K tile (younger: its A1 and

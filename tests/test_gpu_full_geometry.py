@@ -44,7 +44,7 @@ BF16_TOL = 1e-2                                      # the north star's bar, no 
 BLOCK_BF16_TOL = {"x3d_m": 8.5e-3, "x3d_l": 6.8e-3, "slowfast_r50": 8.0e-3, "mvit_b_32x3": 5.3e-3}
 # the same gate on the STRESS instance (block-final gamma ~ 1: the branch is as large as the trunk, so a defect in the branch's
 # kernels is not diluted by the identity path): measured clean in round 5 (profiles/r5/parity_full.jsonl) x 1.3
-BLOCK_BF16_TOL_STRESS = {"x3d_m": 1.2e-2, "slowfast_r50": 1.2e-2}
+BLOCK_BF16_TOL_STRESS = {"x3d_m": 9.0e-3, "slowfast_r50": 1.1e-2}      # measured 6.8e-3 / 8.4e-3
 # bench batch, per ROW against the bf16-storage oracle: round 4's measured worst row (4.1e-3 / 6.6e-3 / 1.2e-3 / 3.7e-3) x 1.3
 ROW_KERNEL_BF16 = {"x3d_m": 5.3e-3, "x3d_l": 8.6e-3, "slowfast_r50": 1.6e-3, "mvit_b_32x3": 4.9e-3}
 # stress instance: the larger of (measured on the MI355X in round 3, profiles/r3/parity_full.jsonl, x 1.3) and (1.35 x the

@@ -94,7 +94,7 @@ def run(label, B, T, H, W, cin, cout, k, s, p, iters=20):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * B * To * Ho * Wo * cout * taps * cin
     byts = 2.0 * (x.numel() + w.numel() + y.numel())
-    print("%-48s %8.3f ms %8.1f TF/s %8.1f GB/s" % (label, ms, flops / ms / 1e9, byts / ms / 1e6), flush=True)
+    print("%-48s %8.4f ms %8.1f TF/s %8.1f GB/s" % (label, ms, flops / ms / 1e9, byts / ms / 1e6), flush=True)
 
 
 if __name__ == "__main__":
