@@ -597,7 +597,9 @@ int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
     const long Mv = (long)d.B * d.To * d.Ho * d.Wo, tn = pv_ceil_div((long)pv_round_up(d.cout, 8), BT9);
     const long t256 = pv_ceil_div(Mv, BT9) * tn, th = pv_ceil_div(Mv, BT9 / 2) * tn;
     const bool one_round_here = t256 >= pv_tune("gemm9_min_tiles", 120) && th > 256;
-    if (mode != 2 && ((t256 < pv_tune("gemm9h_below", 200) && !one_round_here) || pv_tune("gemm9h", 1) == 2)) {
+    const long c8 = pv_round_up(d.cout, 8);
+    const bool padded_here = (double)(tn * BT9 - c8) > 0.15 * (double)c8;   // 128-channel layers: the transposed half tile
+    if (mode != 2 && ((t256 < pv_tune("gemm9h_below", 200) && !one_round_here) || padded_here || pv_tune("gemm9h", 1) == 2)) {
       const int r = pv_gemm9h_try(d, pw, s);
       if (r != PV_ERR_UNSUPPORTED) return r;
     }

@@ -40,7 +40,7 @@ typedef int i32x4h __attribute__((ext_vector_type(4)));
 // LDS row -> channel inside a 32-row MFMA tile (accumulator register r of lane-half hi is channel 16*hi + r)
 __device__ __forceinline__ int chih(int rho) { return 16 * ((rho >> 2) & 1) + 4 * ((rho >> 3) & 3) + (rho & 3); }
 
-template <bool PW, bool YF32>
+template <bool PW, bool YF32, bool TR>
 __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smemh_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smemh_raw);
@@ -59,12 +59,15 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
   const char* __restrict__ Wb = static_cast<const char*>(d.w);
   const unsigned long zaddr = (unsigned long)reinterpret_cast<const bf16_t*>(pv_zero_pageh);
 
+  // TR: the transposed tile, 256 voxels x 128 channels -- the SPLIT operand (two 128-row units, one per phase) is the voxels,
+  // the WHOLE one (a single unit, read in phase 0 and kept) the weights; everything else is the same loop
+  constexpr int BM = TR ? 2 * BMH : BMH, BN = TR ? BNH / 2 : BNH;
   auto tile_origin = [&](int it, long& m0, int& n0) __attribute__((always_inline)) {   // XCD-aware tile order (bijective for any tile count)
     const int xcd = it & 7, slot = it >> 3;
     const int qn = total_tiles >> 3, rn = total_tiles & 7;
     const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
-    m0 = (long)(tile / tiles_n) * BMH;
-    n0 = (tile % tiles_n) * BNH;
+    m0 = (long)(tile / tiles_n) * BM;
+    n0 = (tile % tiles_n) * BN;
   };
   // DMA j of a unit covers unit rows 64 j + rho0, rho0 = 8 wave + lane / 8; K chunk (8 elements) that lands on LDS position
   // lane % 8 of those rows (the swizzle key (row >> 1) & 7 is the same for rows 64 apart)
@@ -73,21 +76,29 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
   const unsigned a_pitch = (unsigned)K * 2u, a_last = (unsigned)(d.cout - 1) * a_pitch;
   const unsigned b_pitch = (unsigned)d.ldx * 2u, b_last = (unsigned)(M - 1) * b_pitch;
   int iss_c0 = 0, iss_dt = 0, iss_dh = 0, iss_dw = 0;   // channel offset inside the tap, tap coordinates (wave-uniform)
-  unsigned g_a_row = 0, g_b_row = 0;   // byte offsets of this thread's staging rows (a = 0, j = 0) of the stream's output tile
-  // A unit a, row r = 32 wn + i  <->  channel n0 + 64 wn + 32 a + chi(i);  B unit row r  <->  voxel m0 + r
+  unsigned g_a_row = 0, g_b_row = 0;   // byte offsets of this thread's staging rows (half 0, j = 0) of the stream's output tile
+  unsigned gm0 = 0, gm1 = 0, gm2 = 0, gm3 = 0;   // (TR, implicit GEMM) window masks of the four voxel rows [v][j]
+  // Row maps (g4 = wave & 3, g2 = wave >> 2; DMA j of a unit covers its rows 64 j + rho0):
+  //   split unit h, row 32 g4 + i;  whole unit, row 64 g2 + 32 h + i;
+  //   !TR: channel n0 + 64 g4 + 32 h + chi(i) (split)   voxel m0 + 64 g2 + 32 h + i (whole)
+  //    TR: voxel m0 + 64 g4 + 32 h + i (split)          channel n0 + 64 g2 + 32 h + chi(i) (whole)
   auto geom_of = [&](int it) __attribute__((always_inline)) {
     long m0;
     int n0;
     tile_origin(it, m0, n0);
     iss_c0 = iss_dt = iss_dh = iss_dw = 0;
-    g_a_row = (unsigned)(n0 + 64 * (rho0 >> 5) + chih(rho0 & 31)) * a_pitch;   // (a, j): 32 a + 128 j rows further, clamped at use
+    if constexpr (!TR) g_a_row = (unsigned)(n0 + 64 * (rho0 >> 5) + chih(rho0 & 31)) * a_pitch;   // (h, j): 32 h + 128 j rows further, clamped at use
+    else g_a_row = (unsigned)(n0 + 32 * (rho0 >> 5) + chih(rho0 & 31)) * a_pitch;                 // j: 64 rows further
     if constexpr (PW) {
-      g_b_row = (unsigned)((int)m0 + rho0) * b_pitch;                           // j: 64 rows further, clamped at use
+      if constexpr (!TR) g_b_row = (unsigned)((int)m0 + rho0) * b_pitch;                          // j: 64 rows further, clamped at use
+      else g_b_row = (unsigned)((int)m0 + 64 * (rho0 >> 5) + (rho0 & 31)) * b_pitch;              // (h, j): 32 h + 128 j rows further
     } else {
       int* geo = reinterpret_cast<int*>(smemh_raw + kGeoH) + tid * 4;
+      unsigned msk4[4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        long m = m0 + 64 * j + rho0;
+      for (int q4 = 0; q4 < (TR ? 4 : 2); ++q4) {
+        const int j = q4 & 1, h = q4 >> 1;
+        long m = TR ? m0 + 128 * j + 64 * (rho0 >> 5) + 32 * h + (rho0 & 31) : m0 + 64 * j + rho0;
         m = m < M ? m : M - 1;                              // M tail: a clamped row, never stored
         const unsigned b = (unsigned)m / (unsigned)S_out;
         const unsigned sp = (unsigned)m - b * (unsigned)S_out;
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
         const unsigned r2 = sp - to * (unsigned)(d.Ho * d.Wo);
         const unsigned ho = r2 / (unsigned)d.Wo;
         const int t0 = (int)to * d.st - d.pt, h0 = (int)ho * d.sh - d.ph, w0 = (int)(r2 - ho * (unsigned)d.Wo) * d.sw - d.pw;
-        geo[j] = (int)((long)b * d.x_bs + ((long)(t0 * d.Hi + h0) * d.Wi + w0) * d.ldx) + chunk8;
+        geo[q4] = (int)((long)b * d.x_bs + ((long)(t0 * d.Hi + h0) * d.Wi + w0) * d.ldx) + chunk8;
         unsigned msk = 0u;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -103,7 +114,12 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
           if (q < d.kh && (unsigned)(h0 + q * dil_h) < (unsigned)d.Hi) msk |= 1u << (8 + q);
           if (q < d.kw && (unsigned)(w0 + q * dil_w) < (unsigned)d.Wi) msk |= 1u << (16 + q);
         }
-        geo[2 + j] = (int)msk;
+        msk4[q4] = msk;
+      }
+      if constexpr (TR) {       // 16 bytes of LDS per thread hold the four offsets; the masks stay in registers
+        gm0 = msk4[0]; gm1 = msk4[1]; gm2 = msk4[2]; gm3 = msk4[3];
+      } else {                  // [off j0, off j1, mask j0, mask j1]
+        geo[2] = (int)msk4[0]; geo[3] = (int)msk4[1];
       }
     }
   };
@@ -118,26 +134,35 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
     const unsigned long m = 0ul - (unsigned long)ok;
     return reinterpret_cast<const bf16_t*>((p & m) | (zaddr & ~m));
   };
-  auto issue_a = [&](int a, int buf, int j) __attribute__((always_inline)) {   // DMA j of channel unit a of the stream's K tile
-    unsigned off = g_a_row + (unsigned)(32 * a + 128 * j) * a_pitch;
+  auto dma_w = [&](int rows, int unit, int j) __attribute__((always_inline)) {   // one weight row per lane: g_a_row + rows
+    unsigned off = g_a_row + (unsigned)rows * a_pitch;
     off = (off < a_last ? off : a_last) + (unsigned)(iss_ku * 128 + chunk8 * 2);   // N tail: a clamped row, zeroed in the epilogue
     __builtin_amdgcn_global_load_lds((gptrh_t)pick(iss_live, (unsigned long)(Wb + off)),
-                                     (lptrh_t)(smem + (3 * buf + a) * UNITH + (j * 8 + wave) * 512), 16, 0, 0);
+                                     (lptrh_t)(smem + unit * UNITH + (j * 8 + wave) * 512), 16, 0, 0);
   };
-  auto issue_b = [&](int buf, int j, const i32x4h& gq) __attribute__((always_inline)) {   // DMA j of the voxel unit
+  auto dma_x = [&](int rows, int goff, unsigned gmask, int unit, int j) __attribute__((always_inline)) {   // one voxel row per lane
     if constexpr (PW) {
-      unsigned off = g_b_row + (unsigned)(64 * j) * b_pitch;
+      unsigned off = g_b_row + (unsigned)rows * b_pitch;
       off = (off < b_last ? off : b_last) + (unsigned)(iss_ku * 128 + chunk8 * 2);   // M tail: a clamped row, never stored
       __builtin_amdgcn_global_load_lds((gptrh_t)pick(iss_live, (unsigned long)(reinterpret_cast<const char*>(X) + off)),
-                                       (lptrh_t)(smem + (3 * buf + 2) * UNITH + (j * 8 + wave) * 512), 16, 0, 0);
+                                       (lptrh_t)(smem + unit * UNITH + (j * 8 + wave) * 512), 16, 0, 0);
     } else {
       // element offset of the K tile's tap + channel block and the mask bits that must be set for this tap (wave-uniform)
       const int uni = ((iss_dt * dil_t * d.Hi + iss_dh * dil_h) * d.Wi + iss_dw * dil_w) * d.ldx + iss_c0;
       const unsigned sel = (1u << iss_dt) | (1u << (8 + iss_dh)) | (1u << (16 + iss_dw));
-      const bool ok = iss_live && ((unsigned)gq[2 + j] & sel) == sel;
-      __builtin_amdgcn_global_load_lds((gptrh_t)pick(ok, (unsigned long)(X + (long)(gq[j] + uni))),
-                                       (lptrh_t)(smem + (3 * buf + 2) * UNITH + (j * 8 + wave) * 512), 16, 0, 0);
+      const bool ok = iss_live && (gmask & sel) == sel;
+      __builtin_amdgcn_global_load_lds((gptrh_t)pick(ok, (unsigned long)(X + (long)(goff + uni))),
+                                       (lptrh_t)(smem + unit * UNITH + (j * 8 + wave) * 512), 16, 0, 0);
     }
+  };
+  // DMA j of split unit h / of the whole unit of the stream's K tile -> LDS buffer buf (gq: this thread's geometry words)
+  auto issue_s = [&](int h, int buf, int j, const i32x4h& gq) __attribute__((always_inline)) {
+    if constexpr (!TR) dma_w(32 * h + 128 * j, 3 * buf + h, j);
+    else dma_x(32 * h + 128 * j, gq[2 * h + j], h == 0 ? (j == 0 ? gm0 : gm1) : (j == 0 ? gm2 : gm3), 3 * buf + h, j);
+  };
+  auto issue_w = [&](int buf, int j, const i32x4h& gq) __attribute__((always_inline)) {
+    if constexpr (!TR) dma_x(64 * j, gq[j], (unsigned)gq[2 + j], 3 * buf + 2, j);
+    else dma_w(64 * j, 3 * buf + 2, j);
   };
   auto load_geo = [&]() __attribute__((always_inline)) -> i32x4h {
     if constexpr (PW) {
@@ -184,13 +209,14 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
   };
 
   // ---- read side: this lane's fragment position inside a unit, as a BYTE offset from the LDS base ----
-  // A rows: 32 wn + (lane & 31) of unit a; B rows: 64 wm + 32 v + (lane & 31) (v = 1: + 4096 bytes, same swizzle key).
+  // split unit h: row 32 g4 + (lane & 31); whole unit: row 64 g2 + 32 h + (lane & 31) (h = 1: + 4096 bytes, same swizzle key).
   // K slice s reads chunk (2 s + hi) ^ key(row) = (hi ^ key(row)) ^ 2 s: the position of slice 0 in a register, slices 1-3 are
   // that register ^ (s * 32)
-  const int wn = wave & 3, wm = wave >> 2;
-  unsigned rd_a0, rd_b0;
+  const int g4 = wave & 3, g2 = wave >> 2;
+  const int wn = TR ? g2 : g4, wm = TR ? g4 : g2;   // the wave's 64 channels / 64 voxels inside the tile
+  unsigned rd_a0, rd_b0;                            // split / whole operand
   {
-    const int ra = wn * 32 + (lane & 31), rb = wm * 64 + (lane & 31);
+    const int ra = g4 * 32 + (lane & 31), rb = g2 * 64 + (lane & 31);
     const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) unsigned char*)smemh_raw);
     rd_a0 = lds0 + (unsigned)(ra * 128 + (((lane >> 5) ^ ((ra >> 1) & 7)) << 4));
     rd_b0 = lds0 + (unsigned)(2 * UNITH * 2 + rb * 128 + (((lane >> 5) ^ ((rb >> 1) & 7)) << 4));
@@ -210,9 +236,9 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
   issue_tables();
   {
     const i32x4h gq = load_geo();
-    issue_a(0, 0, 0); issue_a(0, 0, 1); issue_b(0, 0, gq); issue_b(0, 1, gq); issue_a(1, 0, 0); issue_a(1, 0, 1);
+    issue_s(0, 0, 0, gq); issue_s(0, 0, 1, gq); issue_w(0, 0, gq); issue_w(0, 1, gq); issue_s(1, 0, 0, gq); issue_s(1, 0, 1, gq);
     advance();
-    issue_a(0, 1, 0); issue_a(0, 1, 1); issue_b(1, 0, gq); issue_b(1, 1, gq); issue_a(1, 1, 0); issue_a(1, 1, 1);
+    issue_s(0, 1, 0, gq); issue_s(0, 1, 1, gq); issue_w(1, 0, gq); issue_w(1, 1, gq); issue_s(1, 1, 0, gq); issue_s(1, 1, 1, gq);
   }
   __builtin_amdgcn_s_waitcnt(vml(8));   // A0, B of K tile 0: this thread's share
   __builtin_amdgcn_s_barrier();
@@ -232,7 +258,12 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
     __builtin_amdgcn_s_barrier();                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                              \
   } while (0)
-#define PVH_M1(A, S, V) acc[A][V] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[S], bf[S][V], acc[A][V], 0, 0, 0)
+  // phase P multiplies split unit P (fragments af) with both halves H of the whole unit (bf): weights are always the A operand
+#define PVH_M1(P, S, H)                                                                             \
+  do {                                                                                              \
+    if constexpr (!TR) acc[P][H] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[S], bf[S][H], acc[P][H], 0, 0, 0);   \
+    else acc[H][P] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[S][H], af[S], acc[H][P], 0, 0, 0);                 \
+  } while (0)
 #define PVH_SLOT(X)                                                                                 \
   do { __builtin_amdgcn_sched_barrier(0); X; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PVH_PHASE(FIRST, N, A, D0, D1, D2)                                                          \
@@ -278,9 +309,9 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
     PVH_READ_B(Q);                                                                                                        \
     PVH_READ_A(Q, 0);                                                                                                     \
-    PVH_PHASE(F0, 6, 0, issue_a(0, QW, 0), issue_a(0, QW, 1), issue_b(QW, 0, gq));                                     \
+    PVH_PHASE(F0, 6, 0, issue_s(0, QW, 0, gq), issue_s(0, QW, 1, gq), issue_w(QW, 0, gq));                                     \
     PVH_READ_A(Q, 1);                                                                                                     \
-    PVH_PHASE(F1, 5, 1, issue_b(QW, 1, gq), issue_a(1, QW, 0), issue_a(1, QW, 1));                                     \
+    PVH_PHASE(F1, 5, 1, issue_w(QW, 1, gq), issue_s(1, QW, 0, gq), issue_s(1, QW, 1, gq));                                     \
   } while (0)
 
   const int nk3 = nk / 3;   // K tiles come in triples (K % 192 == 0, host check): every output tile starts on LDS buffer 0
@@ -455,10 +486,10 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
   __builtin_amdgcn_s_waitcnt(vml(0));          // the stream's trailing (zero-page) DMAs land before the LDS is released
 }
 
-template <bool PW, bool YF32>
+template <bool PW, bool YF32, bool TR>
 int launch9h(const pv_conv3d_desc& d, int tiles_n, long total, hipStream_t s) {
   const size_t lds = (size_t)kLdsHBytes;
-  auto kern = gemm_quad_half_kernel<PW, YF32>;
+  auto kern = gemm_quad_half_kernel<PW, YF32, TR>;
   PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long resident = 256;   // one workgroup per CU
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreadsH);
@@ -486,16 +517,29 @@ int pv_gemm9h_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
       (M + 256) * d.ldx * 2 > 0xffffffffL)
     return PV_ERR_UNSUPPORTED;
   if ((long)d.B * d.y_bs * (d.y_f32 ? 4 : 2) > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
-  const long tiles_m = pv_ceil_div(M, BMH);
-  const int tiles_n = (int)pv_ceil_div(cout_p8, BNH);
+  // tile shape: 128 voxels x 256 channels where 256-channel tiles fit the layer, else the transposed 256 x 128 tile (SlowFast
+  // res3's 1x3x3 convs: 128 channels) -- pv_tune "gemm9h_tr": -1 by the padding each shape costs, 0 / 1 forced
+  const double waste256 = (double)(pv_ceil_div(cout_p8, BNH) * BNH - cout_p8) / (double)cout_p8;
+  const double waste128 = (double)(pv_ceil_div(cout_p8, BNH / 2) * (BNH / 2) - cout_p8) / (double)cout_p8;
+  int tr = pv_tune("gemm9h_tr", -1);
+  if (tr < 0) tr = waste256 > 0.15 && waste128 <= 0.15;
+  const long tiles_m = pv_ceil_div(M, tr ? 2 * BMH : BMH);
+  const int tiles_n = (int)pv_ceil_div(cout_p8, tr ? BNH / 2 : BNH);
   const long total = tiles_m * tiles_n;
   if (total <= 0 || total >= 0x3fffffffL) return PV_ERR_UNSUPPORTED;
   if (mode == 1) {
-    const double waste = (double)((long)tiles_n * BNH - cout_p8) / (double)cout_p8;
-    // (the 256 x 256 kernel is the better one wherever ITS tiles fill the chip: pv_gemm9_try asks this kernel only below that)
-    if (total < pv_tune("gemm9h_min_tiles", 96) || waste > 0.15) return PV_ERR_UNSUPPORTED;
+    // (the 256 x 256 kernel is the better one wherever ITS tiles fill the chip: pv_gemm9_try asks this kernel only below that
+    // or where 256-channel tiles would be mostly padding)
+    if ((tr ? waste128 : waste256) > 0.15) return PV_ERR_UNSUPPORTED;
+    if (total < (tr ? pv_tune("gemm9h_tr_min_tiles", 200) : pv_tune("gemm9h_min_tiles", 96))) return PV_ERR_UNSUPPORTED;
   }
   const bool rows = pw && d.x_bs == (long)d.To * d.Ho * d.Wo * d.ldx;
-  if (d.y_f32) return rows ? launch9h<true, true>(d, tiles_n, total, s) : launch9h<false, true>(d, tiles_n, total, s);
-  return rows ? launch9h<true, false>(d, tiles_n, total, s) : launch9h<false, false>(d, tiles_n, total, s);
+#define PVH_GO(PWv, YFv)                                                \
+  return tr ? launch9h<PWv, YFv, true>(d, tiles_n, total, s) : launch9h<PWv, YFv, false>(d, tiles_n, total, s);
+  if (d.y_f32) {
+    if (rows) { PVH_GO(true, true) } else { PVH_GO(false, true) }
+  } else {
+    if (rows) { PVH_GO(true, false) } else { PVH_GO(false, false) }
+  }
+#undef PVH_GO
 }

@@ -1023,6 +1023,28 @@ def test_quad_phase_gemm_kernel_on_half_height_tiles(B, T, H, W, cin, cout, k, s
     _gemm8_case(2, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm9h")
 
 
+@pytest.mark.parametrize("B,T,H,W,cin,cout,k,stride,act,res,y_f32,affine", [
+    (1, 1, 1, 1000, 384, 100, (1, 1, 1), (1, 1, 1), L.ACT_RELU, True, False, True),     # ragged M and N tails
+    (1, 1, 1, 100, 576, 72, (1, 1, 1), (1, 1, 1), L.ACT_NONE, False, False, False),     # less than one tile in M and N
+    (8, 1, 1, 785, 768, 384, (1, 1, 1), (1, 1, 1), L.ACT_NONE, True, True, False),      # fp32 stream in / out, three channel tiles
+    (1, 1, 1, 70000, 384, 260, (1, 1, 1), (1, 1, 1), L.ACT_NONE, True, False, True),    # 822 tiles: several per workgroup
+    (1, 1, 1, 40000, 384, 128, (1, 1, 1), (1, 1, 1), L.ACT_RELU, True, True, True),     # the same with fp32 stores
+    (2, 8, 10, 10, 128, 96, (3, 1, 1), (1, 1, 1), L.ACT_RELU, False, False, True),      # (3,1,1): temporal padding
+    (16, 8, 32, 32, 128, 128, (1, 3, 3), (1, 1, 1), L.ACT_RELU, False, False, True),    # SlowFast res3 conv_b at full size: 512 tiles
+    (2, 4, 17, 13, 64, 136, (1, 3, 3), (1, 2, 2), L.ACT_RELU, True, False, True),       # stride 2, odd grid, two channel tiles
+    (2, 3, 9, 11, 64, 120, (3, 3, 3), (1, 1, 1), L.ACT_NONE, False, False, False),      # all three axes padded, 27 taps
+    (1, 32, 6, 6, 192, 128, (7, 1, 1), (4, 1, 1), L.ACT_RELU, False, False, True),      # lateral-shaped (7,1,1) / stride 4
+    (2, 4, 16, 16, 384, 256, (1, 1, 1), (1, 2, 2), L.ACT_NONE, False, False, True),     # projection shortcut: strided 1x1x1
+])
+def test_quad_phase_gemm_kernel_on_transposed_half_tiles(B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine):
+    """pv_gemm9h.hip with the 256 (voxels) x 128 (channels) tile: the voxel rows are the split operand."""
+    L.tune(gemm9h_tr=1)
+    try:
+        _gemm8_case(2, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, knob="gemm9h")
+    finally:
+        L.tune(gemm9h_tr=-1)
+
+
 
 
 @pytest.mark.parametrize("B,T,H,W,cin,cout,k,stride", [

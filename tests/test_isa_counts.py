@@ -117,8 +117,9 @@ def gemm9h_asm(tmp_path_factory):
     return open(out).read()
 
 
-@pytest.mark.parametrize("frag", ["gemm_quad_half_kernelILb1ELb0EE", "gemm_quad_half_kernelILb0ELb0EE",
-                                  "gemm_quad_half_kernelILb1ELb1EE"])
+@pytest.mark.parametrize("frag", ["gemm_quad_half_kernelILb1ELb0ELb0EE", "gemm_quad_half_kernelILb0ELb0ELb0EE",
+                                  "gemm_quad_half_kernelILb1ELb1ELb0EE", "gemm_quad_half_kernelILb1ELb0ELb1EE",
+                                  "gemm_quad_half_kernelILb0ELb0ELb1EE"])
 def test_half_height_gemm_main_loop_carries_the_counted_waits_and_no_scratch(gemm9h_asm, frag):
     """csrc/pv_gemm9h.hip: three K tiles per loop trip, two phases each: vmcnt(6) in phase 0, vmcnt(5) in phase 1, 16 MFMAs
     and 6 LDS-DMAs per K tile, and no scratch anywhere in the kernel (64 accumulator registers leave room)."""

@@ -49,6 +49,12 @@ SHAPES = [  # (label, B, T,H,W in, cin, cout, k(t,h,w), s(t,h,w), p)
     ("hb mvit proj b15 M3k  K768 N768", 4, 1, 1, 785, 768, 768, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("hb mvit fc1 b15  M3k  K768 N3072", 4, 1, 1, 785, 768, 3072, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("hb mvit fc2 b15  M3k  K3072 N768", 4, 1, 1, 785, 3072, 768, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("real sf shortcut res3 320->512 s122 in64", 16, 8, 64, 64, 320, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0)),   # real: the model's grids
+    ("real sf conv_a res3 first 320->128 in64", 16, 8, 64, 64, 320, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("real sf shortcut res4 640->1024 s122 in32", 16, 8, 32, 32, 640, 1024, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ("real sf shortcut res5 1280->2048 s122 in16", 16, 8, 16, 16, 1280, 2048, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ("real sf conv_b res3 first 1x3x3 128->128 s122", 16, 8, 64, 64, 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("real sf conv_a res2 256->64 in64", 16, 8, 64, 64, 256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("sf stem slow 1x7x7 3->64", 16, 8, 256, 256, 8, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
     ("sf stem fast 5x7x7 3->8", 16, 32, 256, 256, 8, 8, (5, 7, 7), (1, 2, 2), (2, 3, 3)),
     ("x3d stem 1x3x3 3->24", 32, 16, 224, 224, 8, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
