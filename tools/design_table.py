@@ -19,6 +19,7 @@ def main():
           "algorithmic rate → `roofline.frac` | PMC traffic / algorithmic bytes per launch | whole model: SURVEY byte model · plan's own bytes · MFMA | "
           "kernels ≥ 5 % of the step (ms) | CPU baseline (threads: clips/s) |")
     print("|---|---|---|---|---|---|---|---|---|---|")
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     for wl, label in NAMES:
         a = json.load(open(os.path.join(d, wl + "_bench_default.json")))
         b = json.load(open(os.path.join(d, wl + "_bench_streams1.json")))
@@ -29,7 +30,10 @@ def main():
         if r.get("second_roof"):
             s2 = r["second_roof"]
             second = "; %s roof: %.1f of %.1f %s = %.2f" % (s2.get("bound"), s2.get("achieved", 0), s2.get("peak", 0), s2.get("unit", ""), s2.get("frac", 0))
-        tr = r.get("traffic")
+        # PMC traffic of the SAME evidence pass (profiles/traffic.json, per kernel symbol); the JSON line itself was printed before
+        # that pass was adopted and still carries the previous round's figure
+        ent = (tj.get(wl, {}).get("_by_kernel") or {}).get(r["kernel"])
+        tr = ent["hbm_bytes_per_launch"] if ent else r.get("traffic")
         traffic = "%.1f / %.1f MB = %.2f" % (tr / 1e6, r["alg_bytes_per_launch"] / 1e6, tr / r["alg_bytes_per_launch"]) if tr else "—"
         whole = "%.2f · %.2f · %.3f" % (r.get("model_hbm_frac") or 0, r.get("model_hbm_frac_plan") or 0, r.get("model_mfma_frac") or 0)
         ks = ", ".join("`%s` %.2f" % (k, v) for k, v in r["kernels_ms_per_step"].items())
