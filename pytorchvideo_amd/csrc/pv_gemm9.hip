@@ -76,7 +76,7 @@ struct Geom9 {         // per-thread staging rows of one output tile (DMA j of a
 };
 
 template <bool PW, bool YF32, int VAR>
-__global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles) {
+__global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles, int tap_rot) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem9_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem9_raw);
 
@@ -111,11 +111,26 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   const unsigned b_pitch = (unsigned)d.ldx * 2u, b_last = (unsigned)(M - 1) * b_pitch;
   int* geo = reinterpret_cast<int*>(smem9_raw + kGeo9) + tid * 8;   // (!PW) this thread's staging geometry
   int iss_c0 = 0, iss_dt = 0, iss_dh = 0, iss_dw = 0;   // channel offset inside the tap, tap coordinates (wave-uniform)
+  unsigned iss_wk = 0;                                  // byte offset of the stream's K tile inside a weight row
   auto geom_of = [&](int it, Geom9& g) __attribute__((always_inline)) {
     long m0;
     int n0;
     tile_origin(it, m0, n0);
-    iss_c0 = iss_dt = iss_dh = iss_dw = 0;
+    iss_c0 = iss_dh = iss_dw = 0;
+    // temporal-tap rotation (tap_rot: temporal stride 1, whole tiles inside one frame -- host check): the tile of output frame t
+    // starts its reduction at tap (pt - t) mod kt and wraps, so that in step i EVERY concurrent tile reads an input frame with
+    // index = i (mod kt): the kt consumers of a frame fetch it at the same moment instead of kt times through a 4 MB L2
+    // (SlowFast res4 conv_a: 32 tiles per XCD touch 7.3 MB of frames per tap; PMC fetch 2.95 x the input without this)
+    int rot = 0;
+    if constexpr (!PW) {
+      if (tap_rot) {
+        const unsigned sp = (unsigned)m0 % (unsigned)S_out;
+        rot = (d.pt - (int)(sp / (unsigned)(d.Ho * d.Wo))) % d.kt;
+        rot = rot < 0 ? rot + d.kt : rot;
+      }
+    }
+    iss_dt = rot;
+    iss_wk = (unsigned)(rot * d.kh * d.kw * d.cin) * 2u;
     const int rho0 = 8 * wave + (lane >> 3);   // unit row of DMA 0 (< 64)
     g.a_row = (unsigned)(n0 + 32 * (rho0 >> 5) + chi9(rho0 & 31)) * a_pitch;
     if constexpr (PW) {
@@ -159,7 +174,7 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   };
   // jsel: 0 / 1 = that DMA of the unit only, -1 = both
   auto issue_a = [&](int a, int unit, int jsel) __attribute__((always_inline)) {   // channel half a of the stream's K tile -> LDS unit `unit`
-    const unsigned kc = (unsigned)(iss_ku * 128 + chunk8 * 2);
+    const unsigned kc = iss_wk + (unsigned)(chunk8 * 2);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (jsel >= 0 && jsel != j) continue;
@@ -222,18 +237,23 @@ __global__ __launch_bounds__(kThreads9) void gemm_quad_kernel(const pv_conv3d_de
   };
   auto advance = [&]() __attribute__((always_inline)) {   // next K tile of the stream
     ++iss_ku;
+    iss_wk += 128u;
     if constexpr (!PW) {
       iss_c0 += 64;
       if (iss_c0 == d.cin) {
         iss_c0 = 0;
         if (++iss_dw == d.kw) {
           iss_dw = 0;
-          if (++iss_dh == d.kh) { iss_dh = 0; ++iss_dt; }
+          if (++iss_dh == d.kh) {
+            iss_dh = 0;
+            if (++iss_dt == d.kt) { iss_dt = 0; iss_wk = 0u; }   // (a rotated reduction wraps to tap 0 = weight column 0)
+          }
         }
       }
     }
     if (iss_ku == nk) {
       iss_ku = 0;
+      iss_wk = 0u;
       iss_it += gridDim.x;
       ++iss_jt;
       iss_live = iss_it < total_tiles;
@@ -555,7 +575,9 @@ int launch9(const pv_conv3d_desc& d, int tiles_n, long total, hipStream_t s) {
   PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long resident = 256;   // one workgroup per CU
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads9);
-  PV_LAUNCH(kern, grid, block, lds, s, d, tiles_n, (int)total);
+  // tap rotation: only where a whole tile lies inside one output frame and frames map to taps one to one
+  const int tap_rot = !PW && d.kt > 1 && d.st == 1 && d.dil_t <= 1 && (d.Ho * d.Wo) % BT9 == 0 && pv_tune("gemm9_tap_rot", 1);
+  PV_LAUNCH(kern, grid, block, lds, s, d, tiles_n, (int)total, tap_rot);
   pv_note_kernel("gemm_quad_kernel");   // (launched through a function pointer: PV_LAUNCH saw only the variable)
   PV_LAUNCH_CHECK();
   return PV_OK;

@@ -41,7 +41,7 @@ typedef int i32x4h __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int chih(int rho) { return 16 * ((rho >> 2) & 1) + 4 * ((rho >> 3) & 3) + (rho & 3); }
 
 template <bool PW, bool YF32, bool TR>
-__global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles) {
+__global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv3d_desc d, int tiles_n, int total_tiles, int tap_rot) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smemh_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smemh_raw);
 
@@ -76,6 +76,7 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
   const unsigned a_pitch = (unsigned)K * 2u, a_last = (unsigned)(d.cout - 1) * a_pitch;
   const unsigned b_pitch = (unsigned)d.ldx * 2u, b_last = (unsigned)(M - 1) * b_pitch;
   int iss_c0 = 0, iss_dt = 0, iss_dh = 0, iss_dw = 0;   // channel offset inside the tap, tap coordinates (wave-uniform)
+  unsigned iss_wk = 0;                                  // byte offset of the stream's K tile inside a weight row
   unsigned g_a_row = 0, g_b_row = 0;   // byte offsets of this thread's staging rows (half 0, j = 0) of the stream's output tile
   unsigned gm0 = 0, gm1 = 0, gm2 = 0, gm3 = 0;   // (TR, implicit GEMM) window masks of the four voxel rows [v][j]
   // Row maps (g4 = wave & 3, g2 = wave >> 2; DMA j of a unit covers its rows 64 j + rho0):
@@ -86,7 +87,18 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
     long m0;
     int n0;
     tile_origin(it, m0, n0);
-    iss_c0 = iss_dt = iss_dh = iss_dw = 0;
+    iss_c0 = iss_dh = iss_dw = 0;
+    // temporal-tap rotation (see pv_gemm9.hip): the tile of output frame t starts at tap (pt - t) mod kt and wraps
+    int rot = 0;
+    if constexpr (!PW) {
+      if (tap_rot) {
+        const unsigned sp = (unsigned)m0 % (unsigned)S_out;
+        rot = (d.pt - (int)(sp / (unsigned)(d.Ho * d.Wo))) % d.kt;
+        rot = rot < 0 ? rot + d.kt : rot;
+      }
+    }
+    iss_dt = rot;
+    iss_wk = (unsigned)(rot * d.kh * d.kw * d.cin) * 2u;
     if constexpr (!TR) g_a_row = (unsigned)(n0 + 64 * (rho0 >> 5) + chih(rho0 & 31)) * a_pitch;   // (h, j): 32 h + 128 j rows further, clamped at use
     else g_a_row = (unsigned)(n0 + 32 * (rho0 >> 5) + chih(rho0 & 31)) * a_pitch;                 // j: 64 rows further
     if constexpr (PW) {
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
   };
   auto dma_w = [&](int rows, int unit, int j) __attribute__((always_inline)) {   // one weight row per lane: g_a_row + rows
     unsigned off = g_a_row + (unsigned)rows * a_pitch;
-    off = (off < a_last ? off : a_last) + (unsigned)(iss_ku * 128 + chunk8 * 2);   // N tail: a clamped row, zeroed in the epilogue
+    off = (off < a_last ? off : a_last) + iss_wk + (unsigned)(chunk8 * 2);   // N tail: a clamped row, zeroed in the epilogue
     __builtin_amdgcn_global_load_lds((gptrh_t)pick(iss_live, (unsigned long)(Wb + off)),
                                      (lptrh_t)(smem + unit * UNITH + (j * 8 + wave) * 512), 16, 0, 0);
   };
@@ -188,18 +200,23 @@ __global__ __launch_bounds__(kThreadsH) void gemm_quad_half_kernel(const pv_conv
   };
   auto advance = [&]() __attribute__((always_inline)) {   // next K tile of the stream
     ++iss_ku;
+    iss_wk += 128u;
     if constexpr (!PW) {
       iss_c0 += 64;
       if (iss_c0 == d.cin) {
         iss_c0 = 0;
         if (++iss_dw == d.kw) {
           iss_dw = 0;
-          if (++iss_dh == d.kh) { iss_dh = 0; ++iss_dt; }
+          if (++iss_dh == d.kh) {
+            iss_dh = 0;
+            if (++iss_dt == d.kt) { iss_dt = 0; iss_wk = 0u; }   // (a rotated reduction wraps to tap 0 = weight column 0)
+          }
         }
       }
     }
     if (iss_ku == nk) {
       iss_ku = 0;
+      iss_wk = 0u;
       iss_it += gridDim.x;
       ++iss_jt;
       iss_live = iss_it < total_tiles;
@@ -493,7 +510,8 @@ int launch9h(const pv_conv3d_desc& d, int tiles_n, long total, hipStream_t s) {
   PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long resident = 256;   // one workgroup per CU
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreadsH);
-  PV_LAUNCH(kern, grid, block, lds, s, d, tiles_n, (int)total);
+  const int tap_rot = !PW && d.kt > 1 && d.st == 1 && d.dil_t <= 1 && (d.Ho * d.Wo) % (TR ? 2 * BMH : BMH) == 0 && pv_tune("gemm9_tap_rot", 1);
+  PV_LAUNCH(kern, grid, block, lds, s, d, tiles_n, (int)total, tap_rot);
   pv_note_kernel("gemm_quad_half_kernel");
   PV_LAUNCH_CHECK();
   return PV_OK;

@@ -1047,6 +1047,32 @@ def test_quad_phase_gemm_kernel_on_transposed_half_tiles(B, T, H, W, cin, cout, 
 
 
 
+# temporal-tap rotation of the eight-phase kernels (whole tiles inside one output frame, temporal stride 1): the tile of output
+# frame t starts its reduction at tap (pt - t) mod kt and wraps through weight column 0
+@pytest.mark.parametrize("knob,tr,B,T,H,W,cin,cout,k,stride", [
+    ("gemm9", -1, 16, 8, 16, 16, 256, 256, (3, 1, 1), (1, 1, 1)),     # SlowFast res4 conv_a: a frame = one 256-voxel tile
+    ("gemm9", -1, 2, 5, 16, 16, 384, 256, (5, 1, 1), (1, 1, 1)),      # five taps, pt = 2: every rotation 0..4 occurs
+    ("gemm9", -1, 2, 4, 16, 16, 128, 256, (3, 3, 3), (1, 1, 1)),      # 27 taps: the rotation moves only the temporal index
+    ("gemm9", -1, 2, 8, 10, 10, 128, 96, (3, 1, 1), (1, 1, 1)),       # tiles straddle frames: not rotated (same stream code)
+    ("gemm9h", 0, 16, 8, 16, 16, 256, 256, (3, 1, 1), (1, 1, 1)),     # two 128-voxel tiles per frame
+    ("gemm9h", 0, 2, 5, 16, 16, 384, 256, (5, 1, 1), (1, 1, 1)),
+    ("gemm9h", 0, 4, 6, 16, 8, 128, 96, (3, 1, 1), (1, 1, 1)),        # a frame = exactly one 128-voxel tile
+    ("gemm9h", 0, 2, 4, 16, 16, 128, 256, (3, 3, 3), (1, 1, 1)),
+    ("gemm9h", 0, 2, 8, 10, 10, 128, 96, (3, 1, 1), (1, 1, 1)),
+    ("gemm9h", 1, 16, 8, 16, 16, 256, 128, (3, 1, 1), (1, 1, 1)),     # transposed tile: a frame = one 256-voxel tile
+    ("gemm9h", 1, 2, 5, 16, 16, 384, 256, (5, 1, 1), (1, 1, 1)),
+    ("gemm9h", 1, 2, 4, 16, 16, 128, 120, (3, 3, 3), (1, 1, 1)),
+])
+def test_eight_phase_kernels_temporal_tap_rotation(knob, tr, B, T, H, W, cin, cout, k, stride):
+    L.tune(gemm9h_tr=tr)
+    try:
+        _gemm8_case(2, B, T, H, W, cin, cout, k, stride, L.ACT_RELU, False, False, True, knob=knob)
+        L.tune(gemm9_tap_rot=0)            # ... and the same stream code without the rotation
+        _gemm8_case(2, B, T, H, W, cin, cout, k, stride, L.ACT_RELU, False, False, True, knob=knob)
+    finally:
+        L.tune(gemm9h_tr=-1, gemm9_tap_rot=1)
+
+
 @pytest.mark.parametrize("B,T,H,W,cin,cout,k,stride", [
     (2, 8, 16, 16, 8, 8, (1, 3, 3), (1, 1, 1)),      # SlowFast fast pathway res2 conv_b: 16 bytes per voxel
     (2, 8, 16, 16, 32, 8, (3, 1, 1), (1, 1, 1)),     # ... conv_a (3,1,1)
