@@ -5,7 +5,7 @@ models/hub/vision_transformers.py:31-39) and X3D-L 16x224^2 (configs[4]) -- the 
 Metric everywhere: max|d| / max|oracle output|.  Every bound is a FIXED number.
 
 0. Round 5 (verdict items): the bench-batch case asserts EVERY ROW (normalised by the row's own logits, a stricter metric than
-   the batch-wide one): against the bf16-storage oracle a fixed per-workload kernel-arithmetic bound (round 4's measured worst
+   the batch-wide one): against the bf16-storage oracle a fixed per-workload kernel-arithmetic bound (the measured worst
    row x 1.3), against the fp32 oracle max(1e-2, 1.15 x what bf16 storage ALONE does to that row with exact arithmetic, no
    kernel) -- X3D-L's worst row is 1.06e-2 where storage alone gives ~1.0e-2; the per-block kernel gate is the measured worst
    x 1.3 per workload instead of a flat 1e-2; the block-final gamma U(0.1, 0.4) instance is a reported second case held to its own
@@ -45,8 +45,10 @@ BLOCK_BF16_TOL = {"x3d_m": 8.5e-3, "x3d_l": 6.8e-3, "slowfast_r50": 8.0e-3, "mvi
 # the same gate on the STRESS instance (block-final gamma ~ 1: the branch is as large as the trunk, so a defect in the branch's
 # kernels is not diluted by the identity path): measured clean in round 5 (profiles/r5/parity_full.jsonl) x 1.3
 BLOCK_BF16_TOL_STRESS = {"x3d_m": 9.0e-3, "slowfast_r50": 1.1e-2}      # measured 6.8e-3 / 8.4e-3
-# bench batch, per ROW against the bf16-storage oracle: round 4's measured worst row (4.1e-3 / 6.6e-3 / 1.2e-3 / 3.7e-3) x 1.3
-ROW_KERNEL_BF16 = {"x3d_m": 5.3e-3, "x3d_l": 8.6e-3, "slowfast_r50": 1.6e-3, "mvit_b_32x3": 4.9e-3}
+# bench batch, per ROW against the bf16-storage oracle: the measured worst row x 1.3 (round 4: 4.1e-3 / 6.6e-3 / 1.2e-3 / 3.7e-3;
+# round 5, profiles/r5/parity_full.jsonl: 4.1e-3 / 6.6e-3 / 1.4e-3 / 3.7e-3 -- SlowFast's GEMM layers moved to the eight-phase
+# kernels, another fp32 summation order, and its bound follows the measurement: 1.41e-3 x 1.3)
+ROW_KERNEL_BF16 = {"x3d_m": 5.3e-3, "x3d_l": 8.6e-3, "slowfast_r50": 1.85e-3, "mvit_b_32x3": 4.9e-3}
 # stress instance: the larger of (measured on the MI355X in round 3, profiles/r3/parity_full.jsonl, x 1.3) and (1.35 x the
 # bf16-storage oracle's own answer to a ONE-ulp nudge of its fp32 values, tools/storage_floor.py: 1.6e-2 / 6.7e-2 / 9.3e-3 /
 # 3.2e-3) -- an implementation whose fp32 arithmetic differs in the last bit cannot agree with the emulation better than
