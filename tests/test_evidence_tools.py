@@ -84,3 +84,30 @@ def test_kernel_trace_is_aligned_with_the_plan(tmp_path):
     assert "| 1 | 0.0050 | 0.3000 |" in line and "pw_stream_kernel<8>" in line       # 5000 ns, not the prefix kernel's 3000
     line = [l for l in out.splitlines() if l.startswith("| attn.pool_q |")][0]
     assert "0.0040" in line and "dw3_plane_kernel<2, 2, 0>" in line
+
+
+def test_design_md_measured_table_is_the_generators_output():
+    """DESIGN.md section 4's table is GENERATED from profiles/r5/ (tools/design_table.py): every row of the generator's output
+    stands verbatim in the document, and the traffic figures it quotes are the ones profiles/traffic.json holds for the commit
+    stamped there -- the numbers a reader checks against profiles/ are the numbers in the text."""
+    import json
+    import design_table
+    buf = io.StringIO()
+    argv = sys.argv
+    sys.argv = ["design_table.py", "r5"]
+    try:
+        with redirect_stdout(buf):
+            design_table.main()
+    finally:
+        sys.argv = argv
+    rows = [l for l in buf.getvalue().split("\n") if l.startswith("| ") and "clips/s (default form)" not in l]
+    assert len(rows) == 4
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for r in rows:
+        assert r in design, r[:80]
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert set(tj["_measured_on"]) >= {"x3d_m", "mvit_b_32x3", "slowfast_r50", "x3d_l"}
+    for wl in ("x3d_m", "mvit_b_32x3", "slowfast_r50", "x3d_l"):
+        line = json.load(open(os.path.join(ROOT, "profiles", "r5", wl + "_bench_default.json")))
+        assert line["roofline"]["kernel"] in tj[wl]["_by_kernel"]     # the dominant symbol has its own PMC population
+        assert line["cpu_baseline"]["kind"] in ("port", "reference") and len(line["cpu_baseline"]["threads_sweep"]) >= 2
