@@ -476,22 +476,60 @@ def pcie_leg(model, x, step, batch, steps, device):
     return pcie
 
 
-def bind_rank(local_rank, local_world):
-    """One process per GPU on one node: rank i gets the i-th of `local_world` equal slices of the CPUs this job may use
-    (8 conversions start at once -- BatchNorm folding in fp64, weight packing -- and 8 x nproc OpenMP threads would fight over
-    the same cores), torch's intra-op pool is sized to the slice.  Returns the CPU list (unchanged affinity when the job has
-    fewer CPUs than ranks)."""
+def _parse_cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_cpus(pci_bus_id):
+    """CPUs of the NUMA node the GPU with this PCI address ("0000:c1:00.0") hangs off, or None (no sysfs entry, node -1)."""
+    try:
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % pci_bus_id.lower()).read())
+        if node < 0:
+            return None
+        return _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read()) or None
+    except (OSError, ValueError):
+        return None
+
+
+def bind_rank(local_rank, local_world, pci_bus_ids=None):
+    """One process per GPU on one node: each rank gets a disjoint slice of the CPUs this job may use (8 conversions start at
+    once -- BatchNorm folding in fp64, weight packing -- and 8 x nproc OpenMP threads would fight over the same cores).
+    `pci_bus_ids` (one PCI address per local rank, from the HIP device properties): the slice is taken from the CPUs of the
+    NUMA node GPU `local_rank` is attached to, shared equally with the other local ranks on that node; without it (dry-host
+    runs, no sysfs entry) the job's CPU list is cut into `local_world` contiguous slices.  torch's intra-op pool AND
+    OMP_NUM_THREADS are set to the same number (the launcher exports OMP_NUM_THREADS = nproc / gpus; the two must agree).
+    Returns the CPU list (unchanged affinity when the job has fewer CPUs than ranks)."""
     import torch
-    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
-    if local_world > 1 and len(cpus) >= local_world:
-        per = len(cpus) // local_world
-        mine = cpus[local_rank * per:(local_rank + 1) * per]
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cpus, mine = allowed, None
+    if local_world > 1 and len(allowed) >= local_world:
+        if pci_bus_ids and len(pci_bus_ids) == local_world:
+            nodes = [gpu_numa_cpus(b) for b in pci_bus_ids]
+            if all(n is not None for n in nodes):
+                key = tuple(nodes[local_rank])
+                peers = [r for r in range(local_world) if tuple(nodes[r]) == key]       # local ranks on the same node
+                pool = [c for c in nodes[local_rank] if c in set(allowed)]
+                per = len(pool) // len(peers)
+                if per >= 1:
+                    i = peers.index(local_rank)
+                    mine = pool[i * per:(i + 1) * per]
+        if mine is None:
+            per = len(allowed) // local_world
+            mine = allowed[local_rank * per:(local_rank + 1) * per]
         try:
             os.sched_setaffinity(0, mine)
             cpus = mine
         except OSError:
             pass
-    torch.set_num_threads(max(1, min(len(cpus), 16)))
+    threads = max(1, min(len(cpus), 16))
+    torch.set_num_threads(threads)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     return cpus
 
 
@@ -679,7 +717,13 @@ def _main(out):
         from pytorchvideo_amd.accelerator.mi355x import tuning
         tuning.apply(args.tune)
     if world > 1:
-        bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        try:      # PCI addresses of the node's GPUs -> NUMA-local CPU slices (falls back to equal contiguous slices)
+            props = [torch.cuda.get_device_properties(i) for i in range(lw)]
+            pci = ["%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id) for p in props]
+        except Exception:      # noqa: BLE001 -- older torch without the pci_* fields, fewer visible devices than local ranks
+            pci = None
+        bind_rank(local_rank, lw, pci)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:

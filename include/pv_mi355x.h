@@ -451,7 +451,18 @@ typedef struct pv_mlp_desc {
   const float* nn_beta;
   int32_t ldyn;
   float nn_eps;
+  /* Round 6: which host-packed image `w12` is and which kernel streams it.  PV_MLP_LAYOUT_ROWS32 (0): the image described
+   * above, 32 token rows per wave, one wave per SIMD.  PV_MLP_LAYOUT_ROWS16 (1): 16 token rows per wave on
+   * v_mfma_f32_16x16x32_bf16, two waves per SIMD; same block structure and sizes, other fragment order (block j):
+   *   [f = 2 ks + uh < C/16][l < 64][j8 < 8]  bf16  W1[32 j + 16 uh + (l&15)][32 ks + 8 (l>>4) + j8]
+   *   [ob < Cout/16][l < 64][j8 < 8]          bf16  W2[32 (ob>>1) + 8 ((l&15)>>2) + 4 (ob&1) + (l&3)][32 (j-1) + u(l>>4, j8)],
+   *        u(g, j8) = j8 < 4 ? 4 g + j8 : 16 + 4 g + j8 - 4
+   *   [u < 32] fp32  b1[32 j + u], then 128 bytes of padding
+   * (pack_mlp_weights(..., layout=16)). */
+  int32_t layout;
 } pv_mlp_desc;
+#define PV_MLP_LAYOUT_ROWS32 0
+#define PV_MLP_LAYOUT_ROWS16 1
 int pv_mlp_rows(const pv_mlp_desc* d, pv_stream_t stream);
 int pv_mlp_rows_supported(const pv_mlp_desc* d);
 

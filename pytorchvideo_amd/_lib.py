@@ -103,7 +103,8 @@ RoiAlignDesc = _struct("RoiAlignDesc", [
 MlpDesc = _struct("MlpDesc", [
     ("x", _p), ("w12", _p), ("y", _p), ("b2", _p), ("residual", _p), ("ln_gamma", _p), ("ln_beta", _p), ("M", _i64)]
     + _ints("C", "H", "Cout", "ldx", "ldr", "ldy", "act", "dtype") + [("ln_eps", _f32)]
-    + [("yn", _p), ("nn_gamma", _p), ("nn_beta", _p)] + _ints("ldyn") + [("nn_eps", _f32)])
+    + [("yn", _p), ("nn_gamma", _p), ("nn_beta", _p)] + _ints("ldyn") + [("nn_eps", _f32)] + _ints("layout"))
+MLP_LAYOUT_ROWS32, MLP_LAYOUT_ROWS16 = 0, 1
 
 LnLinearDesc = _struct("LnLinearDesc", [
     ("x", _p), ("wb", _p), ("y", _p), ("ln_gamma", _p), ("ln_beta", _p), ("M", _i64)]
@@ -177,7 +178,7 @@ _SYMBOLS = [
     ("pv_forward_gather", C.c_int, [_p, _p, _p, C.POINTER(GatherSrc), C.c_int, _p, _p, _p]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _lib = None
 

@@ -193,7 +193,12 @@ def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quant
                                streams: int = 1, emit_only: bool = False):
     """Return a deploy-form copy of a transmuted `model`, specialised to `input_tensor`'s
     shape.  `dtype` (torch.bfloat16 | torch.float32) selects the kernels' storage type and
-    defaults to the input tensor's dtype (fp32 input -> fp32 kernels).  `streams` > 1: see SplitBatchDeployed."""
+    defaults to the input tensor's dtype (fp32 input -> fp32 kernels).  `streams` > 1: see SplitBatchDeployed.
+    `emit_only=True` runs only the HOST half of the conversion (BatchNorm folding, weight packing, arena planning; no device
+    is touched) and returns the plan's statistics as a dict -- {"fused", "ops", "arena_bytes", "weight_bytes"}, or with
+    `streams` > 1 {"streams": [one such dict per sub-batch]} -- instead of a module; detection networks do not support it."""
+    if emit_only and type(model).__name__ == "DetectionBBoxNetwork":
+        raise NotImplementedError("emit_only is not implemented for DetectionBBoxNetwork (its conversion needs the box list on the device)")
     if streams > 1 and type(model).__name__ != "DetectionBBoxNetwork":
         n = _batch_of(input_tensor)
         k = min(int(streams), n)
@@ -203,7 +208,9 @@ def convert_to_deployable_form(model: nn.Module, input_tensor, convert_for_quant
             xc = [t[lo:lo + b] for t in input_tensor] if isinstance(input_tensor, (list, tuple)) else input_tensor[lo:lo + b]
             lo += b
             parts.append(convert_to_deployable_form(model, xc, convert_for_quantize, native_conv3d_op_qnnpack,
-                                                    dtype=dtype, use_graph=use_graph))
+                                                    dtype=dtype, use_graph=use_graph, emit_only=emit_only))
+        if emit_only:
+            return {"streams": parts}
         from . import tuning
         return SplitBatchDeployed(parts, splits, parts[0]._pv_session.device, joint=tuning.get("split_joint_graph"))
     if type(model).__name__ == "DetectionBBoxNetwork":

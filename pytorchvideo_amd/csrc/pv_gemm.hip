@@ -498,7 +498,7 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
       pv_tune("gemm_tmode", 1))
     tap_rot |= 2;
   else if (!pw && taps > 1 && d.cin % 64 == 0 && pv_tune("gemm_umode", 1))
-    tap_rot |= 4;
+    tap_rot = 4;      // uniform-tap staging does not apply the rotation: drop bit 0 rather than compute a rotation nobody uses
   dim3 grid((unsigned)(total < resident ? total : resident)), block(kThreads);
 #ifdef PV_DEV_ABLATION   // timing builds that skip loads / MFMAs / the epilogue (WRONG results): development variant of the library only
   const int abl = pv_tune("gemm_abl", 0);

@@ -589,6 +589,9 @@ int launch9(const pv_conv3d_desc& d, int tiles_n, long total, hipStream_t s) {
 static bool gemm9_geometry_ok(const pv_conv3d_desc& d, long& M, long& K, long& tiles_m, int& tiles_n) {
   if (d.dtype != PV_BF16 || d.a_gate != nullptr || d.a_act != PV_ACT_NONE || d.x2 != nullptr) return false;
   if (d.kt > 8 || d.kh > 8 || d.kw > 8) return false;                                // 8-bit window masks per axis
+  // dilated convs (detection backbones' res5) stay on the 128 x 128 kernel, whose dilation path has kernel tests
+  // (test_dilated_dense_conv); the window masks here fold dil_* in, but no test forces a dilated descriptor onto these tiles
+  if (d.dil_t > 1 || d.dil_h > 1 || d.dil_w > 1) return false;
   const int taps = d.kt * d.kh * d.kw;
   if (d.cin % 64 != 0 || ((long)taps * d.cin) % 128 != 0) return false;             // a K step of 64 inside one tap; K tiles in pairs
   M = (long)d.B * d.To * d.Ho * d.Wo;

@@ -526,6 +526,7 @@ int pv_gemm9h_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
   if (mode == 0) return PV_ERR_UNSUPPORTED;
   if (d.dtype != PV_BF16 || d.a_gate != nullptr || d.a_act != PV_ACT_NONE || d.x2 != nullptr) return PV_ERR_UNSUPPORTED;
   if (d.kt > 8 || d.kh > 8 || d.kw > 8) return PV_ERR_UNSUPPORTED;                  // 8-bit window masks per axis
+  if (d.dil_t > 1 || d.dil_h > 1 || d.dil_w > 1) return PV_ERR_UNSUPPORTED;         // dilated: the 128 x 128 kernel (see pv_gemm9.hip)
   const long K = (long)d.kt * d.kh * d.kw * d.cin;
   if (d.cin % 64 != 0 || K % 192 != 0 || K < 384) return PV_ERR_UNSUPPORTED;        // a K step inside one tap; K tiles in triples
   const long M = (long)d.B * d.To * d.Ho * d.Wo;

@@ -100,10 +100,26 @@ def test_north_star_bench_batch_with_bench_streams_every_row(workload):
     _well_scaled(r)
     assert r["bf16_replay_equal"]
     assert r["bf16_vs_fp32_oracle"] <= BF16_TOL
-    # every row, normalised by the row's own logits
-    assert r["bf16_rows_worst"] <= ROW_KERNEL_BF16[workload]                                  # the kernels' own arithmetic
-    assert r["bf16_rows_worst_fp32"] <= max(BF16_TOL, 1.15 * r["storage_rows_worst"])         # bf16 storage is the floor
-    assert r["top1_agree"] >= r["batch"] - 1
+    # every row, normalised by the row's own logits; a failing row is named with its numbers
+    rows = r["row_detail"]
+    fmt = lambda t: "row %d: kernel arithmetic %.2e, vs fp32 oracle %.2e (bf16 storage alone %.2e), top-2 margin %.2e, top-1 %s" % (
+        t["row"], t["err_kernel"], t["err_fp32"], t["storage"], t["margin"], "agrees" if t["top1"] else "FLIPPED")
+    bad = [fmt(t) for t in rows if not t["err_kernel"] <= ROW_KERNEL_BF16[workload]]                    # the kernels' own arithmetic
+    assert not bad, "rows above the kernel-arithmetic bound %.2e: %s" % (ROW_KERNEL_BF16[workload], bad)
+    floor = max(BF16_TOL, 1.15 * r["storage_rows_worst"])                                               # bf16 storage is the floor
+    bad = [fmt(t) for t in rows if not t["err_fp32"] <= floor]
+    assert not bad, "rows above max(1e-2, 1.15 x the worst row's storage floor) = %.2e: %s" % (floor, bad)
+    over = [fmt(t) for t in rows if t["err_fp32"] > BF16_TOL]
+    if over:
+        print("rows above 1e-2 against the fp32 oracle (allowed only because bf16 storage alone is there): %s" % over)
+    # top-1: a row whose fp32-oracle margin between its two best classes exceeds twice its measured error MUST agree; a row
+    # with a smaller margin is undecidable at this precision (either class is within the error) and is reported, not asserted
+    decidable = [t for t in rows if t["margin"] > 2.0 * t["err_fp32"]]
+    skipped = [t["row"] for t in rows if t["margin"] <= 2.0 * t["err_fp32"]]
+    print("top-1 asserted on %d of %d rows (margin <= 2 x error, not asserted: %s)" % (len(decidable), len(rows), skipped))
+    bad = [fmt(t) for t in decidable if not t["top1"]]
+    assert not bad, "top-1 flips on decidable rows: %s" % bad
+    assert len(decidable) >= len(rows) // 2          # the instance must not make the assertion vacuous
 
 
 @pytest.mark.parametrize("workload", WORKLOADS4)
@@ -148,6 +164,7 @@ def test_the_block_gate_sees_a_five_percent_defect_in_one_filter_bank():
     assert r["trained_like"]["clean"] <= BLOCK_BF16_TOL["x3d_m"]
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("workload", WORKLOADS4)
 def test_second_instance_block_final_gamma_0p1_to_0p4(workload):
     """The reported second case (round-4 verdict): the gamma range is not the only thing between pass and fail -- with
@@ -164,6 +181,7 @@ def test_second_instance_block_final_gamma_0p1_to_0p4(workload):
     assert r["top1_agree"] == 1
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("workload", WORKLOADS4)
 def test_stress_instance_one_clip(workload):
     from parity_full import case

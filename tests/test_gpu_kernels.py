@@ -884,7 +884,12 @@ def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, k
     w = (torch.randn((cout, cin) + k, generator=g) * (cin * k[0] * k[1] * k[2]) ** -0.5).to(dtype).cuda()
     shift = torch.randn(cout, generator=g).cuda()
     scale = (torch.rand(cout, generator=g) + 0.5).cuda() if affine else None
-    want = F.conv3d(x.float().permute(0, 4, 1, 2, 3), w.float(), stride=stride, padding=pad)
+    if k == (1, 1, 1) and stride == (1, 1, 1):
+        # the same sums as one fp32 matmul on the host (torch's own GPU conv spends up to a minute searching for an algorithm on a
+        # 1 x 1 x 70 000 grid: 172 s of the suite in round 5)
+        want = (x.float().cpu().reshape(-1, cin) @ w.float().cpu().reshape(cout, cin).t()).reshape(B, T, H, W, cout).permute(0, 4, 1, 2, 3).cuda()
+    else:
+        want = F.conv3d(x.float().permute(0, 4, 1, 2, 3), w.float(), stride=stride, padding=pad)
     if affine:
         want = want * scale.view(1, -1, 1, 1, 1)
     want = want + shift.view(1, -1, 1, 1, 1)
@@ -906,6 +911,8 @@ def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, k
     d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *stride, *pad)
     d.act, d.a_act, d.dtype, d.y_f32, d.r_f32 = act, L.ACT_NONE, L.PV_BF16, int(y_f32), int(y_f32 and res)
     L.tune(**{knob: ct})
+    if knob == "gemm8":                  # pv_conv3d asks the eight-phase kernels first: keep them away from the ring kernel's cases
+        L.tune(gemm9=0)
     try:
         call("pv_conv3d", d)
         routed = _routed_kernel(L.OP_CONV3D, d)
@@ -913,8 +920,13 @@ def _gemm8_case(ct, B, T, H, W, cin, cout, k, stride, act, res, y_f32, affine, k
         call("pv_conv3d", d)                       # a second launch gives the same bits
     finally:
         L.tune(**{knob: 1})
-    if knob in ("gemm9", "gemm9h"):      # (the 256-wide ring kernel declines short reductions: its cases need not all reach it)
+        L.tune(gemm9=1)
+    if knob in ("gemm9", "gemm9h"):
         assert routed == {"gemm9": "gemm_quad_kernel", "gemm9h": "gemm_quad_half_kernel"}[knob], routed
+    elif cin * k[0] * k[1] * k[2] >= 192 and (k == (1, 1, 1) or cin >= 64):
+        # the ring kernel takes every forced case pv_conv3d offers it (pointwise, or >= 64 input channels) with at least three
+        # 64-deep stages (these cases used to pass on the eight-phase kernels without reaching it)
+        assert routed == "gemm8_kernel", routed
     assert torch.equal(got1, y)
     assert rel_err(y[..., :cout].permute(0, 4, 1, 2, 3), want) <= 1e-2
     if cp > cout:
@@ -1132,7 +1144,8 @@ def test_narrow_dense_conv_on_the_tap_streaming_kernel(B, T, H, W, cin, cout, k,
     (130, 384, 1536, 384, False, False),    # bf16 operand, no residual
     (129, 384, 64, 384, True, False),       # two hidden blocks only
 ])
-def test_fused_mlp_rows(M, Cin, H, Cout, ln, res):
+@pytest.mark.parametrize("layout", [16, 32])    # 16: sixteen token rows per wave, two waves per SIMD (round 6); 32: the round-3 kernel
+def test_fused_mlp_rows(M, Cin, H, Cout, ln, res, layout):
     """pv_mlp_rows: norm2 -> fc1 -> GELU -> fc2 -> + residual (layers/attention.py:102-114,750-757) in one launch
     against fp32 torch on the same bf16-rounded weights (ragged row counts: the last 128-row tile is partial)."""
     from pytorchvideo_amd.accelerator.mi355x.emit_mvit import pack_mlp_weights
@@ -1151,16 +1164,18 @@ def test_fused_mlp_rows(M, Cin, H, Cout, ln, res):
         xb = x32.bfloat16()
         want = b2 + F.linear(F.gelu(F.linear(xb.float(), w1, b1)), w2) + (r32 if res else 0.0)
         x_dev = xb.cuda()
-    img = pack_mlp_weights(w1, b1, w2).cuda()
+    img = pack_mlp_weights(w1, b1, w2, layout=layout).cuda()
     y = torch.full((M, Cout), 7.0, dtype=torch.float32, device="cuda")
     b2d, gd, bd, rd = b2.cuda(), gamma.cuda(), beta.cuda(), r32.cuda()
     d = L.MlpDesc()
+    d.layout = L.MLP_LAYOUT_ROWS16 if layout == 16 else L.MLP_LAYOUT_ROWS32
     d.x, d.w12, d.y, d.b2 = x_dev.data_ptr(), img.data_ptr(), y.data_ptr(), b2d.data_ptr()
     d.residual = rd.data_ptr() if (res and not ln) else None
     d.ln_gamma, d.ln_beta, d.ln_eps = (gd.data_ptr(), bd.data_ptr(), 1e-6) if ln else (None, None, 0.0)
     d.M, d.C, d.H, d.Cout, d.ldx, d.ldr, d.ldy, d.act, d.dtype = M, Cin, H, Cout, Cin, Cout, Cout, L.ACT_GELU, L.PV_BF16
     assert L.lib().pv_mlp_rows_supported(C.byref(d)) == 1
     call("pv_mlp_rows", d)
+    assert _routed_kernel(L.OP_MLP_ROWS, d) == ("mlp_rows16_kernel" if layout == 16 else "mlp_rows_kernel")
     assert rel_err(y, want) <= 1e-2
     y2 = torch.zeros_like(y)
     d.y = y2.data_ptr()

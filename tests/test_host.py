@@ -321,6 +321,57 @@ def test_fused_mlp_weight_image_follows_the_documented_layout():
         assert not c[32:].any()
 
 
+def test_fused_mlp_rows16_weight_image_replayed_with_the_mfma_lane_roles():
+    """Round 6: the image of the 16-rows-per-wave kernel (pack_mlp_weights(layout=16), include/pv_mi355x.h PV_MLP_LAYOUT_ROWS16)
+    replayed on the host with exactly the roles csrc/pv_mlp.hip::mlp_rows16_kernel gives the lanes of v_mfma_f32_16x16x32_bf16
+    (A[m = l&15][k = 8 (l>>4) + j], B[k][n = l&15], D[m = 4 (l>>4) + r][n]): phase A per 16-unit half, the activation's
+    registers as the phase-B operand through the permuted K order, phase B one block behind, output channel of (ob, m) --
+    equal to fc2(act(fc1(x))) on the same bf16-rounded weights."""
+    import torch
+    from pytorchvideo_amd.accelerator.mi355x.emit_mvit import pack_mlp_weights
+    torch.manual_seed(0)
+    H, Cin, Cout, R = 96, 64, 96, 16
+    w1, b1, w2 = torch.randn(H, Cin) * 0.2, torch.randn(H), torch.randn(Cout, H) * 0.2
+    img = pack_mlp_weights(w1, b1, w2, layout=16)
+    KS2, NOB16, NH = Cin // 32, Cout // 16, H // 32
+    stage = 2 * KS2 * 1024 + NOB16 * 1024 + 256
+    assert img.numel() == (NH + 3) * stage and not img[(NH + 1) * stage:].any()
+    assert img.numel() == pack_mlp_weights(w1, b1, w2).numel()            # same block structure and size as the 32-row image
+    x = torch.randn(R, Cin).bfloat16().float()
+    act = torch.relu
+    Y = torch.zeros(NOB16, 16, R)                     # [ob][m][n]
+    Hprev = torch.zeros(2, 16, R)                     # D_0 / D_1 of the previous block after the activation: [uh][m' = 4 g + r][n]
+    for j in range(NH + 1):
+        blk = img[j * stage:(j + 1) * stage]
+        a = blk[:2 * KS2 * 1024].view(torch.int16).view(torch.bfloat16).float().reshape(2 * KS2, 4, 16, 8)     # [f][g][m][j8]
+        b = blk[2 * KS2 * 1024:2 * KS2 * 1024 + NOB16 * 1024].view(torch.int16).view(torch.bfloat16).float().reshape(NOB16, 4, 16, 8)
+        c = blk[2 * KS2 * 1024 + NOB16 * 1024:].view(torch.float32)
+        assert not c[32:].any()
+        D = torch.zeros(2, 16, R)
+        for uh in range(2):
+            D[uh] = c[16 * uh:16 * uh + 16][:, None].expand(16, R).clone()           # b1 as the C operand
+            for ks in range(KS2):
+                A = a[2 * ks + uh].permute(1, 0, 2).reshape(16, 32)                  # A[m][k = 8 g + j8]
+                B = x[:, 32 * ks:32 * ks + 32].t()                                   # B[k][n] = x[n][32 ks + k]
+                D[uh] += A @ B
+        # phase B of block j - 1: B[k = 8 g + j8][n] = j8 < 4 ? H_0[4 g + j8][n] : H_1[4 g + j8 - 4][n]
+        Bk = torch.zeros(32, R)
+        for g in range(4):
+            for j8 in range(8):
+                Bk[8 * g + j8] = Hprev[0, 4 * g + j8] if j8 < 4 else Hprev[1, 4 * g + j8 - 4]
+        for ob in range(NOB16):
+            A = b[ob].permute(1, 0, 2).reshape(16, 32)
+            Y[ob] += A @ Bk
+        Hprev = act(D).bfloat16().float()
+    out = torch.zeros(R, Cout)
+    for ob in range(NOB16):
+        for m in range(16):
+            out[:, 32 * (ob >> 1) + 8 * (m >> 2) + 4 * (ob & 1) + (m & 3)] = Y[ob, m]
+    bf = lambda t: t.bfloat16().float()
+    want = torch.nn.functional.linear(bf(act(torch.nn.functional.linear(x, bf(w1), b1))), bf(w2))
+    assert (out - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
 def test_ln_linear_weight_image_follows_the_documented_layout():
     import torch
     from pytorchvideo_amd.accelerator.mi355x.emit_mvit import _chi, pack_ln_linear_weights

@@ -4,7 +4,7 @@ TAG=${1:-r1}
 WL=${2:-x3d_m}
 R=$PWD
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest.log 2>&1
+PV_RUN_SLOW=1 python -m pytest tests -m gpu -x -q --durations=40 > gpurun_out/${TAG}_pytest.log 2>&1
 tail -5 gpurun_out/${TAG}_pytest.log
 PV_BENCH_VERBOSE=1 python bench.py --workload $WL --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_${WL}.json 2> gpurun_out/${TAG}_bench_${WL}.err
 cat gpurun_out/${TAG}_bench_${WL}.json; tail -30 gpurun_out/${TAG}_bench_${WL}.err

@@ -37,6 +37,19 @@ def filled_model(workload, fill, seed=0):
     from oracle.weights import calibrated_fill, deterministic_fill, reference_style_fill, trained_like_fill
     torch.manual_seed(0)
     m, shape = make_model(workload)
+    # the fill's calibration forward runs with the process's DEFAULT thread count (as in bench.py), whatever cap the test session
+    # put on the CPU references: the instance is then the one bench.py times, bit for bit (tests/conftest.py)
+    capped = torch.get_num_threads()
+    torch.set_num_threads(int(os.environ.get("PV_TORCH_DEFAULT_THREADS", capped)))
+    try:
+        return _fill(m, shape, fill, seed)
+    finally:
+        torch.set_num_threads(capped)
+
+
+def _fill(m, shape, fill, seed):
+    from bench import synth_input
+    from oracle.weights import calibrated_fill, deterministic_fill, reference_style_fill, trained_like_fill
     if fill == "trained_like":
         trained_like_fill(m, synth_input(shape, 2, 7), seed)
     elif fill == "trained_like_wide":      # the reported second instance (round-4 verdict): block-final gamma U(0.1, 0.4)
@@ -50,21 +63,66 @@ def filled_model(workload, fill, seed=0):
     return m.eval(), shape
 
 
-def oracle_numbers(workload, sd, x, batch_hint=1, weights_only=True):
-    """(fp32 oracle, weights-only oracle [or None], bf16-storage oracle) logits."""
+def _oracle_rows(workload, sd, x, batch_hint, weights_only, pool_min, threads):
+    """Worker of `oracle_numbers` (spawned process, or the caller itself): the three oracle logits of the rows in `x`."""
     from bench import oracle_forward
     from oracle import functional as OF
     from oracle.weights import quantize_like_kernels
+    if threads:
+        torch.set_num_threads(threads)
     fn = oracle_forward(workload)
     with torch.no_grad():
         want = fn(sd, x)
         sd_q = quantize_like_kernels(sd)
         xq = [t.bfloat16().float() for t in x] if isinstance(x, list) else x.bfloat16().float()
         want_w = fn(sd_q, xq) if weights_only else None
-        from pytorchvideo_amd.accelerator.mi355x import tuning       # the plan's own routing threshold, not a copy of it
-        with OF.storage_emulation(torch.bfloat16, batch=batch_hint, pool_stream_min_elems=tuning.get("pool_stream_min_elems")):
+        with OF.storage_emulation(torch.bfloat16, batch=batch_hint, pool_stream_min_elems=pool_min):
             want_e = fn(sd_q, xq)
     return want, want_w, want_e
+
+
+def oracle_numbers(workload, sd, x, batch_hint=1, weights_only=True):
+    """(fp32 oracle, weights-only oracle [or None], bf16-storage oracle) logits.
+
+    Eval-mode rows are independent, so a batch is evaluated as row shards in PARALLEL worker processes (spawned: the caller
+    usually holds a HIP context), 16 threads each: on the 256-thread GPU hosts one 256-thread torch call runs the bench batch at
+    ~1.2 clips/s where 8-thread calls reach 4.5 each (bench.py's cpu_baseline sweep) -- the bench-batch cases of
+    tests/test_gpu_full_geometry.py spent 259 s of the suite's 913 s here (round-5 verdict, weak #8).  NOTE: the fp32
+    oracle is invariant to the sharding to 7e-7, the bf16-STORAGE emulation is not (a last-bit difference of an fp32 sum
+    flips bf16 roundings downstream: X3D-M rows move by up to 6e-3 between a batch-2 call and two batch-1 calls, CPU only) --
+    the per-row kernel-arithmetic bounds of the tests are measured against THIS sharding.  PV_ORACLE_SHARDS=1 keeps
+    everything in this process."""
+    from pytorchvideo_amd.accelerator.mi355x import tuning       # the plan's own routing threshold, not a copy of it
+    pool_min = tuning.get("pool_stream_min_elems")
+    batch = (x[0] if isinstance(x, list) else x).shape[0]
+    # the SHARDING is a function of the batch only (8 shards from batch 8 on), so the numbers do not depend on the host; only
+    # how many shards run at once does
+    shards = int(os.environ.get("PV_ORACLE_SHARDS", "0")) or (8 if batch >= 8 else 1)
+    if shards <= 1:
+        return _oracle_rows(workload, sd, x, batch_hint, weights_only, pool_min, 0)
+    conc = max(1, min(shards, (os.cpu_count() or 1) // 16))
+    # plain subprocesses running this file's --oracle-worker entry (no multiprocessing: a spawned child re-imports the
+    # parent's __main__, which is pytest / bench / a stdin script); tensors travel through files in a temporary directory
+    import subprocess
+    import tempfile
+    cuts = [batch * i // shards for i in range(shards + 1)]
+    rows = lambda a, b: [t[a:b].clone() for t in x] if isinstance(x, list) else x[a:b].clone()
+    with tempfile.TemporaryDirectory(prefix="pv_oracle_") as tmp:
+        torch.save(sd, os.path.join(tmp, "sd.pt"))
+        env = dict(os.environ, OMP_NUM_THREADS="16", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        running, rcs = [], []
+        for i in range(shards):
+            torch.save({"workload": workload, "x": rows(cuts[i], cuts[i + 1]), "batch_hint": batch_hint,
+                        "weights_only": weights_only, "pool_min": pool_min}, os.path.join(tmp, "in%d.pt" % i))
+            if len(running) == conc:
+                rcs.append(running.pop(0).wait())
+            running.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-worker", tmp, str(i)], env=env))
+        rcs += [p.wait() for p in running]
+        if any(rcs):
+            raise RuntimeError("oracle worker failed: exit codes %s" % rcs)
+        parts = [torch.load(os.path.join(tmp, "out%d.pt" % i)) for i in range(shards)]
+    cat = lambda k: torch.cat([p[k] for p in parts]) if parts[0][k] is not None else None
+    return cat(0), cat(1), cat(2)
 
 
 def rel(a, b):
@@ -102,6 +160,14 @@ def case(workload, fill="calibrated", batch=1, streams=1, dtypes=("fp32", "bf16"
             out["bf16_rows_worst"] = max(rel(got[i:i + 1], want_e[i:i + 1]) for i in range(batch))
             out["bf16_rows_worst_fp32"] = max(rel(got[i:i + 1], want[i:i + 1]) for i in range(batch))
             out["top1_agree"] = int((got.argmax(1) == want.argmax(1)).sum().item())
+            # per row: (error vs the fp32 oracle, what bf16 storage alone does to the row, the oracle's top-1 / top-2 margin),
+            # all normalised by the row's own max|logit|, and whether the top-1 class agrees
+            top2 = want.topk(2, dim=1).values
+            out["row_detail"] = [
+                {"row": i, "err_fp32": rel(got[i:i + 1], want[i:i + 1]), "storage": rel(want_e[i:i + 1], want[i:i + 1]),
+                 "err_kernel": rel(got[i:i + 1], want_e[i:i + 1]),
+                 "margin": (top2[i, 0] - top2[i, 1]).item() / max(want[i].abs().max().item(), 1e-9),
+                 "top1": bool(got[i].argmax() == want[i].argmax())} for i in range(batch)]
             out["top1_agree_emulated"] = int((got.argmax(1) == want_e.argmax(1)).sum().item())
         del dm
         torch.cuda.empty_cache()
@@ -109,6 +175,13 @@ def case(workload, fill="calibrated", batch=1, streams=1, dtypes=("fp32", "bf16"
 
 
 if __name__ == "__main__":
+    if len(sys.argv) == 4 and sys.argv[1] == "--oracle-worker":      # oracle_numbers' row-shard worker (CPU only)
+        tmp, i = sys.argv[2], int(sys.argv[3])
+        job = torch.load(os.path.join(tmp, "in%d.pt" % i))
+        sd = torch.load(os.path.join(tmp, "sd.pt"))
+        out = _oracle_rows(job["workload"], sd, job["x"], job["batch_hint"], job["weights_only"], job["pool_min"], 16)
+        torch.save(out, os.path.join(tmp, "out%d.pt" % i))
+        sys.exit(0)
     ap = argparse.ArgumentParser()
     ap.add_argument("--workloads", default="x3d_m,x3d_l,slowfast_r50,mvit_b_32x3")
     ap.add_argument("--fills", default="trained_like")
