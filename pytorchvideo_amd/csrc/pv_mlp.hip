@@ -500,7 +500,7 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <int KS2, int NOB16, bool LN, int ACT, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void mlp_rows16_kernel(const pv_mlp_desc d) {
   using G = Mlp16Geom<KS2, NOB16>;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * G::STAGE + NOB16 * 128];   // + gamma | beta of the next block's norm1 (d.yn)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * G::STAGE + NOB16 * 192];   // + gamma | beta of the next block's norm1 (d.yn) + b2 (LayerNorm mode: added in the epilogue)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -534,50 +534,64 @@ __global__ __launch_bounds__(512, 2) void mlp_rows16_kernel(const pv_mlp_desc d)
     const int k = tid < NOB16 * 4 ? tid : tid - NOB16 * 4;
     reinterpret_cast<f32x4*>(smem + 3 * G::STAGE)[tid] = reinterpret_cast<const f32x4*>(tid < NOB16 * 4 ? d.nn_gamma : d.nn_beta)[k];
   }
+  if (LN && tid >= 256 && tid < 256 + NOB16 * 4)      // b2 -> LDS (threads of the second half: the first loads gamma | beta)
+    reinterpret_cast<f32x4*>(smem + 3 * G::STAGE + NOB16 * 128)[tid - 256] = reinterpret_cast<const f32x4*>(d.b2)[tid - 256];
 
   // ---- prologue: operand fragments and accumulator initialisation (residual + b2 go INTO the accumulators) ----
   bf16x8 bx[KS2];
   f32x4 Y[NOB16];
   if constexpr (LN) {
     static_assert(2 * KS2 == NOB16, "LayerNorm mode needs C == Cout");
+    // ONE pass over the fp32 row: its quarter (the token's four lanes hold a quarter row each) is loaded straight INTO the
+    // accumulators (Y = x is the residual), the statistics are taken from those registers (mean, then centred squares: no
+    // cancellation problem, no shift), the normalised values become the operand fragments; b2 is added in the epilogue, from
+    // LDS (adding it here made hipcc keep old and new accumulators side by side and spill 150 registers).  (The 32-row
+    // kernel reads the row three times: with 192 accumulators + 96 fragment registers it cannot keep it.  H = 32 sweep,
+    // tools/r6/mlp_h_sweep.py: 40-47 us of a 100 us launch were prologue + epilogue, all workgroups in it at the same time.)
     const float* xr = static_cast<const float*>(d.x) + mm * d.ldx + 8 * g;
-    // pass 1: shifted row statistics (shift = the row's first element); the token's four lanes hold a quarter row each
-    const float shift0 = static_cast<const float*>(d.x)[mm * d.ldx];
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS2; ++ks) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(xr + 32 * ks), v1 = *reinterpret_cast<const f32x4*>(xr + 32 * ks + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float t0 = v0[e] - shift0, t1 = v1[e] - shift0;
-        s1 += t0 + t1;
-        s2 += t0 * t0 + t1 * t1;
-      }
+      Y[2 * ks] = *reinterpret_cast<const f32x4*>(xr + 32 * ks);
+      Y[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xr + 32 * ks + 4);
     }
-    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    float s1 = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < NOB16; ++ob) s1 += (Y[ob][0] + Y[ob][1]) + (Y[ob][2] + Y[ob][3]);
+    s1 += __shfl_xor(s1, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
     const float inv_c = 1.0f / (float)(32 * KS2);
-    const float mu_s = s1 * inv_c;
-    const float mean = shift0 + mu_s;
-    const float rstd = rsqrtf(fmaxf(s2 * inv_c - mu_s * mu_s, 0.f) + d.ln_eps);
-    asm volatile("" ::: "memory");      // pass 2 reads the row again (L2 / L1 hit) instead of keeping 96 values live across the reduction
+    const float mean = s1 * inv_c;
+    float s2 = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < NOB16; ++ob)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float t = Y[ob][e] - mean; s2 += t * t; }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    float rstd = rsqrtf(s2 * inv_c + d.ln_eps);
+    // the parameter loads below do not depend on the statistics: without this fence the scheduler hoists all 72 of them (288
+    // registers) above the reductions and carries them through scratch
+    asm volatile("" : "+v"(rstd) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < KS2; ++ks) {
       const int c0 = 32 * ks + 8 * g;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(xr + 32 * ks), v1 = *reinterpret_cast<const f32x4*>(xr + 32 * ks + 4);
       const f32x4 g0 = *reinterpret_cast<const f32x4*>(d.ln_gamma + c0), g1 = *reinterpret_cast<const f32x4*>(d.ln_gamma + c0 + 4);
       const f32x4 e0 = *reinterpret_cast<const f32x4*>(d.ln_beta + c0), e1 = *reinterpret_cast<const f32x4*>(d.ln_beta + c0 + 4);
-      const f32x4 c20 = *reinterpret_cast<const f32x4*>(d.b2 + c0), c21 = *reinterpret_cast<const f32x4*>(d.b2 + c0 + 4);
       bf16x8 t;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        t[e] = (bf16_t)((v0[e] - mean) * rstd * g0[e] + e0[e]);
-        t[4 + e] = (bf16_t)((v1[e] - mean) * rstd * g1[e] + e1[e]);
+        t[e] = (bf16_t)((Y[2 * ks][e] - mean) * rstd * g0[e] + e0[e]);
+        t[4 + e] = (bf16_t)((Y[2 * ks + 1][e] - mean) * rstd * g1[e] + e1[e]);
       }
-      bx[ks] = t;
-      Y[2 * ks] = v0 + c20;
-      Y[2 * ks + 1] = v1 + c21;
-      if (ks & 1) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }   // two K steps of loads in flight (64 registers): more and the compiler hoists every load of the row above the arithmetic and spills
+      {
+        // pin the fragment HERE: its only use is in the main loop, and LLVM otherwise sinks all the arithmetic below the last
+        // parameter load (every gamma / beta value of the row live at once: 56 registers through scratch)
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t pin = __builtin_bit_cast(u32x4_t, t);
+        asm volatile("" : "+v"(pin) :: "memory");
+        bx[ks] = __builtin_bit_cast(bf16x8, pin);
+      }
     }
   } else {
     const bf16_t* xr = static_cast<const bf16_t*>(d.x) + mm * d.ldx + 8 * g;
@@ -702,6 +716,11 @@ __global__ __launch_bounds__(512, 2) void mlp_rows16_kernel(const pv_mlp_desc d)
 
   // ---- epilogue: 8 consecutive channels per lane and block pair, a full 128-byte line per token and pair ----
   __builtin_amdgcn_s_waitcnt(vm(0));        // the padding block's LDS-DMA must not outlive the workgroup
+  if constexpr (LN) {
+    const f32x4* c2 = reinterpret_cast<const f32x4*>(smem + 3 * G::STAGE + NOB16 * 128);      // [Cout] b2
+#pragma unroll
+    for (int ob = 0; ob < NOB16; ++ob) Y[ob] += c2[8 * (ob >> 1) + 2 * g + (ob & 1)];           // channels 32 (ob>>1) + 8 g + 4 (ob&1) ..
+  }
   if (ok) {
     float* yr = static_cast<float*>(d.y) + m * d.ldy + 8 * g;
 #pragma unroll
