@@ -410,6 +410,35 @@ typedef struct pv_roi_align_desc {
 } pv_roi_align_desc;
 int pv_roi_align(const pv_roi_align_desc* d, pv_stream_t stream);
 
+/* ---- X3D bottleneck block, fully fused (round 6) ------------------------------------------------------------
+ * Replaces a whole residual block without squeeze-excitation -- pytorchvideo/models/x3d.py:169-212
+ * (create_x3d_bottleneck_block: conv_a 1x1x1 + norm_a + ReLU, conv_b depthwise 3x3x3 + norm_b + Swish, conv_c 1x1x1 + norm_c),
+ * models/resnet.py:1345-1365 (BottleneckBlock.forward) and :1179-1189 (ResBlock.forward: + shortcut, activation) -- in ONE launch
+ * that never writes the expanded tensor (csrc/pv_block.hip):
+ *     y = act_out( r + sc * (Wc . act_b( sb * dw3x3x3( act_a( sa * (Wa . x) + ha ) ) + hb )) + hc )
+ * x (B, T, H, W, cin), r = residual (B, T, H, W, cout) or NULL, y (B, T, H, W, cout): bf16 channels-last, all strides 1,
+ * the depthwise conv zero-pads the EXPANDED tensor by 1 on every side.  Host-packed operands (Cp = round_up(C, 32),
+ * cin_p = round_up(cin, 32)):
+ *   wa  [Cp/16][cin_p/32][64 lanes][8] bf16   Wa[16 mt + (l&15)][32 ks + 8 (l>>4) + j]   (zeros beyond C / cin)
+ *   wb  [27][Cp] fp32                         depthwise taps, t = (kt*3 + kh)*3 + kw
+ *   wc  [cout/16][Cp/32][64 lanes][8] bf16    Wc[16 mt + (l&15)][32 ks + 8 (l>>4) + j]   (zeros beyond C)
+ *   sa, ha, sb, hb [Cp] fp32; sc, hc [cout] fp32: the folded BatchNorms (zeros in the padding channels)
+ * (pytorchvideo_amd/accelerator/mi355x/emit.py::emit_fused_bottleneck packs them.)  pv_bottleneck_supported(d) == 1 for the
+ * geometries the kernel is instantiated for: W <= 14, X3D res4 (cin 96, C 216, cout 96). */
+typedef struct pv_bottleneck_desc {
+  const void* x; void* y; const void* residual;
+  const void* wa; const float* wb; const void* wc;
+  const float* sa; const float* ha; const float* sb; const float* hb; const float* sc; const float* hc;
+  int64_t x_bs, y_bs, r_bs;          /* batch strides, elements */
+  int32_t ldx, ldy, ldr;             /* voxel strides, elements */
+  int32_t B, T, H, W;
+  int32_t cin, C, cout;              /* true channel counts */
+  int32_t act_a, act_b, act_out;     /* pv_act after norm_a / norm_b / the residual join */
+  int32_t dtype;                     /* PV_BF16 */
+} pv_bottleneck_desc;
+int pv_bottleneck(const pv_bottleneck_desc* d, pv_stream_t stream);
+int pv_bottleneck_supported(const pv_bottleneck_desc* d);
+
 /* ---- fused MLP of a MultiScaleBlock on token rows -------------------------------------------------------
  * Replaces  norm2 -> Mlp.fc1 -> GELU -> Mlp.fc2 -> + residual  (pytorchvideo/layers/attention.py:102-114 Mlp.forward,
  * :750-757 the block's second half) in ONE launch whose hidden tensor never leaves the chip (csrc/pv_mlp.hip):
@@ -502,7 +531,8 @@ enum pv_op_kind {
   PV_OP_CONV3D = 1, PV_OP_DWCONV3D = 2, PV_OP_SE_GATE = 3, PV_OP_POOL3D = 4,
   PV_OP_LAYERNORM = 5, PV_OP_SOFTMAX_ROWS = 6, PV_OP_MEAN_ROWS = 7, PV_OP_POSENC = 8,
   PV_OP_ATTENTION = 9, PV_OP_ADD_ACT = 10, PV_OP_INGEST = 11, PV_OP_EGRESS = 12, PV_OP_TOKEN_POOL = 13,
-  PV_OP_ROI_ALIGN = 14, PV_OP_LATERAL = 15, PV_OP_AFFINE_ROWS = 16, PV_OP_MLP_ROWS = 17, PV_OP_LN_LINEAR = 18
+  PV_OP_ROI_ALIGN = 14, PV_OP_LATERAL = 15, PV_OP_AFFINE_ROWS = 16, PV_OP_MLP_ROWS = 17, PV_OP_LN_LINEAR = 18,
+  PV_OP_BOTTLENECK = 19
 };
 typedef struct pv_plan pv_plan;
 pv_plan* pv_plan_create(void);

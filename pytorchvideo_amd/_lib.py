@@ -19,7 +19,7 @@ ACT_NONE, ACT_RELU, ACT_SWISH, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 POOL_MAX, POOL_AVG = 0, 1
 (OP_CONV3D, OP_DWCONV3D, OP_SE_GATE, OP_POOL3D, OP_LAYERNORM, OP_SOFTMAX_ROWS, OP_MEAN_ROWS,
  OP_POSENC, OP_ATTENTION, OP_ADD_ACT, OP_INGEST, OP_EGRESS, OP_TOKEN_POOL, OP_ROI_ALIGN, OP_LATERAL,
- OP_AFFINE_ROWS, OP_MLP_ROWS, OP_LN_LINEAR) = range(1, 19)
+ OP_AFFINE_ROWS, OP_MLP_ROWS, OP_LN_LINEAR, OP_BOTTLENECK) = range(1, 20)
 
 _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -110,6 +110,11 @@ LnLinearDesc = _struct("LnLinearDesc", [
     ("x", _p), ("wb", _p), ("y", _p), ("ln_gamma", _p), ("ln_beta", _p), ("M", _i64)]
     + _ints("C", "N", "ldx", "ldy", "act", "dtype") + [("ln_eps", _f32)])
 
+BottleneckDesc = _struct("BottleneckDesc", [
+    ("x", _p), ("y", _p), ("residual", _p), ("wa", _p), ("wb", _p), ("wc", _p),
+    ("sa", _p), ("ha", _p), ("sb", _p), ("hb", _p), ("sc", _p), ("hc", _p), ("x_bs", _i64), ("y_bs", _i64), ("r_bs", _i64)]
+    + _ints("ldx", "ldy", "ldr", "B", "T", "H", "W", "cin", "C", "cout", "act_a", "act_b", "act_out", "dtype"))
+
 GatherSrc = _struct("GatherSrc", [("ptr", _p), ("row_bytes", C.c_size_t), ("row_pitch", C.c_size_t), ("rows", _i64)])
 
 DESC_FOR_OP = {
@@ -117,7 +122,7 @@ DESC_FOR_OP = {
     OP_LAYERNORM: RowsDesc, OP_SOFTMAX_ROWS: RowsDesc, OP_MEAN_ROWS: RowsDesc, OP_POSENC: PosencDesc,
     OP_ATTENTION: AttentionDesc, OP_ADD_ACT: AddDesc, OP_INGEST: LayoutDesc, OP_EGRESS: LayoutDesc,
     OP_TOKEN_POOL: TokenPoolDesc, OP_ROI_ALIGN: RoiAlignDesc, OP_LATERAL: LateralDesc, OP_AFFINE_ROWS: RowsDesc,
-    OP_MLP_ROWS: MlpDesc, OP_LN_LINEAR: LnLinearDesc,
+    OP_MLP_ROWS: MlpDesc, OP_LN_LINEAR: LnLinearDesc, OP_BOTTLENECK: BottleneckDesc,
 }
 
 # every symbol the header declares: (name, restype, argtypes)
@@ -150,6 +155,8 @@ _SYMBOLS = [
     ("pv_mlp_rows_supported", C.c_int, [C.POINTER(MlpDesc)]),
     ("pv_ln_linear_rows", C.c_int, [C.POINTER(LnLinearDesc), _p]),
     ("pv_ln_linear_rows_supported", C.c_int, [C.POINTER(LnLinearDesc)]),
+    ("pv_bottleneck", C.c_int, [C.POINTER(BottleneckDesc), _p]),
+    ("pv_bottleneck_supported", C.c_int, [C.POINTER(BottleneckDesc)]),
     ("pv_tune_set", C.c_int, [C.c_char_p, C.c_int]),
     ("pv_tune_clear", C.c_int, []),
     ("pv_plan_create", _p, []),
@@ -178,7 +185,7 @@ _SYMBOLS = [
     ("pv_forward_gather", C.c_int, [_p, _p, _p, C.POINTER(GatherSrc), C.c_int, _p, _p, _p]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _lib = None
 

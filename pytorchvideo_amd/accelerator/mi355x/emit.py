@@ -596,6 +596,81 @@ def emit_bottleneck(sess, bb, x, residual=None, final_act=L.ACT_NONE, out=None, 
     return c
 
 
+def pack_bottleneck_operands(conv_a, norm_a, conv_b, bn_b, conv_c, norm_c):
+    """Host-packed operands of pv_bottleneck (layout: include/pv_mi355x.h, pv_bottleneck_desc): dict of CPU tensors
+    wa / wc (bf16 MFMA A-fragment images), wb (fp32 taps), sa ha sb hb sc hc (folded BatchNorms, fp32)."""
+    cin, Cc, cout = conv_a.in_channels, conv_a.out_channels, conv_c.out_channels
+    Cp, cin_p = (Cc + 31) // 32 * 32, (cin + 31) // 32 * 32
+
+    def frag_image(w, rows_p, cols_p):      # [rows_p/16][cols_p/32][lane = 16 q + m][j] = w[16 mt + m][32 ks + 8 q + j]
+        wp = torch.zeros(rows_p, cols_p, dtype=torch.float32)
+        wp[:w.shape[0], :w.shape[1]] = w
+        return wp.reshape(rows_p // 16, 16, cols_p // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().to(torch.bfloat16).reshape(-1)
+
+    wa = frag_image(conv_a.weight.detach().float().cpu().reshape(Cc, cin), Cp, cin_p)
+    wc = frag_image(conv_c.weight.detach().float().cpu().reshape(cout, Cc), cout, Cp)
+    wb = torch.zeros(27, Cp, dtype=torch.float32)
+    wb[:, :Cc] = conv_b.weight.detach().float().cpu().reshape(Cc, 27).t()
+
+    def padded(v, n):
+        o = torch.zeros(n, dtype=torch.float32)
+        o[:v.numel()] = v
+        return o
+
+    sa, ha = fold_norm(norm_a, Cc, conv_a.bias)
+    sb, hb = fold_norm(bn_b, Cc, conv_b.bias)
+    sc, hc = fold_norm(norm_c, cout, conv_c.bias)
+    return dict(wa=wa, wb=wb.reshape(-1), wc=wc, sa=padded(sa, Cp), ha=padded(ha, Cp), sb=padded(sb, Cp), hb=padded(hb, Cp), sc=sc, hc=hc)
+
+
+def can_fuse_bottleneck(sess, bb, x, residual):
+    """A whole residual block without squeeze-excitation as ONE pv_bottleneck launch (csrc/pv_block.hip)?  conv_a 1x1x1,
+    depthwise 3x3x3 conv_b with unit stride and padding 1, conv_c 1x1x1, identity shortcut; the library decides the geometry."""
+    if not tuning.get("fuse_block") or sess.itemsize != 2 or x.f32 or residual is not x:
+        return False
+    ca, cb, cc = getattr(bb, "conv_a", None), getattr(bb, "conv_b", None), getattr(bb, "conv_c", None)
+    if not all(isinstance(c, nn.Conv3d) for c in (ca, cb, cc)):
+        return False
+    try:
+        bn_b, se = _split_norm_b(bb.norm_b)
+        if se is not None or check_conv3d(ca) or not check_conv3d(cb) or check_conv3d(cc) or group_width(cb) != 1:
+            return False
+        acts = (act_code(bb.act_a), act_code(bb.act_b))
+    except Unsupported:
+        return False
+    for c in (ca, cc):
+        if c.kernel_size != (1, 1, 1) or c.stride != (1, 1, 1) or _triple(c.padding) != (0, 0, 0) or c.groups != 1:
+            return False
+    if cb.kernel_size != (3, 3, 3) or cb.stride != (1, 1, 1) or _triple(cb.padding) != (1, 1, 1) or _triple(cb.dilation) != (1, 1, 1):
+        return False
+    if ca.in_channels != x.C or ca.out_channels != cb.in_channels or cb.out_channels != cc.in_channels or cc.out_channels != x.C:
+        return False
+    d = L.BottleneckDesc()
+    d.B, d.T, d.H, d.W, d.cin, d.C, d.cout = x.B, x.T, x.H, x.W, x.C, ca.out_channels, cc.out_channels
+    d.ldx, d.ldy, d.ldr, d.dtype = x.ld, pad8(cc.out_channels), x.ld, sess.pv_dtype
+    d.act_a, d.act_b, d.act_out = acts[0], acts[1], L.ACT_RELU
+    return x.bs == x.voxels * x.ld and L.lib().pv_bottleneck_supported(C.byref(d)) == 1
+
+
+def emit_fused_bottleneck(sess, bb, x, final_act, out=None):
+    """ResBlock.forward (resnet.py:1179-1189) with an identity shortcut around BottleneckBlock.forward (resnet.py:1345-1365,
+    built by x3d.py:169-212) as one launch."""
+    bn_b, _ = _split_norm_b(bb.norm_b)
+    ops = pack_bottleneck_operands(bb.conv_a, bb.norm_a, bb.conv_b, bn_b, bb.conv_c, bb.norm_c)
+    cin, Cc, cout = bb.conv_a.in_channels, bb.conv_a.out_channels, bb.conv_c.out_channels
+    y = out if out is not None else sess.alloc_act(x.B, x.T, x.H, x.W, cout)
+    f = dict(x=x.ptr, y=y.ptr, residual=x.ptr, x_bs=x.bs, y_bs=y.bs, r_bs=x.bs, ldx=x.ld, ldy=y.ld, ldr=x.ld,
+             B=x.B, T=x.T, H=x.H, W=x.W, cin=cin, C=Cc, cout=cout,
+             act_a=act_code(bb.act_a), act_b=act_code(bb.act_b), act_out=final_act, dtype=sess.pv_dtype)
+    for k in ("wa", "wb", "wc", "sa", "ha", "sb", "hb", "sc", "hc"):
+        f[k] = sess.add_weight(ops[k])
+    vox = x.B * x.T * x.H * x.W
+    sess.add_op(L.OP_BOTTLENECK, f, label="block.fused|%dx%dx%dx%d c%d->%d->%d k1x1x1+k3x3x3+k1x1x1" % (x.B, x.T, x.H, x.W, cin, Cc, cout),
+                alg_bytes=sess.itemsize * vox * (pad8(cin) + pad8(cout)) + 2 * Cc * (cin + cout) + 108 * Cc,
+                flops=2 * vox * Cc * (cin + cout + 27))
+    return y
+
+
 def emit_res_block(sess, rb, x, out=None):
     """ResBlock.forward (resnet.py:1179-1189): act(shortcut + branch2(x))."""
     if not is_add_fusion(rb.branch_fusion):
@@ -608,6 +683,8 @@ def emit_res_block(sess, rb, x, out=None):
         # the projection shortcut rides in conv_c as a second K operand: no launch, no round trip of its output
         return emit_bottleneck(sess, bb, x, residual=None, final_act=act_code(rb.activation), out=out,
                                shortcut=(rb.branch1_conv, rb.branch1_norm, x))
+    if rb.branch1_conv is None and can_fuse_bottleneck(sess, bb, x, x):
+        return emit_fused_bottleneck(sess, bb, x, act_code(rb.activation), out=out)
     if rb.branch1_conv is None:
         shortcut = x
     else:

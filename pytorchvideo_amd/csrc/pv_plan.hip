@@ -10,7 +10,7 @@
 
 namespace {
 thread_local std::string g_last_error;
-constexpr int kAbiVersion = 26;
+constexpr int kAbiVersion = 27;
 }  // namespace
 
 int pv_set_hip_error(hipError_t e, const char* what) {
@@ -102,6 +102,7 @@ size_t desc_size(int kind) {
     case PV_OP_LATERAL: return sizeof(pv_lateral_desc);
     case PV_OP_MLP_ROWS: return sizeof(pv_mlp_desc);
     case PV_OP_LN_LINEAR: return sizeof(pv_ln_linear_desc);
+    case PV_OP_BOTTLENECK: return sizeof(pv_bottleneck_desc);
     default: return 0;
   }
 }
@@ -127,6 +128,7 @@ int run_op(const pv_plan::Op& op, pv_stream_t s) {
     case PV_OP_AFFINE_ROWS: return pv_affine_rows(static_cast<const pv_rows_desc*>(p), s);
     case PV_OP_MLP_ROWS: return pv_mlp_rows(static_cast<const pv_mlp_desc*>(p), s);
     case PV_OP_LN_LINEAR: return pv_ln_linear_rows(static_cast<const pv_ln_linear_desc*>(p), s);
+    case PV_OP_BOTTLENECK: return pv_bottleneck(static_cast<const pv_bottleneck_desc*>(p), s);
     default: return PV_ERR_INVALID;
   }
 }

@@ -1202,6 +1202,69 @@ def test_fused_mlp_rows(M, Cin, H, Cout, ln, res, layout):
     assert L.lib().pv_mlp_rows_supported(C.byref(d)) == 0
 
 
+@pytest.mark.parametrize("B,T,H,W,act_b", [
+    (2, 5, 14, 14, L.ACT_SWISH),     # X3D res4: 14 x 14 maps, seven 2-row tiles per clip
+    (1, 3, 7, 9, L.ACT_SWISH),       # odd height (the last tile holds one row), narrower than the 14-output stencil row
+    (3, 1, 2, 14, L.ACT_RELU),       # a single frame: both temporal neighbours are padding
+    (1, 16, 13, 5, L.ACT_NONE),
+])
+def test_fused_bottleneck_block(B, T, H, W, act_b):
+    """pv_bottleneck (round 6, csrc/pv_block.hip): conv_a + BN + ReLU -> depthwise 3x3x3 + BN + Swish -> conv_c + BN -> + x -> ReLU
+    of an X3D res4 block (models/x3d.py:169-212, models/resnet.py:1345-1365, :1179-1189) in one launch, against fp32 torch on
+    the same bf16-rounded operands -- plainly, and with the two intermediate tensors rounded to bf16 where the kernel rounds them."""
+    import torch.nn as nn
+    from pytorchvideo_amd.accelerator.mi355x.emit import pack_bottleneck_operands
+    cin, Cc, cout = 96, 216, 96
+    g = torch.Generator().manual_seed(100 * H + W)
+    ca, cb, cc = nn.Conv3d(cin, Cc, 1, bias=False), nn.Conv3d(Cc, Cc, 3, padding=1, groups=Cc, bias=False), nn.Conv3d(Cc, cout, 1, bias=False)
+    with torch.no_grad():
+        ca.weight.copy_((torch.randn(Cc, cin, 1, 1, 1, generator=g) * cin ** -0.5).bfloat16().float())
+        cb.weight.copy_(torch.randn(Cc, 1, 3, 3, 3, generator=g) * 27 ** -0.5)
+        cc.weight.copy_((torch.randn(cout, Cc, 1, 1, 1, generator=g) * Cc ** -0.5).bfloat16().float())
+
+    def bn(c):
+        m = nn.BatchNorm3d(c).eval()
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            m.bias.copy_(torch.randn(c, generator=g) * 0.3)
+            m.running_mean.copy_(torch.randn(c, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+        return m
+
+    na, nb, nc = bn(Cc), bn(Cc), bn(cout)
+    fb = {L.ACT_SWISH: lambda t: t * torch.sigmoid(t), L.ACT_RELU: F.relu, L.ACT_NONE: lambda t: t}[act_b]
+    x = torch.randn(B, T, H, W, cin, generator=g).bfloat16()
+    xc = x.float().permute(0, 4, 1, 2, 3)
+    q = lambda t: t.bfloat16().float()
+    with torch.no_grad():
+        want = F.relu(xc + nc(cc(fb(nb(cb(F.relu(na(ca(xc))))))))).permute(0, 2, 3, 4, 1)
+        want_q = F.relu(xc + nc(cc(q(fb(nb(cb(q(F.relu(na(ca(xc))))))))))).permute(0, 2, 3, 4, 1)
+    ops = {k: v.cuda() for k, v in pack_bottleneck_operands(ca, na, cb, nb, cc, nc).items()}
+    xd = x.cuda()
+    ldy = cout + 8
+    y = torch.full((B, T, H, W, ldy), 5.0, dtype=torch.bfloat16, device="cuda")
+    d = L.BottleneckDesc()
+    d.x, d.y, d.residual = xd.data_ptr(), y.data_ptr(), xd.data_ptr()
+    for k, v in ops.items():
+        setattr(d, k, v.data_ptr())
+    d.x_bs, d.y_bs, d.r_bs, d.ldx, d.ldy, d.ldr = T * H * W * cin, T * H * W * ldy, T * H * W * cin, cin, ldy, cin
+    d.B, d.T, d.H, d.W, d.cin, d.C, d.cout = B, T, H, W, cin, Cc, cout
+    d.act_a, d.act_b, d.act_out, d.dtype = L.ACT_RELU, act_b, L.ACT_RELU, L.PV_BF16
+    assert L.lib().pv_bottleneck_supported(C.byref(d)) == 1
+    call("pv_bottleneck", d)
+    assert _routed_kernel(L.OP_BOTTLENECK, d) == "bottleneck_block_kernel"
+    got = y[..., :cout]
+    assert rel_err(got, want) <= 1e-2
+    assert rel_err(got, want_q) <= 6e-3                 # one bf16 rounding of the result + fp32 summation order
+    assert torch.all(y[..., cout:] == 5.0)              # nothing written beyond the block's channels
+    y2 = torch.zeros_like(y)
+    d.y = y2.data_ptr()
+    call("pv_bottleneck", d)
+    assert torch.equal(y2[..., :cout], got)             # no atomics: bit-reproducible
+    d.W = 15                                            # wider than the stencil row: declined, not mis-computed
+    assert L.lib().pv_bottleneck_supported(C.byref(d)) == 0 and L.lib().pv_bottleneck(C.byref(d), None) < 0
+
+
 @pytest.mark.parametrize("M,Cin,N", [(300, 96, 288), (1001, 192, 576), (6274, 384, 1152), (129, 384, 96), (785 * 2, 768, 2304),
                                      (31, 96, 32)])
 def test_layernorm_fused_into_the_qkv_linear(M, Cin, N):
