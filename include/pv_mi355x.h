@@ -435,9 +435,19 @@ typedef struct pv_bottleneck_desc {
   int32_t cin, C, cout;              /* true channel counts */
   int32_t act_a, act_b, act_out;     /* pv_act after norm_a / norm_b / the residual join */
   int32_t dtype;                     /* PV_BF16 */
+  /* mode PV_BLOCK_AB -- blocks WITH squeeze-excitation (x3d.py:190-207: norm_b = Sequential(BN, SE)): the launch stops behind
+   * conv_b.  y receives  sb * dw3x3x3(act_a(...)) + hb  (no activation: conv_c applies gate and Swish while loading its operand)
+   * as bf16 (B, T, H, W, C) with voxel stride ldy, and psum[b][blk][round_up(C, 8)] (fp32, blk < pv_bottleneck_psum_blocks(d))
+   * the sums of those values over the block's voxels -- the squeeze of fvcore's SqueezeExcitation, one writer per entry, no
+   * atomics; pv_se_gate turns them into the gate.  wc, sc, hc, residual, cout, act_b, act_out are ignored. */
+  int32_t mode;
+  float* psum;
 } pv_bottleneck_desc;
+#define PV_BLOCK_FULL 0
+#define PV_BLOCK_AB 1
 int pv_bottleneck(const pv_bottleneck_desc* d, pv_stream_t stream);
 int pv_bottleneck_supported(const pv_bottleneck_desc* d);
+int pv_bottleneck_psum_blocks(const pv_bottleneck_desc* d);
 
 /* ---- fused MLP of a MultiScaleBlock on token rows -------------------------------------------------------
  * Replaces  norm2 -> Mlp.fc1 -> GELU -> Mlp.fc2 -> + residual  (pytorchvideo/layers/attention.py:102-114 Mlp.forward,
@@ -450,11 +460,12 @@ int pv_bottleneck_supported(const pv_bottleneck_desc* d);
  * `w12` is the host-packed LDS image the kernel streams: H/32 + 1 blocks of  C/16*1024 + Cout/32*2048 + 256  bytes, block j
  * holding W1 of hidden block j and W2 of hidden block j - 1 (the kernel multiplies phase B one block behind phase A so that the
  * activation issues in the shadow of MFMAs; W2 of block -1, W1 and b1 of block H/32 are zeros), FOLLOWED BY TWO MORE BLOCKS OF
- * PADDING (any finite values; the kernel prefetches two blocks ahead without a branch).  Block j:
- *   [ks < C/16][hi < 2][rho < 32][j8 < 8]  bf16  W1[32 j + rho][32 (ks>>1) + 16 hi + 8 (ks&1) + j8]
- *   [ob < Cout/32][i < 2][hi < 2][rho < 32][j8 < 8]  bf16  W2[32 ob + chi(rho)][32 (j-1) + (j8&3) + 8 (2 i + (j8>>2)) + 4 hi],
- *        chi(rho) = 16 ((rho>>2)&1) + 4 ((rho>>3)&3) + (rho&3)
- *   [hi < 2][r < 16] fp32  b1[32 j + (r&3) + 8 (r>>2) + 4 hi]  (zeros when the layer has no bias), then 128 bytes of padding
+ * PADDING (any finite values; the kernel prefetches two blocks ahead without a branch).  Block j, in fragments of
+ * v_mfma_f32_16x16x32_bf16 (round 6: 16 token rows per wave, lane l = 16 g + m):
+ *   [f = 2 ks + uh < C/16][l < 64][j8 < 8]  bf16  W1[32 j + 16 uh + (l&15)][32 ks + 8 (l>>4) + j8]
+ *   [ob < Cout/16][l < 64][j8 < 8]          bf16  W2[32 (ob>>1) + 8 ((l&15)>>2) + 4 (ob&1) + (l&3)][32 (j-1) + u(l>>4, j8)],
+ *        u(g, j8) = j8 < 4 ? 4 g + j8 : 16 + 4 g + j8 - 4
+ *   [u < 32] fp32  b1[32 j + u]  (zeros when the layer has no bias), then 128 bytes of padding
  * (pytorchvideo_amd/accelerator/mi355x/emit_mvit.py::pack_mlp_weights builds it).  b2 is [Cout] fp32 or NULL.
  * pv_mlp_rows_supported(d) == 1 for the (C, Cout) pairs the kernel is instantiated for (MViT-B: 96/192, 192/192,
  * 192/384, 384/384; H any multiple of 32). */
@@ -480,18 +491,7 @@ typedef struct pv_mlp_desc {
   const float* nn_beta;
   int32_t ldyn;
   float nn_eps;
-  /* Round 6: which host-packed image `w12` is and which kernel streams it.  PV_MLP_LAYOUT_ROWS32 (0): the image described
-   * above, 32 token rows per wave, one wave per SIMD.  PV_MLP_LAYOUT_ROWS16 (1): 16 token rows per wave on
-   * v_mfma_f32_16x16x32_bf16, two waves per SIMD; same block structure and sizes, other fragment order (block j):
-   *   [f = 2 ks + uh < C/16][l < 64][j8 < 8]  bf16  W1[32 j + 16 uh + (l&15)][32 ks + 8 (l>>4) + j8]
-   *   [ob < Cout/16][l < 64][j8 < 8]          bf16  W2[32 (ob>>1) + 8 ((l&15)>>2) + 4 (ob&1) + (l&3)][32 (j-1) + u(l>>4, j8)],
-   *        u(g, j8) = j8 < 4 ? 4 g + j8 : 16 + 4 g + j8 - 4
-   *   [u < 32] fp32  b1[32 j + u], then 128 bytes of padding
-   * (pack_mlp_weights(..., layout=16)). */
-  int32_t layout;
 } pv_mlp_desc;
-#define PV_MLP_LAYOUT_ROWS32 0
-#define PV_MLP_LAYOUT_ROWS16 1
 int pv_mlp_rows(const pv_mlp_desc* d, pv_stream_t stream);
 int pv_mlp_rows_supported(const pv_mlp_desc* d);
 

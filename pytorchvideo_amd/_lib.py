@@ -103,8 +103,7 @@ RoiAlignDesc = _struct("RoiAlignDesc", [
 MlpDesc = _struct("MlpDesc", [
     ("x", _p), ("w12", _p), ("y", _p), ("b2", _p), ("residual", _p), ("ln_gamma", _p), ("ln_beta", _p), ("M", _i64)]
     + _ints("C", "H", "Cout", "ldx", "ldr", "ldy", "act", "dtype") + [("ln_eps", _f32)]
-    + [("yn", _p), ("nn_gamma", _p), ("nn_beta", _p)] + _ints("ldyn") + [("nn_eps", _f32)] + _ints("layout"))
-MLP_LAYOUT_ROWS32, MLP_LAYOUT_ROWS16 = 0, 1
+    + [("yn", _p), ("nn_gamma", _p), ("nn_beta", _p)] + _ints("ldyn") + [("nn_eps", _f32)])
 
 LnLinearDesc = _struct("LnLinearDesc", [
     ("x", _p), ("wb", _p), ("y", _p), ("ln_gamma", _p), ("ln_beta", _p), ("M", _i64)]
@@ -113,7 +112,9 @@ LnLinearDesc = _struct("LnLinearDesc", [
 BottleneckDesc = _struct("BottleneckDesc", [
     ("x", _p), ("y", _p), ("residual", _p), ("wa", _p), ("wb", _p), ("wc", _p),
     ("sa", _p), ("ha", _p), ("sb", _p), ("hb", _p), ("sc", _p), ("hc", _p), ("x_bs", _i64), ("y_bs", _i64), ("r_bs", _i64)]
-    + _ints("ldx", "ldy", "ldr", "B", "T", "H", "W", "cin", "C", "cout", "act_a", "act_b", "act_out", "dtype"))
+    + _ints("ldx", "ldy", "ldr", "B", "T", "H", "W", "cin", "C", "cout", "act_a", "act_b", "act_out", "dtype", "mode")
+    + [("psum", _p)])
+BLOCK_FULL, BLOCK_AB = 0, 1
 
 GatherSrc = _struct("GatherSrc", [("ptr", _p), ("row_bytes", C.c_size_t), ("row_pitch", C.c_size_t), ("rows", _i64)])
 
@@ -157,6 +158,7 @@ _SYMBOLS = [
     ("pv_ln_linear_rows_supported", C.c_int, [C.POINTER(LnLinearDesc)]),
     ("pv_bottleneck", C.c_int, [C.POINTER(BottleneckDesc), _p]),
     ("pv_bottleneck_supported", C.c_int, [C.POINTER(BottleneckDesc)]),
+    ("pv_bottleneck_psum_blocks", C.c_int, [C.POINTER(BottleneckDesc)]),
     ("pv_tune_set", C.c_int, [C.c_char_p, C.c_int]),
     ("pv_tune_clear", C.c_int, []),
     ("pv_plan_create", _p, []),
@@ -185,7 +187,7 @@ _SYMBOLS = [
     ("pv_forward_gather", C.c_int, [_p, _p, _p, C.POINTER(GatherSrc), C.c_int, _p, _p, _p]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 27
+ABI_VERSION = 29
 
 _lib = None
 

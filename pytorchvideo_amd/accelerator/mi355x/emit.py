@@ -576,7 +576,10 @@ def emit_bottleneck(sess, bb, x, residual=None, final_act=L.ACT_NONE, out=None, 
     for name in ("conv_a", "conv_b", "conv_c"):
         if getattr(bb, name, None) is None:
             raise Unsupported("bottleneck without %s" % name)
-    if can_fuse_pointwise_into_dw(sess, bb.conv_a, bb.conv_b, x):
+    if can_fuse_bottleneck_ab(sess, bb, x):
+        # conv_a -> conv_b -> squeeze sums on the matrix + stencil waves of csrc/pv_block.hip (14 x 14 maps: X3D res4)
+        b, gate, deferred = emit_fused_conv_ab_se(sess, bb, x)
+    elif can_fuse_pointwise_into_dw(sess, bb.conv_a, bb.conv_b, x):
         # conv_a -> conv_b in one pass: the expanded tensor is never written (csrc/pv_pwdw.hip)
         b, gate, deferred = emit_conv_b(sess, bb.conv_b, x, bb.norm_b, bb.act_b,
                                         producer=(bb.conv_a, bb.norm_a, act_code(bb.act_a)))
@@ -599,7 +602,8 @@ def emit_bottleneck(sess, bb, x, residual=None, final_act=L.ACT_NONE, out=None, 
 def pack_bottleneck_operands(conv_a, norm_a, conv_b, bn_b, conv_c, norm_c):
     """Host-packed operands of pv_bottleneck (layout: include/pv_mi355x.h, pv_bottleneck_desc): dict of CPU tensors
     wa / wc (bf16 MFMA A-fragment images), wb (fp32 taps), sa ha sb hb sc hc (folded BatchNorms, fp32)."""
-    cin, Cc, cout = conv_a.in_channels, conv_a.out_channels, conv_c.out_channels
+    cin, Cc = conv_a.in_channels, conv_a.out_channels
+    cout = conv_c.out_channels if conv_c is not None else 16
     Cp, cin_p = (Cc + 31) // 32 * 32, (cin + 31) // 32 * 32
 
     def frag_image(w, rows_p, cols_p):      # [rows_p/16][cols_p/32][lane = 16 q + m][j] = w[16 mt + m][32 ks + 8 q + j]
@@ -608,7 +612,7 @@ def pack_bottleneck_operands(conv_a, norm_a, conv_b, bn_b, conv_c, norm_c):
         return wp.reshape(rows_p // 16, 16, cols_p // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().to(torch.bfloat16).reshape(-1)
 
     wa = frag_image(conv_a.weight.detach().float().cpu().reshape(Cc, cin), Cp, cin_p)
-    wc = frag_image(conv_c.weight.detach().float().cpu().reshape(cout, Cc), cout, Cp)
+    wc = frag_image(conv_c.weight.detach().float().cpu().reshape(cout, Cc), cout, Cp) if conv_c is not None else None
     wb = torch.zeros(27, Cp, dtype=torch.float32)
     wb[:, :Cc] = conv_b.weight.detach().float().cpu().reshape(Cc, 27).t()
 
@@ -619,37 +623,93 @@ def pack_bottleneck_operands(conv_a, norm_a, conv_b, bn_b, conv_c, norm_c):
 
     sa, ha = fold_norm(norm_a, Cc, conv_a.bias)
     sb, hb = fold_norm(bn_b, Cc, conv_b.bias)
-    sc, hc = fold_norm(norm_c, cout, conv_c.bias)
-    return dict(wa=wa, wb=wb.reshape(-1), wc=wc, sa=padded(sa, Cp), ha=padded(ha, Cp), sb=padded(sb, Cp), hb=padded(hb, Cp), sc=sc, hc=hc)
+    out = dict(wa=wa, wb=wb.reshape(-1), sa=padded(sa, Cp), ha=padded(ha, Cp), sb=padded(sb, Cp), hb=padded(hb, Cp))
+    if conv_c is not None:
+        sc, hc = fold_norm(norm_c, cout, conv_c.bias)
+        out.update(wc=wc, sc=sc, hc=hc)
+    return out
+
+
+def _bottleneck_geometry_ok(sess, bb, x, want_se):
+    """Shared structure test of the fused-bottleneck launches: conv_a 1x1x1, depthwise 3x3x3 conv_b with unit stride and padding 1,
+    conv_c 1x1x1, with (want_se) or without squeeze-excitation behind norm_b.  Returns the (act_a, act_b) codes or None."""
+    if not tuning.get("fuse_block") or sess.itemsize != 2 or x.f32:
+        return None
+    ca, cb, cc = getattr(bb, "conv_a", None), getattr(bb, "conv_b", None), getattr(bb, "conv_c", None)
+    if not all(isinstance(c, nn.Conv3d) for c in (ca, cb, cc)):
+        return None
+    try:
+        bn_b, se = _split_norm_b(bb.norm_b)
+        if (se is not None) != want_se or check_conv3d(ca) or not check_conv3d(cb) or check_conv3d(cc) or group_width(cb) != 1:
+            return None
+        if se is not None:
+            if getattr(se, "is_3d", True) is not True:
+                return None
+            _se_parts(se, cb.out_channels)
+        acts = (act_code(bb.act_a), act_code(bb.act_b))
+    except Unsupported:
+        return None
+    for c in (ca, cc):
+        if c.kernel_size != (1, 1, 1) or c.stride != (1, 1, 1) or _triple(c.padding) != (0, 0, 0) or c.groups != 1:
+            return None
+    if cb.kernel_size != (3, 3, 3) or cb.stride != (1, 1, 1) or _triple(cb.padding) != (1, 1, 1) or _triple(cb.dilation) != (1, 1, 1):
+        return None
+    if ca.in_channels != x.C or ca.out_channels != cb.in_channels or cb.out_channels != cc.in_channels:
+        return None
+    if x.bs != x.voxels * x.ld:
+        return None
+    return acts
 
 
 def can_fuse_bottleneck(sess, bb, x, residual):
-    """A whole residual block without squeeze-excitation as ONE pv_bottleneck launch (csrc/pv_block.hip)?  conv_a 1x1x1,
-    depthwise 3x3x3 conv_b with unit stride and padding 1, conv_c 1x1x1, identity shortcut; the library decides the geometry."""
-    if not tuning.get("fuse_block") or sess.itemsize != 2 or x.f32 or residual is not x:
+    """A whole residual block without squeeze-excitation as ONE pv_bottleneck launch (csrc/pv_block.hip)?  Identity shortcut;
+    the library decides the geometry."""
+    if residual is not x:
         return False
-    ca, cb, cc = getattr(bb, "conv_a", None), getattr(bb, "conv_b", None), getattr(bb, "conv_c", None)
-    if not all(isinstance(c, nn.Conv3d) for c in (ca, cb, cc)):
-        return False
-    try:
-        bn_b, se = _split_norm_b(bb.norm_b)
-        if se is not None or check_conv3d(ca) or not check_conv3d(cb) or check_conv3d(cc) or group_width(cb) != 1:
-            return False
-        acts = (act_code(bb.act_a), act_code(bb.act_b))
-    except Unsupported:
-        return False
-    for c in (ca, cc):
-        if c.kernel_size != (1, 1, 1) or c.stride != (1, 1, 1) or _triple(c.padding) != (0, 0, 0) or c.groups != 1:
-            return False
-    if cb.kernel_size != (3, 3, 3) or cb.stride != (1, 1, 1) or _triple(cb.padding) != (1, 1, 1) or _triple(cb.dilation) != (1, 1, 1):
-        return False
-    if ca.in_channels != x.C or ca.out_channels != cb.in_channels or cb.out_channels != cc.in_channels or cc.out_channels != x.C:
+    acts = _bottleneck_geometry_ok(sess, bb, x, want_se=False)
+    if acts is None or bb.conv_c.out_channels != x.C:
         return False
     d = L.BottleneckDesc()
-    d.B, d.T, d.H, d.W, d.cin, d.C, d.cout = x.B, x.T, x.H, x.W, x.C, ca.out_channels, cc.out_channels
-    d.ldx, d.ldy, d.ldr, d.dtype = x.ld, pad8(cc.out_channels), x.ld, sess.pv_dtype
+    d.B, d.T, d.H, d.W, d.cin, d.C, d.cout = x.B, x.T, x.H, x.W, x.C, bb.conv_a.out_channels, bb.conv_c.out_channels
+    d.ldx, d.ldy, d.ldr, d.dtype, d.mode = x.ld, pad8(bb.conv_c.out_channels), x.ld, sess.pv_dtype, L.BLOCK_FULL
     d.act_a, d.act_b, d.act_out = acts[0], acts[1], L.ACT_RELU
-    return x.bs == x.voxels * x.ld and L.lib().pv_bottleneck_supported(C.byref(d)) == 1
+    return L.lib().pv_bottleneck_supported(C.byref(d)) == 1
+
+
+def can_fuse_bottleneck_ab(sess, bb, x):
+    """conv_a + conv_b + the squeeze sums of a block WITH squeeze-excitation as one pv_bottleneck launch (mode PV_BLOCK_AB)?"""
+    acts = _bottleneck_geometry_ok(sess, bb, x, want_se=True)
+    if acts is None:
+        return False
+    d = L.BottleneckDesc()
+    d.B, d.T, d.H, d.W, d.cin, d.C, d.cout = x.B, x.T, x.H, x.W, x.C, bb.conv_a.out_channels, bb.conv_c.out_channels
+    d.ldx, d.ldy, d.dtype, d.mode, d.act_a = x.ld, pad8(bb.conv_a.out_channels), sess.pv_dtype, L.BLOCK_AB, acts[0]
+    return L.lib().pv_bottleneck_supported(C.byref(d)) == 1
+
+
+def emit_fused_conv_ab_se(sess, bb, x):
+    """conv_a + norm_a + act_a + depthwise conv_b + BatchNorm of norm_b + the squeeze of its SqueezeExcitation in one launch; then the
+    gate (pv_se_gate).  Returns (y, gate, deferred activation) like emit_conv_b."""
+    bn_b, se = _split_norm_b(bb.norm_b)
+    ops = pack_bottleneck_operands(bb.conv_a, bb.norm_a, bb.conv_b, bn_b, None, None)
+    cin, Cc = bb.conv_a.in_channels, bb.conv_a.out_channels
+    y = sess.alloc_act(x.B, x.T, x.H, x.W, Cc)
+    f = dict(x=x.ptr, y=y.ptr, residual=None, wc=None, sc=None, hc=None, x_bs=x.bs, y_bs=y.bs, r_bs=0, ldx=x.ld, ldy=y.ld, ldr=0,
+             B=x.B, T=x.T, H=x.H, W=x.W, cin=cin, C=Cc, cout=bb.conv_c.out_channels,
+             act_a=act_code(bb.act_a), act_b=L.ACT_NONE, act_out=L.ACT_NONE, dtype=sess.pv_dtype, mode=L.BLOCK_AB)
+    for k in ("wa", "wb", "sa", "ha", "sb", "hb"):
+        f[k] = sess.add_weight(ops[k])
+    d = L.BottleneckDesc()
+    d.H = x.H
+    nblk = L.lib().pv_bottleneck_psum_blocks(C.byref(d))
+    psum = sess.alloc_raw(4 * x.B * nblk * pad8(Cc))
+    f["psum"] = psum
+    vox = x.B * x.T * x.H * x.W
+    sess.add_op(L.OP_BOTTLENECK, f, label="conv_ab.fused+se|%dx%dx%dx%d c%d->%d k1x1x1+k3x3x3 psum" % (x.B, x.T, x.H, x.W, cin, Cc),
+                alg_bytes=sess.itemsize * vox * (pad8(cin) + pad8(Cc)) + 2 * Cc * cin + 108 * Cc, flops=2 * vox * Cc * (cin + 27))
+    gate = emit_se_gate(sess, se, psum, nblk, x.B, Cc, x.T * x.H * x.W)
+    sess.release(psum)
+    return y, gate, act_code(bb.act_b)
 
 
 def emit_fused_bottleneck(sess, bb, x, final_act, out=None):
@@ -661,7 +721,7 @@ def emit_fused_bottleneck(sess, bb, x, final_act, out=None):
     y = out if out is not None else sess.alloc_act(x.B, x.T, x.H, x.W, cout)
     f = dict(x=x.ptr, y=y.ptr, residual=x.ptr, x_bs=x.bs, y_bs=y.bs, r_bs=x.bs, ldx=x.ld, ldy=y.ld, ldr=x.ld,
              B=x.B, T=x.T, H=x.H, W=x.W, cin=cin, C=Cc, cout=cout,
-             act_a=act_code(bb.act_a), act_b=act_code(bb.act_b), act_out=final_act, dtype=sess.pv_dtype)
+             act_a=act_code(bb.act_a), act_b=act_code(bb.act_b), act_out=final_act, dtype=sess.pv_dtype, mode=L.BLOCK_FULL, psum=None)
     for k in ("wa", "wb", "wc", "sa", "ha", "sb", "hb", "sc", "hc"):
         f[k] = sess.add_weight(ops[k])
     vox = x.B * x.T * x.H * x.W

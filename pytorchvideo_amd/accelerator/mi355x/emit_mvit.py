@@ -367,48 +367,29 @@ def _chi(rho):
     return 16 * ((rho >> 2) & 1) + 4 * ((rho >> 3) & 3) + (rho & 3)
 
 
-def pack_mlp_weights(w1, b1, w2, layout=32):
+def pack_mlp_weights(w1, b1, w2):
     """The per-hidden-block LDS image pv_mlp_rows streams (layout: include/pv_mi355x.h, pv_mlp_desc).
-    w1 [H, C], b1 [H] or None, w2 [Cout, H] (fp32, host) -> uint8 [(H/32 + 3) * (C/16*1024 + Cout/32*2048 + 256)].
-    layout = 32: the 32-rows-per-wave kernel's fragment order (PV_MLP_LAYOUT_ROWS32); 16: the 16-rows-per-wave kernel's
-    (PV_MLP_LAYOUT_ROWS16, round 6) -- same block structure and sizes."""
+    w1 [H, C], b1 [H] or None, w2 [Cout, H] (fp32, host) -> uint8 [(H/32 + 3) * (C/16*1024 + Cout/32*2048 + 256)]."""
     H, Cin = w1.shape
     Cout = w2.shape[0]
     NH, KS, NOB = H // 32, Cin // 16, Cout // 32
     w1 = w1.detach().float().cpu()
     w2 = w2.detach().float().cpu()
-    if layout == 16:
-        # W1: fragment f = 2 ks + uh, lane l = 16 g + m, element j8:  W1[32 hb + 16 uh + m][32 ks + 8 g + j8]
-        #     [hb, uh, m, ks, g, j8] -> [hb, ks, uh, g, m, j8]
-        w1p = w1.reshape(NH, 2, 16, Cin // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).reshape(NH, KS * 512)
-        # W2: fragment ob (16 output channels), lane l = 16 g + m, element j8:
-        #     W2[32 (ob>>1) + 8 (m>>2) + 4 (ob&1) + (m&3)][32 hb + (j8 < 4 ? 4 g + j8 : 16 + 4 g + j8 - 4)]
-        ob = torch.arange(Cout // 16)
-        mrow = torch.arange(16)
-        rows = (32 * (ob >> 1) + 4 * (ob & 1))[:, None] + (8 * (mrow >> 2) + (mrow & 3))[None, :]               # [ob, m]
-        gq, j8 = torch.arange(4), torch.arange(8)
-        unit = torch.where(j8[None, :] < 4, 4 * gq[:, None] + j8[None, :], 16 + 4 * gq[:, None] + j8[None, :] - 4)   # [g, j8]
-        cols = 32 * torch.arange(NH)[:, None, None] + unit[None, :, :]                                         # [hb, g, j8]
-        w2p = w2[rows[None, :, None, :, None], cols[:, None, :, None, :]].reshape(NH, NOB * 1024)              # [hb, ob, g, m, j8]
-        b1p = torch.zeros(NH, 64, dtype=torch.float32)
-        if b1 is not None:
-            b1p[:, :32] = b1.detach().float().cpu().reshape(NH, 32)
-    else:
-        # W1: [hb, rho, q, hi, e, j] -> [hb, ks = (q, e), hi, rho, j];  channel = 32 q + 16 hi + 8 e + j
-        w1p = w1.reshape(NH, 32, Cin // 32, 2, 2, 8).permute(0, 2, 4, 3, 1, 5).reshape(NH, KS * 512)
-        # W2: [hb, ob, i, hi, rho, j] = W2[32 ob + chi(rho)][32 hb + (j&3) + 8 (2 i + (j>>2)) + 4 hi]
-        rho = torch.arange(32)
-        rows = (32 * torch.arange(NOB)[:, None] + torch.tensor([_chi(int(r)) for r in rho])[None, :])            # [ob, rho]
-        j = torch.arange(8)
-        cols = (32 * torch.arange(NH)[:, None, None, None] + (j & 3)[None, None, None, :]
-                + 8 * (2 * torch.arange(2)[None, :, None, None] + (j >> 2)[None, None, None, :])
-                + 4 * torch.arange(2)[None, None, :, None])                                                       # [hb, i, hi, j]
-        w2p = w2[rows[None, :, None, None, :, None], cols[:, None, :, :, None, :]].reshape(NH, NOB * 1024)          # [hb, ob, i, hi, rho, j]
-        r = torch.arange(16)
-        unit = (32 * torch.arange(NH)[:, None, None] + ((r & 3) + 8 * (r >> 2))[None, None, :] + 4 * torch.arange(2)[None, :, None])
-        b1p = torch.zeros(NH, 64, dtype=torch.float32)                                                            # 128 B + 128 B padding
-        if b1 is not None:
-            b1p[:, :32] = b1.detach().float().cpu()[unit].reshape(NH, 32)
+    # W1: fragment f = 2 ks + uh, lane l = 16 g + m, element j8:  W1[32 hb + 16 uh + m][32 ks + 8 g + j8]
+    #     [hb, uh, m, ks, g, j8] -> [hb, ks, uh, g, m, j8]
+    w1p = w1.reshape(NH, 2, 16, Cin // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).reshape(NH, KS * 512)
+    # W2: fragment ob (16 output channels), lane l = 16 g + m, element j8:
+    #     W2[32 (ob>>1) + 8 (m>>2) + 4 (ob&1) + (m&3)][32 hb + (j8 < 4 ? 4 g + j8 : 16 + 4 g + j8 - 4)]
+    ob = torch.arange(Cout // 16)
+    mrow = torch.arange(16)
+    rows = (32 * (ob >> 1) + 4 * (ob & 1))[:, None] + (8 * (mrow >> 2) + (mrow & 3))[None, :]               # [ob, m]
+    gq, j8 = torch.arange(4), torch.arange(8)
+    unit = torch.where(j8[None, :] < 4, 4 * gq[:, None] + j8[None, :], 16 + 4 * gq[:, None] + j8[None, :] - 4)   # [g, j8]
+    cols = 32 * torch.arange(NH)[:, None, None] + unit[None, :, :]                                         # [hb, g, j8]
+    w2p = w2[rows[None, :, None, :, None], cols[:, None, :, None, :]].reshape(NH, NOB * 1024)              # [hb, ob, g, m, j8]
+    b1p = torch.zeros(NH, 64, dtype=torch.float32)
+    if b1 is not None:
+        b1p[:, :32] = b1.detach().float().cpu().reshape(NH, 32)
     # the kernel's software pipeline multiplies phase B of hidden block j - 1 in iteration j: image block j = [W1(j) | W2(j-1) | b1(j)],
     # j = 0 .. NH with W2(-1) = W1(NH) = b1(NH) = 0, followed by two blocks of padding (prefetched, never used)
     z = lambda t: torch.zeros(1, t.shape[1], dtype=t.dtype)
@@ -519,15 +500,13 @@ def emit_mlp_fused(sess, blk, x1):
     widen = blk.dim != blk.dim_out
     act = E.act_code(mlp.act)
     Cin, H, Cout = mlp.fc1.in_features, mlp.fc1.out_features, mlp.fc2.out_features
-    rows16 = bool(tuning.get("mlp_rows16"))     # 16 token rows per wave, two waves per SIMD (round 6) -- else the 32-row kernel
-    w12 = sess.add_weight(pack_mlp_weights(mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, layout=16 if rows16 else 32))
+    w12 = sess.add_weight(pack_mlp_weights(mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight))
     b2 = mlp.fc2.bias.detach().float() if mlp.fc2.bias is not None else torch.zeros(Cout)
     y = sess.alloc_act(x1.B, 1, 1, x1.voxels, Cout, f32=True)
     y.thw, y.has_cls = x1.thw, x1.has_cls
     M = x1.B * x1.voxels
     f = dict(w12=w12, y=y.ptr, b2=sess.add_weight(b2), M=M, C=Cin, H=H, Cout=Cout, ldy=y.ld, act=act, dtype=L.PV_BF16,
-             residual=None, ln_gamma=None, ln_beta=None, ln_eps=0.0, ldr=0, yn=None, nn_gamma=None, nn_beta=None, ldyn=0, nn_eps=0.0,
-             layout=L.MLP_LAYOUT_ROWS16 if rows16 else L.MLP_LAYOUT_ROWS32)
+             residual=None, ln_gamma=None, ln_beta=None, ln_eps=0.0, ldr=0, yn=None, nn_gamma=None, nn_beta=None, ldyn=0, nn_eps=0.0)
     nxt = blk.__dict__.get("_pv_next_block")
     if _next_norm1_standalone(sess, nxt, y):
         # norm1 of the NEXT block from the rows this kernel still holds in registers (round 4): the next block finds the

@@ -19,7 +19,6 @@ OPTIONS = {
     "fuse_ln_qkv_max_c": 192,    # ... for token widths up to this (wider / shorter tensors: the LDS-DMA GEMM wins)
     "fuse_next_norm": True,      # MViT: norm1 of block i+1 written by block i's fused MLP from the rows it holds (emit_mvit.emit_mlp_fused)
     "fuse_mlp": True,            # MViT norm2 + fc1 + GELU + fc2 + residual as ONE launch (pv_mlp_rows)  (emit_mvit)
-    "mlp_rows16": True,          # ... on 16-row wave tiles, two waves per SIMD (round 6; False: the 32-row, one-wave-per-SIMD kernel)
     "arena_guards": 0,           # debug build of the launch plan: every arena buffer gets its own memory (no re-use) followed
                                  # by this many bytes of canary; Session.check_guards() names the buffers a kernel wrote past
 }

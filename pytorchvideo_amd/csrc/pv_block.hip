@@ -50,7 +50,9 @@ template <int CP, int KSA, int COUT> struct BlkGeom {
   static constexpr int E_BYTES = kHR * kWP * E_STRIDE;
   static constexpr int MID_BYTES = kTH * kWP * MID_STRIDE;
   static constexpr int PAR_BYTES = (2 * CP + 2 * COUT) * 4;     // sa | ha | sc | hc
-  static constexpr int TOTAL = WA_BYTES + 2 * E_BYTES + 2 * MID_BYTES + PAR_BYTES;
+  static constexpr int OUT_STRIDE = COUT * 2 + 8;   // bytes per voxel of the output staging planes (+8: the epilogue's 8-byte stores hit distinct banks)
+  static constexpr int OUT_BYTES = kTH * kWP * OUT_STRIDE;
+  static constexpr int TOTAL = WA_BYTES + 2 * E_BYTES + 2 * MID_BYTES + PAR_BYTES + 2 * OUT_BYTES;
   static_assert(MWAVES == 4 && SWAVES == 4, "four matrix waves + four stencil waves");
   static_assert(MTC * kTH % MWAVES == 0, "conv_c tiles split evenly over the matrix waves");
   static_assert(TOTAL <= 160 * 1024, "LDS");
@@ -65,7 +67,13 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
   return __builtin_bit_cast(unsigned, pk);
 }
 
-template <int CP, int KSA, int COUT, int ACT_B>
+// MODE 0: the whole block.  MODE 1 (blocks WITH squeeze-excitation): stop behind conv_b -- the stencil waves store
+// sb * dw(...) + hb (no activation: it is applied with the gate by conv_c's operand load) as bf16 to y (B, T, H, W, C) and add
+// the fp32 values up for the squeeze: psum[b][2 * tile + row][c] = the sum over this workgroup's T x 1 x W output voxels of
+// channel c (deterministic: one writer per entry); the matrix waves run conv_a only.
+// ABL (development variant of the library, timing only, WRONG results): 1 no stencil FMAs, 2 no conv_a MFMAs, 3 no conv_c, 4 no
+// barriers, 5 no filter-fragment / residual loads, 6 no stencil activation
+template <int CP, int KSA, int COUT, int ACT_B, int MODE, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottleneck_desc d, int tiles_h) {
   using G = BlkGeom<CP, KSA, COUT>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[G::TOTAL];
@@ -76,6 +84,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
   float* const s_ha = s_sa + CP;
   float* const s_sc = s_ha + CP;
   float* const s_hc = s_sc + COUT;
+  unsigned char* const s_out = reinterpret_cast<unsigned char*>(s_hc + COUT);      // two planes of finished output rows
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -91,7 +100,8 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
     u32x4* la = reinterpret_cast<u32x4*>(s_wa);
     for (int i = tid; i < G::WA_BYTES / 16; i += 512) la[i] = wa[i];
     for (int i = tid; i < CP; i += 512) { s_sa[i] = d.sa[i]; s_ha[i] = d.ha[i]; }
-    for (int i = tid; i < COUT; i += 512) { s_sc[i] = d.sc[i]; s_hc[i] = d.hc[i]; }
+    if constexpr (MODE == 0)
+      for (int i = tid; i < COUT; i += 512) { s_sc[i] = d.sc[i]; s_hc[i] = d.hc[i]; }
   }
   __syncthreads();
 
@@ -124,37 +134,43 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
     // conv_c's filter fragments of this wave: the same 21 KB every plane, from L2 (it stays hot: every workgroup reads it)
     const u32x4* wcg = static_cast<const u32x4*>(d.wc) + (long)cmt0 * G::KSC * 64 + lane;
 
-    u32x4 xf[KSA], xn[KSA];
-    u32x2 res[G::TPW];
+    // conv_c's filter fragments of this wave stay in REGISTERS for the whole kernel (84 of them: the matrix waves hold no
+    // stencil state), loaded once from L2
     u32x4 wcf[G::TPW][G::KSC];
+    if constexpr (MODE == 0 && ABL != 3) {
+#pragma unroll
+      for (int j = 0; j < G::TPW; ++j)
+#pragma unroll
+        for (int ks = 0; ks < G::KSC; ++ks) wcf[j][ks] = wcg[(j * G::KSC + ks) * 64];
+    }
+    u32x4 xf[KSA], xn[KSA];
+    u32x2 res[G::TPW], resn[G::TPW];
     auto load_x = [&](u32x4 (&dst)[KSA], int p) {      // (planes past the clip read zeros through the range check: p * plane_b >= the descriptor's size)
 #pragma unroll
       for (int ks = 0; ks < KSA; ++ks)
         dst[ks] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(x_off + (unsigned)p * plane_b + (unsigned)ks * 64u), 0, 0);
     };
-    auto load_res = [&](int t) {
+    auto load_res = [&](u32x2 (&dst)[G::TPW], int t) { // (t < 0: garbage from another plane, never used; t >= T: zeros)
 #pragma unroll
-      for (int i = 0; i < G::TPW; ++i)
-        res[i] = has_res ? __builtin_amdgcn_raw_buffer_load_b64(rr, (int)(r_off + (unsigned)t * rplane_b + (unsigned)i * 32u), 0, 0) : u32x2{0u, 0u};
+      for (int j = 0; j < G::TPW; ++j)
+        dst[j] = (has_res && MODE == 0) ? __builtin_amdgcn_raw_buffer_load_b64(rr, (int)(r_off + (unsigned)(t < 0 ? 0 : t) * rplane_b + (unsigned)j * 32u), 0, 0) : u32x2{0u, 0u};
     };
-    load_x(xf, 0);
-#pragma unroll
-    for (int ks = 0; ks < KSA; ++ks) asm volatile("" : "+v"(xf[ks]));
+    load_x(xn, 0);
+    load_res(resn, -3);
 
-    for (int i = 0; i <= T + 2; ++i) {
+    // The matrix waves only LOAD from global memory (finished rows go through LDS to the stencil waves, which only STORE):
+    // vmcnt counts stores too and hipcc waits conservatively where paths join, so a wave that did both waited for its stores
+    // whenever it needed a load -- measured: the block took 53 us whatever was removed from its arithmetic (ablations,
+    // profiles/r6/bench_block_ablations_call10.txt).  Everything requested in iteration i is consumed in iteration i + 1.
+    for (int i = 0; i <= T + 3; ++i) {
       const int tc = i - 3;                       // output plane of this iteration's conv_c
-      const bool do_c = tc >= 0;                  // (tc <= T - 1 by the loop bound)
-      // Every register load of the iteration is requested HERE and waited for at ONE point behind conv_a (below): the next
-      // plane's operands, conv_c's filter fragments and the residual of output plane tc.  (vmcnt counts stores too and hipcc
-      // is conservative where paths join: a wait for a load placed behind this iteration's stores would wait for the stores.)
+      const bool do_c = MODE == 0 && tc >= 0 && tc < T && ABL != 3;
+#pragma unroll
+      for (int ks = 0; ks < KSA; ++ks) { asm volatile("" : "+v"(xn[ks])); xf[ks] = xn[ks]; }
+#pragma unroll
+      for (int j = 0; j < G::TPW; ++j) { asm volatile("" : "+v"(resn[j])); res[j] = resn[j]; }
       load_x(xn, i + 1);
-      if (do_c) {
-#pragma unroll
-        for (int j = 0; j < G::TPW; ++j)
-#pragma unroll
-          for (int ks = 0; ks < G::KSC; ++ks) wcf[j][ks] = wcg[(j * G::KSC + ks) * 64];
-        load_res(tc);
-      }
+      load_res(resn, tc + 1);
       if (i < T) {
         // ---- [A] conv_a + BN + ReLU of plane i's halo rows -> E[i & 1] ----
         unsigned char* const eb = s_e + (i & 1) * G::E_BYTES + e_dst;
@@ -166,8 +182,12 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
           for (int ks = 0; ks < KSA; ++ks) {
             const bf16x8 af = *reinterpret_cast<const bf16x8*>(s_wa + ((mt * KSA + ks) * 64 + lane) * 16);
             const bf16x8 bf = *reinterpret_cast<const bf16x8*>(s_wa + (((mt + 1) * KSA + ks) * 64 + lane) * 16);
-            ca4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, xf[ks]), ca4, 0, 0, 0);
-            cb4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, __builtin_bit_cast(bf16x8, xf[ks]), cb4, 0, 0, 0);
+            if constexpr (ABL != 2) {
+              ca4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, xf[ks]), ca4, 0, 0, 0);
+              cb4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, __builtin_bit_cast(bf16x8, xf[ks]), cb4, 0, 0, 0);
+            } else {
+              asm volatile("" :: "v"(af), "v"(bf), "v"(xf[ks]));
+            }
           }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -185,17 +205,8 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
           }
         }
       }
-      // the one wait of the iteration: everything requested above has had conv_a's time to land
-#pragma unroll
-      for (int ks = 0; ks < KSA; ++ks) asm volatile("" : "+v"(xn[ks]));
-#pragma unroll
-      for (int j = 0; j < G::TPW; ++j) {
-        asm volatile("" : "+v"(res[j]));
-#pragma unroll
-        for (int ks = 0; ks < G::KSC; ++ks) asm volatile("" : "+v"(wcf[j][ks]));
-      }
       if (do_c) {
-        // ---- [C] conv_c + BN + residual + ReLU of output plane tc from MID[tc & 1] ----
+        // ---- [C] conv_c + BN + residual + ReLU of output plane tc from MID[tc & 1] -> the staging plane s_out[tc & 1] ----
         f32x4 c4[G::TPW];
 #pragma unroll
         for (int j = 0; j < G::TPW; ++j) c4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
           for (int j = 0; j < G::TPW; ++j)
             c4[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wcf[j][ks]), bfr, c4[j], 0, 0, 0);
         }
-        const unsigned tb_y = (unsigned)tc * yplane_b;
+        unsigned char* const ob = s_out + (tc & 1) * G::OUT_BYTES + (cnt * kWP + n16) * G::OUT_STRIDE + (cmt0 * 16 + q * 4) * 2;
 #pragma unroll
         for (int j = 0; j < G::TPW; ++j) {
           const f32x4 s4 = *reinterpret_cast<const f32x4*>(s_sc + (cmt0 + j) * 16 + q * 4);
@@ -221,13 +232,10 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
           }
-          const u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-          __builtin_amdgcn_raw_buffer_store_b64(o, ry, (int)(y_off + tb_y + (unsigned)j * 32u), 0, 0);
+          *reinterpret_cast<u32x2*>(ob + j * 32) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
         }
       }
-#pragma unroll
-      for (int ks = 0; ks < KSA; ++ks) xf[ks] = xn[ks];
-      __syncthreads();
+      if constexpr (ABL != 4) __syncthreads();
     }
   } else {
     // =========================================== STENCIL waves ===========================================
@@ -246,8 +254,45 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int n = 0; n < kNW; ++n) acc[a][n] = float2{0.f, 0.f};
+    // MODE 1: this thread's output row in global memory and its squeeze sums
+    const int soh = h0 + srow;
+    const bool st_ok = MODE == 1 && p_ok && 2 * pair < pv_round_up(d.C, 8) && soh < H;
+    bf16_t* Mp = static_cast<bf16_t*>(d.y) + (long)b * d.y_bs;
+    const unsigned mplane_b = (unsigned)(H * W * d.ldy) * 2u, mvox_b = (unsigned)d.ldy * 2u;
+    __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)Mp, 0, (int)(mplane_b * (unsigned)T), 0x00020000);
+    const unsigned m_off = (unsigned)((soh * W) * d.ldy + 2 * pair) * 2u;
+    float2 ps = {0.f, 0.f};
 
-    for (int i = 0; i <= T + 2; ++i) {
+    // MODE 0: this wave's share of a finished output plane in the staging buffer: 16-byte chunks, (voxel slot, chunk) = item / item % CH
+    constexpr int CH = COUT * 2 / 16;             // 16-byte chunks per voxel
+    constexpr int ITEMS = kTH * kWP * CH, ROUNDS = (ITEMS + 255) / 256;
+    bf16_t* Yo = static_cast<bf16_t*>(d.y) + (long)b * d.y_bs;
+    const unsigned yplane_b = (unsigned)(H * W * d.ldy) * 2u;
+    __amdgpu_buffer_rsrc_t ryo = __builtin_amdgcn_make_buffer_rsrc((void*)Yo, 0, (int)(yplane_b * (unsigned)T), 0x00020000);
+    unsigned o_src[ROUNDS], o_dst[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int item = r * 256 + sw * 64 + lane;
+      const int slot = item / CH, chunk = item - slot * CH;
+      const int orow = slot / kWP, ocol = slot - orow * kWP;
+      const bool ok = MODE == 0 && item < ITEMS && h0 + orow < H && ocol < W;
+      o_src[r] = (unsigned)(slot * G::OUT_STRIDE + chunk * 16);
+      o_dst[r] = ok ? (unsigned)(((h0 + orow) * W + ocol) * d.ldy) * 2u + (unsigned)chunk * 16u : 0x80000000u;
+    }
+
+    for (int i = 0; i <= T + 3; ++i) {
+      if (MODE == 0 && i >= 4 && ABL != 3) {
+        // ---- the rows the matrix waves finished in the last iteration (output plane i - 4): LDS -> global memory, 16 bytes per lane ----
+        const unsigned char* ob = s_out + ((i - 4) & 1) * G::OUT_BYTES;
+        const unsigned tb = (unsigned)(i - 4) * yplane_b;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(ob + o_src[r]);
+          const u32x2 hi = *reinterpret_cast<const u32x2*>(ob + o_src[r] + 8);
+          const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+          __builtin_amdgcn_raw_buffer_store_b128(v, ryo, (int)(o_dst[r] + tb), 0, 0);
+        }
+      }
       const int p = i - 1;                        // input plane of this iteration's stencil
       if (p_ok && p >= 0 && p <= T) {
         if (p < T) {
@@ -270,23 +315,40 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
               const float2 w2 = wt[(2 * 3 + dh) * 3 + dw];   // kt = 2: output p-1
 #pragma unroll
               for (int n = 0; n < kNW; ++n) {
+                // (hipcc packs each pair into v_pk_fma_f32; single v_fmac_f32 by inline asm measured 56.4 against 52.8 us per block)
                 const float2 x2 = xv[n + dw];
-                acc[2][n].x += x2.x * w0.x; acc[2][n].y += x2.y * w0.y;
-                acc[1][n].x += x2.x * w1.x; acc[1][n].y += x2.y * w1.y;
-                acc[0][n].x += x2.x * w2.x; acc[0][n].y += x2.y * w2.y;
+                if constexpr (ABL != 1) {
+                  acc[2][n].x += x2.x * w0.x; acc[2][n].y += x2.y * w0.y;
+                  acc[1][n].x += x2.x * w1.x; acc[1][n].y += x2.y * w1.y;
+                  acc[0][n].x += x2.x * w2.x; acc[0][n].y += x2.y * w2.y;
+                } else {
+                  asm volatile("" :: "v"(x2.x), "v"(x2.y));
+                }
               }
             }
           }
         }
         if (p >= 1) {
-          // ---- output plane p-1 is complete: BN + activation -> bf16 -> MID[(p-1) & 1] ----
-          unsigned char* mbase = s_mid + ((p - 1) & 1) * G::MID_BYTES + (srow * kWP) * G::MID_STRIDE + pair * 4;
+          if constexpr (MODE == 0) {
+            // ---- output plane p-1 is complete: BN + activation -> bf16 -> MID[(p-1) & 1] ----
+            unsigned char* mbase = s_mid + ((p - 1) & 1) * G::MID_BYTES + (srow * kWP) * G::MID_STRIDE + pair * 4;
 #pragma unroll
-          for (int n = 0; n < kNW; ++n) {
-            float v0 = acc[0][n].x * sb2.x + hb2.x, v1 = acc[0][n].y * sb2.y + hb2.y;
-            if (ACT_B == PV_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-            else if (ACT_B == PV_ACT_SWISH) { v0 *= pv_sigmoid(v0); v1 *= pv_sigmoid(v1); }
-            *reinterpret_cast<unsigned*>(mbase + n * G::MID_STRIDE) = pack2(v0, v1);
+            for (int n = 0; n < kNW; ++n) {
+              float v0 = acc[0][n].x * sb2.x + hb2.x, v1 = acc[0][n].y * sb2.y + hb2.y;
+              if (ACT_B == PV_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+              else if (ACT_B == PV_ACT_SWISH && ABL != 6) { v0 *= pv_sigmoid(v0); v1 *= pv_sigmoid(v1); }
+              *reinterpret_cast<unsigned*>(mbase + n * G::MID_STRIDE) = pack2(v0, v1);
+            }
+          } else {
+            // ---- output plane p-1: BN -> bf16 -> global memory (256 contiguous bytes per voxel and wave), fp32 sums for the squeeze ----
+            const unsigned tb = (unsigned)(p - 1) * mplane_b;
+#pragma unroll
+            for (int n = 0; n < kNW; ++n) {
+              const float v0 = acc[0][n].x * sb2.x + hb2.x, v1 = acc[0][n].y * sb2.y + hb2.y;
+              const bool ok = st_ok && n < W;
+              if (ok) { ps.x += v0; ps.y += v1; }
+              __builtin_amdgcn_raw_buffer_store_b32(pack2(v0, v1), rm, (int)((ok ? m_off + (unsigned)n * mvox_b : 0x80000000u) + tb), 0, 0);
+            }
           }
         }
 #pragma unroll
@@ -296,16 +358,28 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
           acc[2][n] = float2{0.f, 0.f};
         }
       }
-      __syncthreads();
+      if constexpr (ABL != 4) __syncthreads();
+    }
+    if (MODE == 1 && d.psum != nullptr && p_ok && 2 * pair < pv_round_up(d.C, 8)) {
+      const int c_p = pv_round_up(d.C, 8);
+      float* dst = d.psum + ((long)b * (tiles_h * kTH) + (blockIdx.x - b * tiles_h) * kTH + srow) * c_p + 2 * pair;
+      *reinterpret_cast<float2*>(dst) = soh < H ? ps : float2{0.f, 0.f};
     }
   }
 }
 
 int check(const pv_bottleneck_desc& d) {
-  if (!d.x || !d.y || !d.wa || !d.wb || !d.wc || !d.sa || !d.ha || !d.sb || !d.hb || !d.sc || !d.hc) return PV_ERR_INVALID;
+  if (!d.x || !d.y || !d.wa || !d.wb || !d.sa || !d.ha || !d.sb || !d.hb) return PV_ERR_INVALID;
+  if (d.mode != PV_BLOCK_FULL && d.mode != PV_BLOCK_AB) return PV_ERR_INVALID;
   if (d.B <= 0 || d.T <= 0 || d.H <= 0 || d.W <= 0 || d.cin <= 0 || d.C <= 0 || d.cout <= 0) return PV_ERR_INVALID;
-  if (d.ldx < pv_round_up(d.cin, 8) || d.ldx % 8 || d.ldy < pv_round_up(d.cout, 8) || d.ldy % 4) return PV_ERR_INVALID;
-  if (d.residual && (d.ldr < pv_round_up(d.cout, 8) || d.ldr % 4)) return PV_ERR_INVALID;
+  if (d.ldx < pv_round_up(d.cin, 8) || d.ldx % 8) return PV_ERR_INVALID;
+  if (d.mode == PV_BLOCK_FULL) {
+    if (!d.wc || !d.sc || !d.hc) return PV_ERR_INVALID;
+    if (d.ldy < pv_round_up(d.cout, 8) || d.ldy % 4) return PV_ERR_INVALID;
+    if (d.residual && (d.ldr < pv_round_up(d.cout, 8) || d.ldr % 4)) return PV_ERR_INVALID;
+  } else if (d.ldy < pv_round_up(d.C, 8) || d.ldy % 2) {
+    return PV_ERR_INVALID;
+  }
   return PV_OK;
 }
 
@@ -318,13 +392,22 @@ extern "C" int pv_bottleneck_supported(const pv_bottleneck_desc* dp) {
   if (d.dtype != PV_BF16) return 0;
   if (d.B <= 0 || d.T <= 0 || d.H <= 0 || d.W <= 0 || d.W > kNW) return 0;
   if (d.act_a != PV_ACT_RELU && d.act_a != PV_ACT_NONE) return 0;
-  if (d.act_b != PV_ACT_SWISH && d.act_b != PV_ACT_RELU && d.act_b != PV_ACT_NONE) return 0;
-  if (d.act_out != PV_ACT_RELU && d.act_out != PV_ACT_NONE) return 0;
+  if (d.mode != PV_BLOCK_FULL && d.mode != PV_BLOCK_AB) return 0;
+  if (d.mode == PV_BLOCK_FULL) {
+    if (d.act_b != PV_ACT_SWISH && d.act_b != PV_ACT_RELU && d.act_b != PV_ACT_NONE) return 0;
+    if (d.act_out != PV_ACT_RELU && d.act_out != PV_ACT_NONE) return 0;
+  }
   // 31-bit byte offsets inside a clip
   if ((long)d.T * d.H * d.W * (d.ldx > d.ldy ? d.ldx : d.ldy) * 2 > 0x7fffffffL) return 0;
   if ((long)d.B * pv_ceil_div(d.H, kTH) > 0x7fffffffL) return 0;
   // instantiated: X3D res4 (96 -> 216 -> 96)
-  return pv_round_up(d.C, 32) == 224 && pv_round_up(d.cin, 32) == 96 && d.cout == 96 && d.ldx >= 96;
+  if (pv_round_up(d.C, 32) != 224 || pv_round_up(d.cin, 32) != 96 || d.ldx < 96) return 0;
+  return d.mode == PV_BLOCK_AB || d.cout == 96;
+}
+
+// squeeze partial-sum blocks per clip of mode PV_BLOCK_AB (psum is [B][blocks][round_up(C, 8)] fp32)
+extern "C" int pv_bottleneck_psum_blocks(const pv_bottleneck_desc* d) {
+  return d ? (int)pv_ceil_div(d->H, kTH) * kTH : 0;
 }
 
 extern "C" int pv_bottleneck(const pv_bottleneck_desc* dp, pv_stream_t stream) {
@@ -336,9 +419,24 @@ extern "C" int pv_bottleneck(const pv_bottleneck_desc* dp, pv_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_h = (int)pv_ceil_div(d.H, kTH);
   const dim3 grid((unsigned)(d.B * tiles_h)), block(512);
-  if (d.act_b == PV_ACT_SWISH) PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, PV_ACT_SWISH>), grid, block, 0, s, d, tiles_h);
-  else if (d.act_b == PV_ACT_RELU) PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, PV_ACT_RELU>), grid, block, 0, s, d, tiles_h);
-  else PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, PV_ACT_NONE>), grid, block, 0, s, d, tiles_h);
+#ifdef PV_DEV_ABLATION   // timing builds with WRONG results: development variant of the library only (tools/r6/bench_block.py)
+  if (const int abl = pv_tune("block_abl", 0); abl && d.mode == PV_BLOCK_FULL && d.act_b == PV_ACT_SWISH) {
+    switch (abl) {
+      case 1: PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, PV_ACT_SWISH, 0, 1>), grid, block, 0, s, d, tiles_h); break;
+      case 2: PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, PV_ACT_SWISH, 0, 2>), grid, block, 0, s, d, tiles_h); break;
+      case 3: PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, PV_ACT_SWISH, 0, 3>), grid, block, 0, s, d, tiles_h); break;
+      case 4: PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, PV_ACT_SWISH, 0, 4>), grid, block, 0, s, d, tiles_h); break;
+      case 5: PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, PV_ACT_SWISH, 0, 5>), grid, block, 0, s, d, tiles_h); break;
+      default: PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, PV_ACT_SWISH, 0, 6>), grid, block, 0, s, d, tiles_h); break;
+    }
+    PV_LAUNCH_CHECK();
+    return PV_OK;
+  }
+#endif
+  if (d.mode == PV_BLOCK_AB) PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, PV_ACT_NONE, 1>), grid, block, 0, s, d, tiles_h);
+  else if (d.act_b == PV_ACT_SWISH) PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, PV_ACT_SWISH, 0>), grid, block, 0, s, d, tiles_h);
+  else if (d.act_b == PV_ACT_RELU) PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, PV_ACT_RELU, 0>), grid, block, 0, s, d, tiles_h);
+  else PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, PV_ACT_NONE, 0>), grid, block, 0, s, d, tiles_h);
   PV_LAUNCH_CHECK();
   return PV_OK;
 }

@@ -1144,8 +1144,7 @@ def test_narrow_dense_conv_on_the_tap_streaming_kernel(B, T, H, W, cin, cout, k,
     (130, 384, 1536, 384, False, False),    # bf16 operand, no residual
     (129, 384, 64, 384, True, False),       # two hidden blocks only
 ])
-@pytest.mark.parametrize("layout", [16, 32])    # 16: sixteen token rows per wave, two waves per SIMD (round 6); 32: the round-3 kernel
-def test_fused_mlp_rows(M, Cin, H, Cout, ln, res, layout):
+def test_fused_mlp_rows(M, Cin, H, Cout, ln, res):
     """pv_mlp_rows: norm2 -> fc1 -> GELU -> fc2 -> + residual (layers/attention.py:102-114,750-757) in one launch
     against fp32 torch on the same bf16-rounded weights (ragged row counts: the last 128-row tile is partial)."""
     from pytorchvideo_amd.accelerator.mi355x.emit_mvit import pack_mlp_weights
@@ -1164,18 +1163,17 @@ def test_fused_mlp_rows(M, Cin, H, Cout, ln, res, layout):
         xb = x32.bfloat16()
         want = b2 + F.linear(F.gelu(F.linear(xb.float(), w1, b1)), w2) + (r32 if res else 0.0)
         x_dev = xb.cuda()
-    img = pack_mlp_weights(w1, b1, w2, layout=layout).cuda()
+    img = pack_mlp_weights(w1, b1, w2).cuda()
     y = torch.full((M, Cout), 7.0, dtype=torch.float32, device="cuda")
     b2d, gd, bd, rd = b2.cuda(), gamma.cuda(), beta.cuda(), r32.cuda()
     d = L.MlpDesc()
-    d.layout = L.MLP_LAYOUT_ROWS16 if layout == 16 else L.MLP_LAYOUT_ROWS32
     d.x, d.w12, d.y, d.b2 = x_dev.data_ptr(), img.data_ptr(), y.data_ptr(), b2d.data_ptr()
     d.residual = rd.data_ptr() if (res and not ln) else None
     d.ln_gamma, d.ln_beta, d.ln_eps = (gd.data_ptr(), bd.data_ptr(), 1e-6) if ln else (None, None, 0.0)
     d.M, d.C, d.H, d.Cout, d.ldx, d.ldr, d.ldy, d.act, d.dtype = M, Cin, H, Cout, Cin, Cout, Cout, L.ACT_GELU, L.PV_BF16
     assert L.lib().pv_mlp_rows_supported(C.byref(d)) == 1
     call("pv_mlp_rows", d)
-    assert _routed_kernel(L.OP_MLP_ROWS, d) == ("mlp_rows16_kernel" if layout == 16 else "mlp_rows_kernel")
+    assert _routed_kernel(L.OP_MLP_ROWS, d) == "mlp_rows16_kernel"
     assert rel_err(y, want) <= 1e-2
     y2 = torch.zeros_like(y)
     d.y = y2.data_ptr()
@@ -1263,6 +1261,62 @@ def test_fused_bottleneck_block(B, T, H, W, act_b):
     assert torch.equal(y2[..., :cout], got)             # no atomics: bit-reproducible
     d.W = 15                                            # wider than the stencil row: declined, not mis-computed
     assert L.lib().pv_bottleneck_supported(C.byref(d)) == 0 and L.lib().pv_bottleneck(C.byref(d), None) < 0
+
+
+@pytest.mark.parametrize("B,T,H,W", [(2, 5, 14, 14), (1, 3, 7, 9), (2, 2, 13, 14)])
+def test_fused_bottleneck_conv_ab_with_squeeze_sums(B, T, H, W):
+    """pv_bottleneck in mode PV_BLOCK_AB (blocks with squeeze-excitation, models/x3d.py:169-207): conv_a + BN + ReLU -> depthwise
+    3x3x3 + BN as bf16, and the per-block fp32 sums of the (unrounded) result whose total is the squeeze -- against fp32 torch."""
+    import torch.nn as nn
+    from pytorchvideo_amd.accelerator.mi355x.emit import pack_bottleneck_operands
+    cin, Cc = 96, 216
+    g = torch.Generator().manual_seed(10 * H + W)
+    ca, cb = nn.Conv3d(cin, Cc, 1, bias=False), nn.Conv3d(Cc, Cc, 3, padding=1, groups=Cc, bias=False)
+    with torch.no_grad():
+        ca.weight.copy_((torch.randn(Cc, cin, 1, 1, 1, generator=g) * cin ** -0.5).bfloat16().float())
+        cb.weight.copy_(torch.randn(Cc, 1, 3, 3, 3, generator=g) * 27 ** -0.5)
+
+    def bn(c):
+        m = nn.BatchNorm3d(c).eval()
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(c, generator=g) + 0.5)
+            m.bias.copy_(torch.randn(c, generator=g) * 0.3)
+            m.running_mean.copy_(torch.randn(c, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+        return m
+
+    na, nb = bn(Cc), bn(Cc)
+    x = torch.randn(B, T, H, W, cin, generator=g).bfloat16()
+    xc = x.float().permute(0, 4, 1, 2, 3)
+    with torch.no_grad():
+        want = nb(cb(F.relu(na(ca(xc))).bfloat16().float())).permute(0, 2, 3, 4, 1)       # the expanded tensor rounded where the kernel rounds it
+    ops = {k: v.cuda() for k, v in pack_bottleneck_operands(ca, na, cb, nb, None, None).items()}
+    xd = x.cuda()
+    ldy = Cc + 8
+    y = torch.full((B, T, H, W, ldy), 5.0, dtype=torch.bfloat16, device="cuda")
+    d = L.BottleneckDesc()
+    d.x, d.y, d.mode = xd.data_ptr(), y.data_ptr(), L.BLOCK_AB
+    for k, v in ops.items():
+        setattr(d, k, v.data_ptr())
+    d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * cin, T * H * W * ldy, cin, ldy
+    d.B, d.T, d.H, d.W, d.cin, d.C, d.cout = B, T, H, W, cin, Cc, 96
+    d.act_a, d.dtype = L.ACT_RELU, L.PV_BF16
+    assert L.lib().pv_bottleneck_supported(C.byref(d)) == 1
+    nblk = L.lib().pv_bottleneck_psum_blocks(C.byref(d))
+    assert nblk == (H + 1) // 2 * 2
+    psum = torch.full((B, nblk, Cc), 7.0, device="cuda")
+    d.psum = psum.data_ptr()
+    call("pv_bottleneck", d)
+    got = y[..., :Cc]
+    assert rel_err(got, want) <= 6e-3                                    # one bf16 rounding + fp32 summation order
+    assert torch.all(y[..., Cc:] == 5.0)
+    sums = want.sum(dim=(1, 2, 3))                                         # [B, C]
+    assert rel_err(psum.sum(dim=1), sums) <= 1e-4                          # fp32 sums of the unrounded values
+    # per block: block 2 * tile + row holds output row 2 * tile + row of every frame
+    per_row = want.sum(dim=(1, 3))                                         # [B, H, C]
+    assert rel_err(psum[:, :H], per_row) <= 1e-4
+    if nblk > H:
+        assert torch.all(psum[:, H:] == 0)
 
 
 @pytest.mark.parametrize("M,Cin,N", [(300, 96, 288), (1001, 192, 576), (6274, 384, 1152), (129, 384, 96), (785 * 2, 768, 2304),

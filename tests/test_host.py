@@ -61,7 +61,11 @@ def test_plan_build_without_gpu_counts_ops():
     labels = [o[3].split("|")[0] for o in sess.ops]
     # conv_a is evaluated inside conv_b's kernel (fused pointwise producer) while the block input is narrow
     fused = labels.count("conv_ab") + labels.count("conv_ab.dw+se")
-    assert fused == 9 and labels.count("conv_a") == 26 - fused and labels.count("conv_c") == 26
+    # round 6: res4's stride-1 blocks (10 x 10 maps here, 14 x 14 at 224^2) run on csrc/pv_block.hip -- the five without
+    # squeeze-excitation as ONE launch each, the five with it as conv_a + conv_b + squeeze sums in one launch
+    whole, ab_se = labels.count("block.fused"), labels.count("conv_ab.fused+se")
+    assert (whole, ab_se) == (5, 5)
+    assert fused == 9 and labels.count("conv_a") == 26 - fused - whole - ab_se and labels.count("conv_c") == 26 - whole
     assert labels.count("se_gate") == 15  # SE in every other block: 2+3+6+4
     assert (cur.B, cur.C, cur.f32) == (2, 400, True)
     with pytest.raises(AssertionError):
@@ -283,47 +287,9 @@ def test_slowfast_with_a_declined_head_converts_block_by_block():
     assert [r.B for r in m.blocks[0]._in_ref] == [3, 3] and len(sess.ops) > 30
 
 
-def test_fused_mlp_weight_image_follows_the_documented_layout():
-    """pack_mlp_weights builds exactly the LDS image include/pv_mi355x.h documents for pv_mlp_rows: block j carries W1 / b1 of
-    hidden block j and W2 of hidden block j - 1 (software pipeline), zeros at both ends, two blocks of padding."""
-    import torch
-    from pytorchvideo_amd.accelerator.mi355x.emit_mvit import _chi, pack_mlp_weights
-    torch.manual_seed(0)
-    H, Cin, Cout = 96, 64, 96
-    w1, b1, w2 = torch.randn(H, Cin), torch.randn(H), torch.randn(Cout, H)
-    img = pack_mlp_weights(w1, b1, w2)
-    KS, NOB, NH = Cin // 16, Cout // 32, H // 32
-    stage = KS * 1024 + NOB * 2048 + 256
-    assert img.dtype == torch.uint8 and img.numel() == (NH + 3) * stage and not img[(NH + 1) * stage:].any()
-    bf = lambda t: t.to(torch.bfloat16)
-    for j in range(NH + 1):
-        blk = img[j * stage:(j + 1) * stage]
-        a = blk[:KS * 1024].view(torch.int16).view(torch.bfloat16).reshape(KS, 2, 32, 8)
-        b = blk[KS * 1024:KS * 1024 + NOB * 2048].view(torch.int16).view(torch.bfloat16).reshape(NOB, 2, 2, 32, 8)
-        c = blk[KS * 1024 + NOB * 2048:].view(torch.float32)
-        if j == NH:
-            assert not a.float().any() and not c.any()
-        if j == 0:
-            assert not b.float().any()
-        for hi in range(2):
-            for rho in (0, 5, 18, 31):
-                for j8 in range(8):
-                    for ks in range(KS):
-                        if j < NH:
-                            assert a[ks, hi, rho, j8] == bf(w1[32 * j + rho, 32 * (ks >> 1) + 16 * hi + 8 * (ks & 1) + j8])
-                    for ob in range(NOB):
-                        for i in range(2):
-                            if j >= 1:
-                                assert b[ob, i, hi, rho, j8] == bf(w2[32 * ob + _chi(rho), 32 * (j - 1) + (j8 & 3) + 8 * (2 * i + (j8 >> 2)) + 4 * hi])
-            for r in range(16):
-                if j < NH:
-                    assert c[hi * 16 + r] == b1[32 * j + (r & 3) + 8 * (r >> 2) + 4 * hi]
-        assert not c[32:].any()
-
-
 def test_fused_mlp_rows16_weight_image_replayed_with_the_mfma_lane_roles():
-    """Round 6: the image of the 16-rows-per-wave kernel (pack_mlp_weights(layout=16), include/pv_mi355x.h PV_MLP_LAYOUT_ROWS16)
-    replayed on the host with exactly the roles csrc/pv_mlp.hip::mlp_rows16_kernel gives the lanes of v_mfma_f32_16x16x32_bf16
+    """The LDS image pv_mlp_rows streams (pack_mlp_weights, include/pv_mi355x.h pv_mlp_desc: block j carries W1 / b1 of hidden
+    block j and W2 of hidden block j - 1, zeros at both ends, two blocks of padding) replayed on the host with exactly the roles csrc/pv_mlp.hip::mlp_rows16_kernel gives the lanes of v_mfma_f32_16x16x32_bf16
     (A[m = l&15][k = 8 (l>>4) + j], B[k][n = l&15], D[m = 4 (l>>4) + r][n]): phase A per 16-unit half, the activation's
     registers as the phase-B operand through the permuted K order, phase B one block behind, output channel of (ob, m) --
     equal to fc2(act(fc1(x))) on the same bf16-rounded weights."""
@@ -332,11 +298,10 @@ def test_fused_mlp_rows16_weight_image_replayed_with_the_mfma_lane_roles():
     torch.manual_seed(0)
     H, Cin, Cout, R = 96, 64, 96, 16
     w1, b1, w2 = torch.randn(H, Cin) * 0.2, torch.randn(H), torch.randn(Cout, H) * 0.2
-    img = pack_mlp_weights(w1, b1, w2, layout=16)
+    img = pack_mlp_weights(w1, b1, w2)
     KS2, NOB16, NH = Cin // 32, Cout // 16, H // 32
     stage = 2 * KS2 * 1024 + NOB16 * 1024 + 256
     assert img.numel() == (NH + 3) * stage and not img[(NH + 1) * stage:].any()
-    assert img.numel() == pack_mlp_weights(w1, b1, w2).numel()            # same block structure and size as the 32-row image
     x = torch.randn(R, Cin).bfloat16().float()
     act = torch.relu
     Y = torch.zeros(NOB16, 16, R)                     # [ob][m][n]

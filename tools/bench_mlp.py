@@ -44,37 +44,25 @@ def main():
     for M, Cin, H, Cout in ((25096, 384, 1536, 384), (100360, 192, 768, 192), (401416, 96, 384, 192)):
         ln = Cin == Cout
         w1, w2 = torch.randn(H, Cin, generator=g) * Cin ** -0.5, torch.randn(Cout, H, generator=g) * H ** -0.5
-        b1 = torch.randn(H, generator=g)
-        imgs = {32: pack_mlp_weights(w1, b1, w2).cuda(), 16: pack_mlp_weights(w1, b1, w2, layout=16).cuda()}
+        img = pack_mlp_weights(w1, torch.randn(H, generator=g), w2).cuda()
         x = torch.randn(M, Cin, generator=g).cuda()
         xb = x.bfloat16()
         y = torch.empty(M, Cout, device="cuda")
         r = torch.randn(M, Cout, generator=g).cuda()
         b2, gam, bet = torch.zeros(Cout, device="cuda"), torch.ones(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
         d = L.MlpDesc()
-        d.x, d.w12, d.y, d.b2 = (x if ln else xb).data_ptr(), imgs[32].data_ptr(), y.data_ptr(), b2.data_ptr()
+        d.x, d.w12, d.y, d.b2 = (x if ln else xb).data_ptr(), img.data_ptr(), y.data_ptr(), b2.data_ptr()
         d.residual = None if ln else r.data_ptr()
         d.ln_gamma, d.ln_beta, d.ln_eps = (gam.data_ptr(), bet.data_ptr(), 1e-6) if ln else (None, None, 0.0)
         d.M, d.C, d.H, d.Cout, d.ldx, d.ldr, d.ldy, d.act, d.dtype = M, Cin, H, Cout, Cin, Cout, Cout, L.ACT_GELU, L.PV_BF16
         flops = 2.0 * M * H * (Cin + Cout)
-        for abl in ((0, 7, 8, 1, 2, 3, 4, 5, 6) if (Cin, Cout) == (384, 384) else (0,)):
+        # ablations (development variant of the library only; timing builds with WRONG results): 1 no activation, 2 no weight
+        # streaming, 3 no phase B, 4 no phase A, 5 no barrier, 6 no LDS fragment reads, 7 no MFMA at all
+        for abl in ((0, 1, 2, 3, 4, 5, 6, 7, 0) if (Cin, Cout) == (384, 384) else (0, 0, 0)):
             L.tune(mlp_abl=abl)
             us = timed(lambda: L.check(lib.pv_mlp_rows(C.byref(d), st)), a.iters)
             print("mlp_rows M=%d %d->%d->%d ln=%d abl=%d: %8.1f us  %7.1f TF/s" % (M, Cin, H, Cout, ln, abl, us, flops / us / 1e6), flush=True)
         L.tune(mlp_abl=0)
-        # round 6: sixteen token rows per wave, two waves per SIMD (interleaved with the 32-row kernel: same process, same box)
-        if (Cin, Cout) == (384, 384):       # ablations of the 16-row kernel (development variant of the library only)
-            d.w12, d.layout = imgs[16].data_ptr(), L.MLP_LAYOUT_ROWS16
-            for abl in (0, 1, 2, 3, 4, 5, 6, 7):
-                L.tune(mlp_abl=abl)
-                us = timed(lambda: L.check(lib.pv_mlp_rows(C.byref(d), st)), a.iters)
-                print("mlp_rows16 M=%d %d->%d->%d abl=%d: %8.1f us  %7.1f TF/s" % (M, Cin, H, Cout, abl, us, flops / us / 1e6), flush=True)
-            L.tune(mlp_abl=0)
-        for rep in range(3):
-            for layout in (32, 16):
-                d.w12, d.layout = imgs[layout].data_ptr(), (L.MLP_LAYOUT_ROWS16 if layout == 16 else L.MLP_LAYOUT_ROWS32)
-                us = timed(lambda: L.check(lib.pv_mlp_rows(C.byref(d), st)), a.iters)
-                print("mlp_rows M=%d %d->%d->%d ln=%d rows/wave=%d: %8.1f us  %7.1f TF/s" % (M, Cin, H, Cout, ln, layout, us, flops / us / 1e6), flush=True)
     for M, Cin, N in ((25096, 384, 1152), (401416, 192, 576), (401416, 96, 288), (6280, 768, 2304)):
         w = torch.randn(N, Cin, generator=g) * Cin ** -0.5
         img = pack_ln_linear_weights(w, torch.randn(N, generator=g)).cuda()
