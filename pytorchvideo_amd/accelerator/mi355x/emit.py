@@ -612,7 +612,7 @@ def pack_bottleneck_operands(conv_a, norm_a, conv_b, bn_b, conv_c, norm_c):
         return wp.reshape(rows_p // 16, 16, cols_p // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().to(torch.bfloat16).reshape(-1)
 
     wa = frag_image(conv_a.weight.detach().float().cpu().reshape(Cc, cin), Cp, cin_p)
-    wc = frag_image(conv_c.weight.detach().float().cpu().reshape(cout, Cc), cout, Cp) if conv_c is not None else None
+    wc = frag_image(conv_c.weight.detach().float().cpu().reshape(cout, Cc), (cout + 15) // 16 * 16, Cp) if conv_c is not None else None
     wb = torch.zeros(27, Cp, dtype=torch.float32)
     wb[:, :Cc] = conv_b.weight.detach().float().cpu().reshape(Cc, 27).t()
 
@@ -700,8 +700,10 @@ def emit_fused_conv_ab_se(sess, bb, x):
     for k in ("wa", "wb", "sa", "ha", "sb", "hb"):
         f[k] = sess.add_weight(ops[k])
     d = L.BottleneckDesc()
-    d.H = x.H
+    d.H, d.W, d.cin, d.C, d.cout, d.ldx, d.mode, d.dtype = x.H, x.W, cin, Cc, bb.conv_c.out_channels, x.ld, L.BLOCK_AB, sess.pv_dtype
     nblk = L.lib().pv_bottleneck_psum_blocks(C.byref(d))
+    if nblk <= 0:
+        raise Unsupported("bottleneck geometry")
     psum = sess.alloc_raw(4 * x.B * nblk * pad8(Cc))
     f["psum"] = psum
     vox = x.B * x.T * x.H * x.W

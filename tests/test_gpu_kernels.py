@@ -1200,19 +1200,24 @@ def test_fused_mlp_rows(M, Cin, H, Cout, ln, res):
     assert L.lib().pv_mlp_rows_supported(C.byref(d)) == 0
 
 
-@pytest.mark.parametrize("B,T,H,W,act_b", [
-    (2, 5, 14, 14, L.ACT_SWISH),     # X3D res4: 14 x 14 maps, seven 2-row tiles per clip
-    (1, 3, 7, 9, L.ACT_SWISH),       # odd height (the last tile holds one row), narrower than the 14-output stencil row
-    (3, 1, 2, 14, L.ACT_RELU),       # a single frame: both temporal neighbours are padding
-    (1, 16, 13, 5, L.ACT_NONE),
+@pytest.mark.parametrize("chans,B,T,H,W,act_b", [
+    ((96, 216, 96), 2, 5, 14, 14, L.ACT_SWISH),     # X3D res4: 14 x 14 maps, seven 2-row tiles per clip
+    ((96, 216, 96), 1, 3, 7, 9, L.ACT_SWISH),       # odd height (the last tile holds one row), narrower than a 14-column tile
+    ((96, 216, 96), 3, 1, 2, 14, L.ACT_RELU),       # a single frame: both temporal neighbours are padding
+    ((96, 216, 96), 1, 16, 13, 5, L.ACT_NONE),
+    ((96, 216, 96), 1, 2, 5, 31, L.ACT_SWISH),      # three column tiles, the last one ragged (halo columns from the neighbours)
+    ((48, 108, 48), 1, 4, 28, 28, L.ACT_SWISH),     # X3D res3: two column tiles, two 7-output row segments per stencil row
+    ((48, 108, 48), 2, 3, 9, 17, L.ACT_RELU),
+    ((24, 54, 24), 1, 3, 56, 56, L.ACT_SWISH),      # X3D res2: one channel per stencil lane, 24 output channels in a 32-channel tile
+    ((24, 54, 24), 2, 2, 5, 30, L.ACT_NONE),
 ])
-def test_fused_bottleneck_block(B, T, H, W, act_b):
+def test_fused_bottleneck_block(chans, B, T, H, W, act_b):
     """pv_bottleneck (round 6, csrc/pv_block.hip): conv_a + BN + ReLU -> depthwise 3x3x3 + BN + Swish -> conv_c + BN -> + x -> ReLU
     of an X3D res4 block (models/x3d.py:169-212, models/resnet.py:1345-1365, :1179-1189) in one launch, against fp32 torch on
     the same bf16-rounded operands -- plainly, and with the two intermediate tensors rounded to bf16 where the kernel rounds them."""
     import torch.nn as nn
     from pytorchvideo_amd.accelerator.mi355x.emit import pack_bottleneck_operands
-    cin, Cc, cout = 96, 216, 96
+    cin, Cc, cout = chans
     g = torch.Generator().manual_seed(100 * H + W)
     ca, cb, cc = nn.Conv3d(cin, Cc, 1, bias=False), nn.Conv3d(Cc, Cc, 3, padding=1, groups=Cc, bias=False), nn.Conv3d(Cc, cout, 1, bias=False)
     with torch.no_grad():
@@ -1259,17 +1264,19 @@ def test_fused_bottleneck_block(B, T, H, W, act_b):
     d.y = y2.data_ptr()
     call("pv_bottleneck", d)
     assert torch.equal(y2[..., :cout], got)             # no atomics: bit-reproducible
-    d.W = 15                                            # wider than the stencil row: declined, not mis-computed
+    d.C = 300                                           # a width the kernel is not instantiated for: declined, not mis-computed
     assert L.lib().pv_bottleneck_supported(C.byref(d)) == 0 and L.lib().pv_bottleneck(C.byref(d), None) < 0
 
 
-@pytest.mark.parametrize("B,T,H,W", [(2, 5, 14, 14), (1, 3, 7, 9), (2, 2, 13, 14)])
-def test_fused_bottleneck_conv_ab_with_squeeze_sums(B, T, H, W):
+@pytest.mark.parametrize("chans,B,T,H,W", [((96, 216), 2, 5, 14, 14), ((96, 216), 1, 3, 7, 9), ((96, 216), 2, 2, 13, 14),
+                                           ((96, 216), 1, 2, 4, 20), ((48, 108), 1, 3, 28, 28), ((48, 108), 2, 2, 5, 9),
+                                           ((24, 54), 1, 2, 56, 56), ((24, 54), 1, 3, 11, 33)])
+def test_fused_bottleneck_conv_ab_with_squeeze_sums(chans, B, T, H, W):
     """pv_bottleneck in mode PV_BLOCK_AB (blocks with squeeze-excitation, models/x3d.py:169-207): conv_a + BN + ReLU -> depthwise
     3x3x3 + BN as bf16, and the per-block fp32 sums of the (unrounded) result whose total is the squeeze -- against fp32 torch."""
     import torch.nn as nn
     from pytorchvideo_amd.accelerator.mi355x.emit import pack_bottleneck_operands
-    cin, Cc = 96, 216
+    cin, Cc = chans
     g = torch.Generator().manual_seed(10 * H + W)
     ca, cb = nn.Conv3d(cin, Cc, 1, bias=False), nn.Conv3d(Cc, Cc, 3, padding=1, groups=Cc, bias=False)
     with torch.no_grad():
@@ -1299,24 +1306,36 @@ def test_fused_bottleneck_conv_ab_with_squeeze_sums(B, T, H, W):
     for k, v in ops.items():
         setattr(d, k, v.data_ptr())
     d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * cin, T * H * W * ldy, cin, ldy
-    d.B, d.T, d.H, d.W, d.cin, d.C, d.cout = B, T, H, W, cin, Cc, 96
+    d.B, d.T, d.H, d.W, d.cin, d.C, d.cout = B, T, H, W, cin, Cc, cin
     d.act_a, d.dtype = L.ACT_RELU, L.PV_BF16
-    assert L.lib().pv_bottleneck_supported(C.byref(d)) == 1
-    nblk = L.lib().pv_bottleneck_psum_blocks(C.byref(d))
-    assert nblk == (H + 1) // 2 * 2
-    psum = torch.full((B, nblk, Cc), 7.0, device="cuda")
-    d.psum = psum.data_ptr()
-    call("pv_bottleneck", d)
+    # by default this mode is routed for res4 only (on larger maps the plane-streaming kernel with the fused pointwise producer is
+    # faster); the res2 / res3 instantiations exist and are tested under the knob
+    assert L.lib().pv_bottleneck_supported(C.byref(d)) == (1 if Cc == 216 else 0)
+    L.tune(block_stages_ab=0x1c)
+    try:
+        assert L.lib().pv_bottleneck_supported(C.byref(d)) == 1
+        nblk = L.lib().pv_bottleneck_psum_blocks(C.byref(d))
+        segs = 1 if Cc == 216 else 2
+        assert nblk == (H + 1) // 2 * 2 * ((W + 13) // 14) * segs
+        cp8 = (Cc + 7) // 8 * 8
+        psum_p = torch.full((B, nblk, cp8), 7.0, device="cuda")               # [B][blocks][round_up(C, 8)]
+        d.psum = psum_p.data_ptr()
+        call("pv_bottleneck", d)
+    finally:
+        L.tune(block_stages_ab=0x10)
     got = y[..., :Cc]
     assert rel_err(got, want) <= 6e-3                                    # one bf16 rounding + fp32 summation order
-    assert torch.all(y[..., Cc:] == 5.0)
+    assert torch.all(y[..., Cc:cp8] == 0) and torch.all(y[..., cp8:] == 5.0)      # padding channels of the 8-channel chunk are zeros, nothing beyond
+    assert torch.all(psum_p[..., Cc:] == 0)
+    psum = psum_p[..., :Cc]
     sums = want.sum(dim=(1, 2, 3))                                         # [B, C]
     assert rel_err(psum.sum(dim=1), sums) <= 1e-4                          # fp32 sums of the unrounded values
-    # per block: block 2 * tile + row holds output row 2 * tile + row of every frame
-    per_row = want.sum(dim=(1, 3))                                         # [B, H, C]
-    assert rel_err(psum[:, :H], per_row) <= 1e-4
-    if nblk > H:
-        assert torch.all(psum[:, H:] == 0)
+    # per block: with one column tile and one segment, block 2 * tile + row holds output row 2 * tile + row of every frame
+    if nblk == (H + 1) // 2 * 2:
+        per_row = want.sum(dim=(1, 3))                                     # [B, H, C]
+        assert rel_err(psum[:, :H], per_row) <= 1e-4
+        if nblk > H:
+            assert torch.all(psum[:, H:] == 0)
 
 
 @pytest.mark.parametrize("M,Cin,N", [(300, 96, 288), (1001, 192, 576), (6274, 384, 1152), (129, 384, 96), (785 * 2, 768, 2304),
