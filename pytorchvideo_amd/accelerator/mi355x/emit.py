@@ -661,7 +661,7 @@ def _bottleneck_geometry_ok(sess, bb, x, want_se):
     return acts
 
 
-def can_fuse_bottleneck(sess, bb, x, residual):
+def can_fuse_bottleneck(sess, bb, x, residual, final_act=L.ACT_RELU):
     """A whole residual block without squeeze-excitation as ONE pv_bottleneck launch (csrc/pv_block.hip)?  Identity shortcut;
     the library decides the geometry."""
     if residual is not x:
@@ -672,7 +672,7 @@ def can_fuse_bottleneck(sess, bb, x, residual):
     d = L.BottleneckDesc()
     d.B, d.T, d.H, d.W, d.cin, d.C, d.cout = x.B, x.T, x.H, x.W, x.C, bb.conv_a.out_channels, bb.conv_c.out_channels
     d.ldx, d.ldy, d.ldr, d.dtype, d.mode = x.ld, pad8(bb.conv_c.out_channels), x.ld, sess.pv_dtype, L.BLOCK_FULL
-    d.act_a, d.act_b, d.act_out = acts[0], acts[1], L.ACT_RELU
+    d.act_a, d.act_b, d.act_out = acts[0], acts[1], final_act
     return L.lib().pv_bottleneck_supported(C.byref(d)) == 1
 
 
@@ -745,7 +745,7 @@ def emit_res_block(sess, rb, x, out=None):
         # the projection shortcut rides in conv_c as a second K operand: no launch, no round trip of its output
         return emit_bottleneck(sess, bb, x, residual=None, final_act=act_code(rb.activation), out=out,
                                shortcut=(rb.branch1_conv, rb.branch1_norm, x))
-    if rb.branch1_conv is None and can_fuse_bottleneck(sess, bb, x, x):
+    if rb.branch1_conv is None and can_fuse_bottleneck(sess, bb, x, x, act_code(rb.activation)):
         return emit_fused_bottleneck(sess, bb, x, act_code(rb.activation), out=out)
     if rb.branch1_conv is None:
         shortcut = x

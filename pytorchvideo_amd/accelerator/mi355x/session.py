@@ -226,7 +226,13 @@ class Session:
             raise L.PvError("the mi355x deploy form needs a GPU (no CPU fallback); none is visible")
         dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
         self.device = dev
-        self.arena_t = torch.zeros(max(self._arena.peak, _ALIGN), dtype=torch.uint8, device=dev)
+        # a margin of zeros in front of and behind the arena (tuning "arena_margin"): what lies beside an allocation is somebody
+        # else's memory -- with two sub-batch plans, the OTHER plan's arena, written while this one runs
+        from . import tuning
+        margin = int(tuning.get("arena_margin")) // _ALIGN * _ALIGN
+        nbytes = max(self._arena.peak, _ALIGN)
+        self._arena_alloc = torch.zeros(nbytes + 2 * margin, dtype=torch.uint8, device=dev)
+        self.arena_t = self._arena_alloc[margin:margin + nbytes]
         for _, _, boff, blen in self._arena.bands:      # debug plans: canaries behind every buffer
             self.arena_t[boff:boff + blen] = _CANARY
         blob = torch.zeros(max(self._wtop, _ALIGN), dtype=torch.uint8)

@@ -19,6 +19,7 @@ OPTIONS = {
     "fuse_ln_qkv_max_c": 192,    # ... for token widths up to this (wider / shorter tensors: the LDS-DMA GEMM wins)
     "fuse_next_norm": True,      # MViT: norm1 of block i+1 written by block i's fused MLP from the rows it holds (emit_mvit.emit_mlp_fused)
     "fuse_mlp": True,            # MViT norm2 + fc1 + GELU + fc2 + residual as ONE launch (pv_mlp_rows)  (emit_mvit)
+    "arena_margin": 0,           # bytes of zeros in front of and behind a plan's arena (diagnostics)
     "arena_guards": 0,           # debug build of the launch plan: every arena buffer gets its own memory (no re-use) followed
                                  # by this many bytes of canary; Session.check_guards() names the buffers a kernel wrote past
 }
