@@ -14,6 +14,8 @@ from pytorchvideo_amd.utils import synthetic_trained_like_weights  # noqa: E402
 wl = sys.argv[1] if len(sys.argv) > 1 else "x3d_m"
 from pytorchvideo_amd.accelerator.mi355x import tuning  # noqa: E402
 tuning.OPTIONS["arena_margin"] = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+if len(sys.argv) > 3:      # "joint=0": one graph per sub-batch on its own stream instead of one graph with two branches
+    tuning.OPTIONS["split_joint_graph"] = bool(int(sys.argv[3]))
 CASES = ((4, 0, 0), (28, 16, 16)) if len(sys.argv) > 2 else ((0, 0, 0), (16, 0, 0), (8, 0, 0), (4, 0, 0), (0, 16, 0), (0, 0, 16), (28, 16, 16))
 torch.manual_seed(0)
 m, shape = make_model(wl)
