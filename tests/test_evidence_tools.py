@@ -87,14 +87,14 @@ def test_kernel_trace_is_aligned_with_the_plan(tmp_path):
 
 
 def test_design_md_measured_table_is_the_generators_output():
-    """DESIGN.md section 4's table is GENERATED from profiles/r5/ (tools/design_table.py): every row of the generator's output
+    """DESIGN.md section 4's table is GENERATED from profiles/r6/ (tools/design_table.py): every row of the generator's output
     stands verbatim in the document, and the traffic figures it quotes are the ones profiles/traffic.json holds for the commit
     stamped there -- the numbers a reader checks against profiles/ are the numbers in the text."""
     import json
     import design_table
     buf = io.StringIO()
     argv = sys.argv
-    sys.argv = ["design_table.py", "r5"]
+    sys.argv = ["design_table.py", "r6"]
     try:
         with redirect_stdout(buf):
             design_table.main()
@@ -108,6 +108,6 @@ def test_design_md_measured_table_is_the_generators_output():
     tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     assert set(tj["_measured_on"]) >= {"x3d_m", "mvit_b_32x3", "slowfast_r50", "x3d_l"}
     for wl in ("x3d_m", "mvit_b_32x3", "slowfast_r50", "x3d_l"):
-        line = json.load(open(os.path.join(ROOT, "profiles", "r5", wl + "_bench_default.json")))
+        line = json.load(open(os.path.join(ROOT, "profiles", "r6", wl + "_bench_default.json")))
         assert line["roofline"]["kernel"] in tj[wl]["_by_kernel"]     # the dominant symbol has its own PMC population
         assert line["cpu_baseline"]["kind"] in ("port", "reference") and len(line["cpu_baseline"]["threads_sweep"]) >= 2

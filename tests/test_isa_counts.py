@@ -50,9 +50,9 @@ def test_ln_linear_rows_issues_two_stores_per_block(mlp_asm):
 
 
 def test_fused_mlp_main_variant_has_no_scratch_and_streams_its_weights_by_dma(mlp_asm):
-    meta = _meta(mlp_asm, "mlp_rows_kernelILi24ELi12ELb1ELi1ELi3ELi0EE")
+    meta = _meta(mlp_asm, "mlp_rows16_kernelILi12ELi24ELb1ELi3ELi0EE")
     assert meta["private_segment_fixed_size"] == 0 and meta["vgpr_spill_count"] == 0
-    body = _body(mlp_asm, "mlp_rows_kernelILi24ELi12ELb1ELi1ELi3ELi0EE")
+    body = _body(mlp_asm, "mlp_rows16_kernelILi12ELi24ELb1ELi3ELi0EE")
     assert "global_load_lds_dwordx4" in body
 
 

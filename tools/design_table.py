@@ -30,6 +30,10 @@ def main():
         if r.get("second_roof"):
             s2 = r["second_roof"]
             second = "; %s roof: %.1f of %.1f %s = %.2f" % (s2.get("bound"), s2.get("achieved", 0), s2.get("peak", 0), s2.get("unit", ""), s2.get("frac", 0))
+        others = {k: v for k, v in (r.get("second_roofs") or {}).items() if k != r["kernel"]}
+        if others:      # every fp32-stencil symbol of the step against the VALU roof, dominant or not (round 6)
+            second += "; other stencil symbols on the valu roof: " + ", ".join(
+                "`%s` %.2f (%.2f ms)" % (k, v.get("frac", 0), v.get("kernel_ms_per_step", 0)) for k, v in sorted(others.items()))
         # PMC traffic of the SAME evidence pass (profiles/traffic.json, per kernel symbol); the JSON line itself was printed before
         # that pass was adopted and still carries the previous round's figure
         ent = (tj.get(wl, {}).get("_by_kernel") or {}).get(r["kernel"])
