@@ -88,7 +88,7 @@ template <bool PAIR> struct SV;
 template <> struct SV<true> {
   typedef float2 T;
   static __device__ __forceinline__ T zero() { return float2{0.f, 0.f}; }
-  static __device__ __forceinline__ T load(const unsigned char* p) {
+  static __device__ __forceinline__ T load(const unsigned char* p, unsigned) {
     const unsigned u = *reinterpret_cast<const unsigned*>(p);
     return float2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
   }
@@ -98,10 +98,18 @@ template <> struct SV<true> {
 template <> struct SV<false> {
   typedef float T;
   static __device__ __forceinline__ T zero() { return 0.f; }
-  static __device__ __forceinline__ T load(const unsigned char* p) {
-    return __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(p) << 16);
+  // p: the 32-bit word that holds the lane's channel and its neighbour; sel: the v_perm_b32 selector that moves the lane's half into
+  // the upper half of an fp32 (0x01000c0c even channel, 0x03020c0c odd).  NOT a 16-bit LDS load: with ds_read_u16 + the compiler's
+  // partial s_waitcnt lgkmcnt(n) the first value of a row was occasionally consumed before it had arrived when another kernel
+  // loaded the CU's LDS (stride-2 pwdw_plane_kernel beside it) -- irreproducible output column 0 of a thread's segment, gone with
+  // lgkmcnt(0) behind the loads or with 32-bit loads (profiles/r6/replay_locate_*.txt).
+  static __device__ __forceinline__ T load(const unsigned char* p, unsigned sel) {
+    const unsigned u = *reinterpret_cast<const unsigned*>(p);
+    return __uint_as_float(__builtin_amdgcn_perm(u, u, sel));
   }
-  static __device__ __forceinline__ void fma(T& a, const T& x, const T& w) { a += x * w; }
+  // one v_fmac_f32, opaque to the SLP vectoriser (see the note at bottleneck_block_kernel: the packed form it builds for the odd
+  // output of a 7-output segment is not safe on this hardware); same VALU time as v_pk_fma_f32 (4 cycles per 64 FMAs against 8 per 128)
+  static __device__ __forceinline__ void fma(T& a, const T& x, const T& w) { asm("v_fmac_f32 %0, %1, %2" : "+v"(a) : "v"(x), "v"(w)); }
   static __device__ __forceinline__ T ldw(const float* p, bool ok) { return ok ? *p : 0.f; }
 };
 
@@ -269,6 +277,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
         }
       }
       if constexpr (ABL != 4) __syncthreads();
+      if constexpr (ABL == 8) __syncthreads();
     }
   } else {
     // =========================================== STENCIL waves ===========================================
@@ -279,6 +288,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
     constexpr int IB = PAIR ? 4 : 2;              // bytes of an item in E / MID
     constexpr int IC = PAIR ? 2 : 1;              // channels of an item
     const bool p_ok = item < G::NI;
+    const unsigned psel = (item & 1) ? 0x03020c0cu : 0x01000c0cu;     // (one channel per lane: which half of the pair word is the lane's)
     const int pch = p_ok ? IC * item : 0;
     vt wt[27];
 #pragma unroll
@@ -328,12 +338,21 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
       if (p_ok && p >= 0 && p <= T) {
         if (p < T) {
           // ---- [B] plane p into the three rolling accumulator sets ----
-          const unsigned char* ebase = s_e + (p & 1) * G::E_BYTES + (seg * G::NWS) * G::E_STRIDE + item * IB;
+          const unsigned char* ebase = s_e + (p & 1) * G::E_BYTES + (seg * G::NWS) * G::E_STRIDE + (PAIR ? item : item >> 1) * 4;
 #pragma unroll
           for (int dh = 0; dh < 3; ++dh) {
             vt xv[G::NWS + 2];                      // halo columns seg * NWS .. seg * NWS + NWS + 1 = image columns w0 + seg * NWS - 1 ..
+            if constexpr (ABL == 9) {
 #pragma unroll
-            for (int c = 0; c < G::NWS + 2; ++c) xv[c] = V::load(ebase + ((srow + dh) * kWP + c) * G::E_STRIDE);
+              for (int c = G::NWS + 1; c >= 0; --c) { xv[c] = V::load(ebase + ((srow + dh) * kWP + c) * G::E_STRIDE, psel); asm volatile("" : "+v"(xv[c])); }
+            } else {
+#pragma unroll
+              for (int c = 0; c < G::NWS + 2; ++c) {
+                xv[c] = V::load(ebase + ((srow + dh) * kWP + c) * G::E_STRIDE, psel);
+                if constexpr (ABL == 11) asm volatile("" : "+v"(xv[c]));
+              }
+              if constexpr (ABL == 12) __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0), vmcnt / expcnt untouched
+            }
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw) {
               const vt w0v = wt[(0 * 3 + dh) * 3 + dw];   // kt = 0 feeds output p+1
@@ -369,6 +388,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
                 if (ACT_B == PV_ACT_RELU) v0 = fmaxf(v0, 0.f);
                 else if (ACT_B == PV_ACT_SWISH && ABL != 6) v0 *= pv_sigmoid(v0);
                 *reinterpret_cast<bf16_t*>(mbase + n * G::MID_STRIDE) = (bf16_t)v0;
+                if constexpr (ABL == 13) __builtin_amdgcn_sched_barrier(0);
               }
             }
           } else {
@@ -398,6 +418,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_block_kernel(const pv_bottl
         }
       }
       if constexpr (ABL != 4) __syncthreads();
+      if constexpr (ABL == 8) __syncthreads();
     }
     if (MODE == 1 && d.psum != nullptr && p_ok && pch < pv_round_up(d.C, 8)) {
       const int c_p = pv_round_up(d.C, 8);
@@ -464,14 +485,10 @@ extern "C" int pv_bottleneck_supported(const pv_bottleneck_desc* dp) {
   if ((long)d.B * pv_ceil_div(d.H, kTH) * pv_ceil_div(d.W, kTW) > 0x7fffffffL) return 0;
   const int v = variant_of(d);
   if (!v) return 0;
-  // bit s: stage res<s>.  Whole blocks: res3 + res4.  conv_a + conv_b + squeeze sums: res4 only -- on the
-  // larger maps the plane-streaming kernel with the fused pointwise producer (csrc/pv_pwdw.hip) is faster (B = 32: 74 vs 88 us at
-  // res3, 141 vs 190 us at res2; profiles/r6/bench_block_stages_call12.txt against profiles/r5/x3d_m_per_op.txt).
-  // The res2 instantiation (one channel per stencil lane) is NOT routed by default: worth +0.3 % on X3D-M, and with it the
-  // two-branch bench form of X3D-M stopped being bit-reproducible between graph replays -- only with arena re-use AND the second
-  // branch running beside it; the kernel alone, run concurrently with itself, is reproducible (profiles/r6/replay_check_call16.txt,
-  // concurrent_check_call17.txt).  Unexplained, so it stays behind the knob (kernel tests cover it under block_stages = 0x1c).
-  const int stages = d.mode == PV_BLOCK_FULL ? pv_tune("block_stages", 0x18) : pv_tune("block_stages_ab", 0x10);
+  // bit s: stage res<s>.  Whole blocks: res2 + res3 + res4.  conv_a + conv_b + squeeze sums: res4 only -- on the larger maps the
+  // plane-streaming kernel with the fused pointwise producer (csrc/pv_pwdw.hip) is faster (B = 32: 74 vs 88 us at res3, 141 vs
+  // 190 us at res2; profiles/r6/bench_block_stages_call12.txt against profiles/r5/x3d_m_per_op.txt).
+  const int stages = d.mode == PV_BLOCK_FULL ? pv_tune("block_stages", 0x1c) : pv_tune("block_stages_ab", 0x10);
   return (stages >> v) & 1;
 }
 
@@ -492,7 +509,7 @@ extern "C" int pv_bottleneck(const pv_bottleneck_desc* dp, pv_stream_t stream) {
   const int tiles_h = (int)pv_ceil_div(d.H, kTH), tiles_w = (int)pv_ceil_div(d.W, kTW);
   const dim3 grid((unsigned)(d.B * tiles_h * tiles_w));
 #ifdef PV_DEV_ABLATION   // timing builds with WRONG results: development variant of the library only (tools/r6/bench_block.py)
-  if (const int abl = pv_tune("block_abl", 0); abl && variant_of(d) == 4 && d.mode == PV_BLOCK_FULL && d.act_b == PV_ACT_SWISH) {
+  if (const int abl = pv_tune("block_abl", 0); abl && abl < 8 && variant_of(d) == 4 && d.mode == PV_BLOCK_FULL && d.act_b == PV_ACT_SWISH) {
     const dim3 block(512);
     switch (abl) {
       case 1: PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, true, 1, PV_ACT_SWISH, 0, 1>), grid, block, 0, s, d, tiles_h, tiles_w); break;
@@ -500,6 +517,21 @@ extern "C" int pv_bottleneck(const pv_bottleneck_desc* dp, pv_stream_t stream) {
       case 3: PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, true, 1, PV_ACT_SWISH, 0, 3>), grid, block, 0, s, d, tiles_h, tiles_w); break;
       case 4: PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, true, 1, PV_ACT_SWISH, 0, 4>), grid, block, 0, s, d, tiles_h, tiles_w); break;
       default: PV_LAUNCH((bottleneck_block_kernel<224, 3, 96, true, 1, PV_ACT_SWISH, 0, 6>), grid, block, 0, s, d, tiles_h, tiles_w); break;
+    }
+    PV_LAUNCH_CHECK();
+    return PV_OK;
+  }
+#endif
+#ifdef PV_DEV_ABLATION   // diagnostic builds of the res2 instantiation (correct results): 8 two barriers per iteration, 9 the stencil's LDS loads in reverse order, 10 channel pairs
+  if (const int abl = pv_tune("block_abl", 0); abl >= 8 && variant_of(d) == 2 && d.mode == PV_BLOCK_FULL && d.act_b == PV_ACT_SWISH) {
+    const dim3 block(512);
+    switch (abl) {
+      case 8: PV_LAUNCH((bottleneck_block_kernel<64, 1, 32, false, 2, PV_ACT_SWISH, 0, 8>), grid, block, 0, s, d, tiles_h, tiles_w); break;
+      case 9: PV_LAUNCH((bottleneck_block_kernel<64, 1, 32, false, 2, PV_ACT_SWISH, 0, 9>), grid, block, 0, s, d, tiles_h, tiles_w); break;
+      case 11: PV_LAUNCH((bottleneck_block_kernel<64, 1, 32, false, 2, PV_ACT_SWISH, 0, 11>), grid, block, 0, s, d, tiles_h, tiles_w); break;
+      case 12: PV_LAUNCH((bottleneck_block_kernel<64, 1, 32, false, 2, PV_ACT_SWISH, 0, 12>), grid, block, 0, s, d, tiles_h, tiles_w); break;
+      case 13: PV_LAUNCH((bottleneck_block_kernel<64, 1, 32, false, 2, PV_ACT_SWISH, 0, 13>), grid, block, 0, s, d, tiles_h, tiles_w); break;
+      default: PV_LAUNCH((bottleneck_block_kernel<64, 1, 32, true, 2, PV_ACT_SWISH, 0, 0>), grid, block, 0, s, d, tiles_h, tiles_w); break;
     }
     PV_LAUNCH_CHECK();
     return PV_OK;

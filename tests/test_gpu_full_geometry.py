@@ -208,3 +208,59 @@ def test_stress_instance_one_clip(workload):
     assert r["bf16_vs_emulated_oracle"] <= STRESS_KERNEL_BF16[workload]
     assert r["bf16_vs_fp32_oracle"] <= STRESS_VS_FP32[workload]
     assert r["top1_agree_emulated"] == 1
+
+
+def test_x3d_m_fused_blocks_are_bit_reproducible_beside_the_other_sub_batchs_kernels():
+    """Round 6: with the res2 instantiation of bottleneck_block_kernel routed, two replays of the two-branch bench form stopped
+    being bit-identical.  The search (tools/r6/replay_locate.py, profiles/r6/replay_locate_*.txt) ended at that instantiation:
+    beside the other sub-batch's stem kernel or its stride-2 pwdw_plane_kernel -- and only beside those -- output column 0 of a
+    stencil thread's 7-output segment varied from run to run, in the code the SLP vectoriser had packed for the odd output.  With
+    one v_fmac_f32 per tap (csrc/pv_block.hip, SV<false>::fma) it does not.  This test repeats the experiment that showed it: every
+    distinct geometry of the kernel in X3D-M's plan, at the bench's per-branch batch, run behind its predecessors while the other
+    sub-plan loops ONE of its first ops (stem, all of res2, the head of res3: every kernel kind the branch meets early, stride-2
+    ones included) on a second stream; the block's output must be the same bytes in every repetition."""
+    import torch
+    from bench import make_model, synth_input
+    from pytorchvideo_amd.accelerator import convert_to_deployable_form, transmute_model
+    from pytorchvideo_amd.accelerator.mi355x.conversion import _ingest_inputs
+    from pytorchvideo_amd.utils import synthetic_trained_like_weights
+    torch.manual_seed(0)
+    m, shape = make_model("x3d_m")
+    synthetic_trained_like_weights(m, synth_input(shape, 2, 7))
+    m.eval()
+    transmute_model(m, "mi355x")
+    x = synth_input(shape, 32, 99).cuda().bfloat16()
+    dm = convert_to_deployable_form(m, x, dtype=torch.bfloat16, streams=2, use_graph=False)
+    dm(x)
+    torch.cuda.synchronize()
+    parts = list(dm.parts)
+    s0, s1 = [p._pv_session for p in parts]
+    s0.profile(iters=1)
+    seen, targets = set(), []
+    for i, k in enumerate(s0.op_kernels):
+        if "bottleneck_block_kernel" in k and s0.ops[i][3] not in seen:
+            seen.add(s0.ops[i][3])
+            targets.append(i)
+    labels = [s0.ops[i][3].split("|")[0] for i in targets]
+    assert labels.count("block.fused") == 3 and "conv_ab.fused+se" in labels, labels      # res2, res3, res4 whole blocks + res4's squeeze form
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    neighbours = list(range(13))
+    assert any("s122" in s1.ops[j][3] and "pwdw" in s0.op_kernels[j] for j in neighbours)          # a stride-2 pwdw_plane_kernel is among them
+    varied = []
+    for tgt in targets:
+        f = s0.ops[tgt][2]
+        off, nbytes = f["y"].off, int(f["B"]) * int(f["y_bs"]) * 2
+        for j in neighbours:
+            snaps = []
+            for _ in range(3):
+                with torch.cuda.stream(sb):
+                    for _ in range(30):
+                        s1.launch(j, j + 1)
+                with torch.cuda.stream(sa):
+                    _ingest_inputs(s0, x[:16], parts[0]._pv_inputs, False)
+                    s0.launch(0, tgt + 1)
+                torch.cuda.synchronize()
+                snaps.append(s0.arena_t[off:off + nbytes].clone())
+            if not all(torch.equal(snaps[0], t) for t in snaps[1:]):
+                varied.append("%s beside %s" % (s0.ops[tgt][3], s1.ops[j][3]))
+    assert not varied, varied

@@ -1253,25 +1253,16 @@ def test_fused_bottleneck_block(chans, B, T, H, W, act_b):
     d.x_bs, d.y_bs, d.r_bs, d.ldx, d.ldy, d.ldr = T * H * W * cin, T * H * W * ldy, T * H * W * cin, cin, ldy, cin
     d.B, d.T, d.H, d.W, d.cin, d.C, d.cout = B, T, H, W, cin, Cc, cout
     d.act_a, d.act_b, d.act_out, d.dtype = L.ACT_RELU, act_b, L.ACT_RELU, L.PV_BF16
-    assert L.lib().pv_bottleneck_supported(C.byref(d)) == (0 if cin == 24 else 1)      # res2: instantiated, not routed by default
-    L.tune(block_stages=0x1c)
-    try:
-        assert L.lib().pv_bottleneck_supported(C.byref(d)) == 1
-        call("pv_bottleneck", d)
-        assert _routed_kernel(L.OP_BOTTLENECK, d) == "bottleneck_block_kernel"
-    finally:
-        L.tune(block_stages=0x18)
+    assert L.lib().pv_bottleneck_supported(C.byref(d)) == 1
+    call("pv_bottleneck", d)
+    assert _routed_kernel(L.OP_BOTTLENECK, d) == "bottleneck_block_kernel"
     got = y[..., :cout]
     assert rel_err(got, want) <= 1e-2
     assert rel_err(got, want_q) <= 6e-3                 # one bf16 rounding of the result + fp32 summation order
     assert torch.all(y[..., cout:] == 5.0)              # nothing written beyond the block's channels
     y2 = torch.zeros_like(y)
     d.y = y2.data_ptr()
-    L.tune(block_stages=0x1c)
-    try:
-        call("pv_bottleneck", d)
-    finally:
-        L.tune(block_stages=0x18)
+    call("pv_bottleneck", d)
     assert torch.equal(y2[..., :cout], got)             # no atomics: bit-reproducible
     d.C = 300                                           # a width the kernel is not instantiated for: declined, not mis-computed
     assert L.lib().pv_bottleneck_supported(C.byref(d)) == 0 and L.lib().pv_bottleneck(C.byref(d), None) < 0

@@ -61,11 +61,11 @@ def test_plan_build_without_gpu_counts_ops():
     labels = [o[3].split("|")[0] for o in sess.ops]
     # conv_a is evaluated inside conv_b's kernel (fused pointwise producer) while the block input is narrow
     fused = labels.count("conv_ab") + labels.count("conv_ab.dw+se")
-    # round 6 (csrc/pv_block.hip): the blocks WITHOUT squeeze-excitation of res3 / res4 are ONE launch each (2 + 5); of res4's
-    # blocks WITH it, the five stride-1 ones run conv_a + conv_b + squeeze sums in one launch
+    # round 6 (csrc/pv_block.hip): the blocks WITHOUT squeeze-excitation of res2 / res3 / res4 are ONE launch each (1 + 2 + 5); of
+    # res4's blocks WITH it, the five stride-1 ones run conv_a + conv_b + squeeze sums in one launch
     whole, ab_se = labels.count("block.fused"), labels.count("conv_ab.fused+se")
-    assert (whole, ab_se) == (7, 5)
-    assert fused == 7 and labels.count("conv_a") == 26 - fused - whole - ab_se and labels.count("conv_c") == 26 - whole
+    assert (whole, ab_se) == (8, 5)
+    assert fused == 6 and labels.count("conv_a") == 26 - fused - whole - ab_se and labels.count("conv_c") == 26 - whole
     assert labels.count("se_gate") == 15  # SE in every other block: 2+3+6+4
     assert (cur.B, cur.C, cur.f32) == (2, 400, True)
     with pytest.raises(AssertionError):
