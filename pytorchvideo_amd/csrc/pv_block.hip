@@ -99,16 +99,23 @@ template <> struct SV<false> {
   typedef float T;
   static __device__ __forceinline__ T zero() { return 0.f; }
   // p: the 32-bit word that holds the lane's channel and its neighbour; sel: the v_perm_b32 selector that moves the lane's half into
-  // the upper half of an fp32 (0x01000c0c even channel, 0x03020c0c odd).  NOT a 16-bit LDS load: with ds_read_u16 + the compiler's
-  // partial s_waitcnt lgkmcnt(n) the first value of a row was occasionally consumed before it had arrived when another kernel
-  // loaded the CU's LDS (stride-2 pwdw_plane_kernel beside it) -- irreproducible output column 0 of a thread's segment, gone with
-  // lgkmcnt(0) behind the loads or with 32-bit loads (profiles/r6/replay_locate_*.txt).
+  // the upper half of an fp32 (0x01000c0c even channel, 0x03020c0c odd): one ds_read_b32 + one v_perm_b32 per value
   static __device__ __forceinline__ T load(const unsigned char* p, unsigned sel) {
     const unsigned u = *reinterpret_cast<const unsigned*>(p);
     return __uint_as_float(__builtin_amdgcn_perm(u, u, sel));
   }
-  // one v_fmac_f32, opaque to the SLP vectoriser (see the note at bottleneck_block_kernel: the packed form it builds for the odd
-  // output of a 7-output segment is not safe on this hardware); same VALU time as v_pk_fma_f32 (4 cycles per 64 FMAs against 8 per 128)
+  // ONE v_fmac_f32 per tap, opaque to the SLP vectoriser.  With `a += x * w` hipcc packed the taps of neighbouring outputs into
+  // v_pk_fma_f32 and, a segment having 7 outputs, built a separate packed sequence for the odd one (two accumulator sets of output 0
+  // in one register pair, the products of the third by v_pk_mul_f32 + v_add_f32).  That build was NOT bit-reproducible: beside the
+  // other sub-batch's stem kernel or its stride-2 pwdw_plane_kernel -- and beside no other op of the plan -- output column 0 of a
+  // thread's segment differed from run to run (~1e-4 of the voxels, all channels, modest values: one accumulator of that output
+  // wrong).  What removed it: waiting for ALL of a row's LDS loads before the first FMA, pinning the loads in order, channel
+  // pairs (the res3 / res4 form), or this scalar form; what did not: a second barrier per iteration, ordering the MID stores,
+  // 32-bit instead of 16-bit LDS loads.  The instruction-level cause is not established: the most suspicious form of that
+  // sequence (v_pk_fma_f32 whose destination pair is also its broadcast source) is exact in isolation, alone and beside an
+  // LDS-heavy kernel (tools/micro/pk_fma_inplace.hip).  Evidence: profiles/r6/replay_locate_*.txt; regression test:
+  // tests/test_gpu_full_geometry.py::test_x3d_m_fused_blocks_are_bit_reproducible_beside_the_other_sub_batchs_kernels.
+  // Same VALU time as the packed form (4 cycles per 64 FMAs against 8 per 128), fewer register moves: 69 instead of 126 VGPRs.
   static __device__ __forceinline__ void fma(T& a, const T& x, const T& w) { asm("v_fmac_f32 %0, %1, %2" : "+v"(a) : "v"(x), "v"(w)); }
   static __device__ __forceinline__ T ldw(const float* p, bool ok) { return ok ? *p : 0.f; }
 };
