@@ -50,6 +50,10 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const pv_conv3d_de
 
   __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LD];
   __shared__ int s_tap[PW ? 1 : kMaxTaps];
+  // the squeeze-excitation gates of the (at most two) clips a tile's rows belong to: read once per workgroup instead of once per
+  // staged chunk -- the per-chunk global loads sat on the critical path of every K step (X3D res5's gated conv_c: 39 -> ... us)
+  constexpr int kGateMaxC = 512;
+  __shared__ __attribute__((aligned(16))) float s_gate[PW ? 2 * kGateMaxC : 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -84,6 +88,23 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const pv_conv3d_de
                  ((dw * (d.dil_w > 1 ? d.dil_w : 1)) << 16);
     }
     __syncthreads();
+  }
+
+  bool gate_lds = false;
+  int gate_b0 = 0;
+  if constexpr (PW) {
+    if (d.a_gate != nullptr) {
+      gate_b0 = (int)(m0 / S_out);
+      const long m_last = (m0 + BM < M ? m0 + BM : M) - 1;
+      gate_lds = d.cin <= kGateMaxC && (d.cin & 7) == 0 && (int)(m_last / S_out) - gate_b0 <= 1;      // (workgroup-uniform)
+      if (gate_lds) {
+        for (int i = tid; i < 2 * d.cin; i += kThreads) {
+          const int bb = gate_b0 + (i >= d.cin ? 1 : 0);
+          s_gate[i] = bb < d.B ? d.a_gate[(long)bb * d.cin + (i >= d.cin ? i - d.cin : i)] : 0.f;
+        }
+        __syncthreads();
+      }
+    }
   }
 
   // ---- per-thread staging geometry (rows are fixed across K steps) ----
@@ -133,9 +154,12 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const pv_conv3d_de
     w_off[i] = (long)c * K;
   }
 
-  Chunk8<T> xr[XCH], wr[WCH];
+  // Two K tiles in flight in registers, in two FIXED sets used alternately (round 6; no copies between them: a copy waits for the
+  // load).  A step's global loads used to be hidden only behind ONE step of MFMAs (~0.1 us of a ~2 us latency), so small-M layers
+  // -- X3D res5's gated conv_c: 392 tiles, 14 steps -- ran at one memory latency per step.
+  Chunk8<T> xrA[XCH], wrA[WCH], xrB[XCH], wrB[WCH];
 
-  auto load_global = [&](int ks) {
+  auto load_global = [&](Chunk8<T> (&xr)[XCH], Chunk8<T> (&wr)[WCH], int ks) {
     const int k0 = ks * kBK + kc * 8;
     if constexpr (PW) {
       const bool kok = k0 < K;
@@ -166,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const pv_conv3d_de
     }
   };
 
-  auto store_lds = [&](int buf, int ks) {
+  auto store_lds = [&](Chunk8<T> (&xr)[XCH], Chunk8<T> (&wr)[WCH], int buf, int ks) {
     T* xs = smem + buf * (BM + BN) * LD;
     T* ws = xs + BM * LD;
     const int k0 = ks * kBK + kc * 8;
@@ -178,9 +202,16 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const pv_conv3d_de
         float f[8];
         xr[i].to_f32(f);
         if (d.a_gate != nullptr && k0 < K) {
-          const float* g = d.a_gate + (long)x_b[i] * d.cin + k0;
-          const float4 g0 = *reinterpret_cast<const float4*>(g);
-          const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
+          float4 g0, g1;
+          if (PW && gate_lds) {
+            const float* g = s_gate + (x_ok[i] ? x_b[i] - gate_b0 : 0) * d.cin + k0;      // (rows past M carry zeros and clip 0)
+            g0 = *reinterpret_cast<const float4*>(g);
+            g1 = *reinterpret_cast<const float4*>(g + 4);
+          } else {
+            const float* g = d.a_gate + (long)x_b[i] * d.cin + k0;
+            g0 = *reinterpret_cast<const float4*>(g);
+            g1 = *reinterpret_cast<const float4*>(g + 4);
+          }
           f[0] *= g0.x; f[1] *= g0.y; f[2] *= g0.z; f[3] *= g0.w;
           f[4] *= g1.x; f[5] *= g1.y; f[6] *= g1.z; f[7] *= g1.w;
         }
@@ -206,12 +237,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const pv_conv3d_de
   const int wave_c0 = n0 + wn * (TN * 16);
 
   const int nk = (K + kBK - 1) / kBK;
-  load_global(0);
-  store_lds(0, 0);
-  __syncthreads();
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) load_global(ks + 1);
+  auto compute = [&](int buf) {
     const T* xs = smem + buf * (BM + BN) * LD;
     const T* ws = xs + BM * LD;
     if constexpr (sizeof(T) == 2) {
@@ -248,7 +274,23 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const pv_conv3d_de
         }
       }
     }
-    if (ks + 1 < nk) store_lds(buf ^ 1, ks + 1);
+  };
+  load_global(xrA, wrA, 0);
+  store_lds(xrA, wrA, 0, 0);
+  if (nk > 1) load_global(xrA, wrA, 1);
+  if (nk > 2) load_global(xrB, wrB, 2);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ks += 2) {
+    // even step: tile ks + 1 waits in set A, tile ks + 2 is on its way into set B
+    compute(0);
+    if (ks + 1 < nk) store_lds(xrA, wrA, 1, ks + 1);
+    if (ks + 3 < nk) load_global(xrA, wrA, ks + 3);
+    __syncthreads();
+    if (ks + 1 >= nk) break;
+    // odd step: tile ks + 2 waits in set B, tile ks + 3 is on its way into set A
+    compute(1);
+    if (ks + 2 < nk) store_lds(xrB, wrB, 0, ks + 2);
+    if (ks + 4 < nk) load_global(xrB, wrB, ks + 4);
     __syncthreads();
   }
 
