@@ -13,7 +13,7 @@ OPTIONS = {
     "fuse_kv_pool": True,        # MViT pool_k + pool_v as one depthwise launch                   (emit_mvit)
     "fuse_posenc": True,         # position tables added in the patch-embedding conv's epilogue   (emit_mvit)
     "split_joint_graph": True,   # sub-batches of SplitBatchDeployed as branches of ONE hipGraph  (conversion)
-    "pool_stream_min_elems": 1 << 23,   # MViT pooling convs on grids at least this big use the plane-streaming kernel + a
+    "pool_stream_min_elems": 1 << 22,   # MViT pooling convs on grids at least this big use the plane-streaming kernel + a
                                         # separate per-head LayerNorm; smaller ones the fused pool + LayerNorm kernel  (emit_mvit)
     "fuse_ln_qkv": True,         # MViT norm1 + the q|k|v Linear as ONE launch (pv_ln_linear_rows)               (emit_mvit)
     "fuse_ln_qkv_max_c": 192,    # ... for token widths up to this (wider / shorter tensors: the LDS-DMA GEMM wins)
