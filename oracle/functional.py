@@ -25,7 +25,7 @@ import torch.nn.functional as F
 # against the fp32 reference (tools/storage_floor.py).
 _STORE = None
 _BATCH_HINT = 1     # clips in the deploy form's batch: the MViT plan routes pooling convs by tensor size
-POOL_STREAM_MIN_ELEMS_DEFAULT = 1 << 23     # the deploy form's default routing threshold (tuning.OPTIONS["pool_stream_min_elems"]);
+POOL_STREAM_MIN_ELEMS_DEFAULT = 1 << 22     # the deploy form's default routing threshold (tuning.OPTIONS["pool_stream_min_elems"]);
 _POOL_STREAM_MIN_ELEMS = POOL_STREAM_MIN_ELEMS_DEFAULT   # tests/test_host.py pins the two to each other
 
 

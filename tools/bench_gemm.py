@@ -60,6 +60,10 @@ SHAPES = [  # (label, B, T,H,W in, cin, cout, k(t,h,w), s(t,h,w), p)
     ("x3d stem 1x3x3 3->24", 32, 16, 224, 224, 8, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     ("x3d conv_a s5 192->432", 32, 16, 7, 7, 192, 432, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("x3d conv_c s4 216->96", 32, 16, 14, 14, 216, 96, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("x3d conv_c s5 432->192", 32, 16, 7, 7, 432, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("x3d hb conv_a s5 192->432", 16, 16, 7, 7, 192, 432, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("x3d hb conv_c s5 432->192", 16, 16, 7, 7, 432, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("x3d pre_conv s5 192->432", 32, 16, 7, 7, 192, 432, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("sf shortcut res3 320->512 s122", 16, 8, 32, 32, 320, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
     ("sf shortcut res4 640->1024 s122", 16, 8, 16, 16, 640, 1024, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
     ("sf shortcut res5 1280->2048 s122", 16, 8, 8, 8, 1280, 2048, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
