@@ -343,6 +343,19 @@ __global__ __launch_bounds__(kThreads, (KS >= 14 || X2V) ? 2 : ((NT >= 4 || KS >
   }
 }
 
+// Workgroups of `kern` one CU holds at a time, at most 4: what the RUNTIME says for this variant's registers and this launch's
+// LDS.  (Until round 6 the grid was sized from the LDS footprint alone, 4 per CU where it allowed; the variants that compile
+// to 146-162 VGPRs -- the two-operand ones, <4, 2, true, 4> -- hold 3, so a quarter of the grid ran as a second, mostly empty round.)
+inline long resident_per_cu(const void* kern, size_t lds) {
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kThreads, lds) != hipSuccess || occ < 1) {
+    (void)hipGetLastError();
+    const long by_lds = lds > 0 ? (160 * 1024) / (long)(lds + 1024) : 4;
+    return by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
+  }
+  return occ > 4 ? 4 : occ;
+}
+
 template <int NT, int TM, bool XFORM, int KS, bool F32>
 int launch_pw_f(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) {
   const long M = (long)d.B * d.To * d.Ho * d.Wo;
@@ -358,8 +371,8 @@ int launch_pw_f(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) 
       auto kern2 = pw_stream_kernel<NT, TM, XFORM, KS, false, true>;
       if (lds > 64 * 1024)
         PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      const long per_cu2 = lds > 0 ? (160 * 1024) / (long)(lds + 1024) : 4;
-      const long resident2 = 256 * (per_cu2 < 1 ? 1 : (per_cu2 > 4 ? 4 : per_cu2));
+      const long per_cu2 = resident_per_cu(reinterpret_cast<const void*>(kern2), lds);
+      const long resident2 = 256 * per_cu2;
       long nchunks2 = pv_ceil_div(resident2, nsplit2);
       if (nchunks2 > ngroups2) nchunks2 = ngroups2;
       const long blocks2 = pv_ceil_div(nchunks2, 8) * 8 * nsplit2;
@@ -377,8 +390,8 @@ int launch_pw_f(const pv_conv3d_desc& d, int ksteps, size_t lds, hipStream_t s) 
   // one resident generation of workgroups (what LDS and the 4-waves-per-SIMD register budget admit
   // per CU); the rest is the grid-stride loop, so the weight slab is staged once per resident
   // workgroup, not once per 64 voxels
-  const long per_cu = lds > 0 ? (160 * 1024) / (long)(lds + 1024) : 4;
-  const long resident = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+  const long per_cu = resident_per_cu(reinterpret_cast<const void*>(kern), lds);
+  const long resident = 256 * per_cu;
   long nchunks = pv_ceil_div(resident, nsplit);
   if (nchunks > ngroups) nchunks = ngroups;
   const long blocks = pv_ceil_div(nchunks, 8) * 8 * nsplit;
