@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 INCLUDE = os.path.join(ROOT, "include")
 OUT_DIR = os.path.join(os.path.dirname(HERE), "_lib")
 LIB = os.path.join(OUT_DIR, "libpv_mi355x.so")
-SOURCES = ["pv_conv.hip", "pv_pwconv.hip", "pv_gemm.hip", "pv_gemm8.hip", "pv_gemm9.hip", "pv_gemm9h.hip", "pv_stem.hip", "pv_dwconv.hip", "pv_pwdw.hip", "pv_misc.hip", "pv_tokpool.hip", "pv_attn.hip", "pv_roi.hip", "pv_lateral.hip", "pv_mlp.hip", "pv_block.hip", "pv_headgemm.hip", "pv_comm.hip", "pv_plan.hip"]
+SOURCES = ["pv_conv.hip", "pv_pwconv.hip", "pv_gemm.hip", "pv_gemm8.hip", "pv_gemm9.hip", "pv_gemm9h.hip", "pv_stem.hip", "pv_dwconv.hip", "pv_pwdw.hip", "pv_misc.hip", "pv_tokpool.hip", "pv_attn.hip", "pv_attn64.hip", "pv_roi.hip", "pv_lateral.hip", "pv_mlp.hip", "pv_block.hip", "pv_headgemm.hip", "pv_comm.hip", "pv_plan.hip"]
 HEADERS = [os.path.join(HERE, "pv_common.h"), os.path.join(INCLUDE, "pv_mi355x.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", HERE,

@@ -27,6 +27,8 @@
 #include <type_traits>
 #include "pv_common.h"
 
+int pv_attn_w64_try(const pv_attention_desc& d, hipStream_t s);   // pv_attn64.hip; PV_ERR_UNSUPPORTED = not its case
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -696,6 +698,10 @@ extern "C" int pv_attention(const pv_attention_desc* dp, pv_stream_t stream) {
   const int width = d.heads * d.head_dim;
   if (d.ldq < width || d.ldk < width || d.ldv < width || d.ldo < width) return PV_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  {   // bf16, head dim 96 (MViT): the one-wave-per-SIMD kernel of pv_attn64.hip
+    const int r = pv_attn_w64_try(d, s);
+    if (r != PV_ERR_UNSUPPORTED) return r;
+  }
   if (d.dtype == PV_BF16) return launch_attn_d<bf16_t>(d, s);
   if (d.dtype == PV_F32) return launch_attn_d<float>(d, s);
   return PV_ERR_UNSUPPORTED;

@@ -42,5 +42,13 @@ def run(label, B, heads, Nq, Nk, hd=96, iters=20):
 
 
 if __name__ == "__main__":
-    tot = sum(run(*s) * n for s, n in zip(SHAPES, (1, 1, 1, 1, 10, 1, 1)))
-    print("MViT-B 32x3 attention total per step: %.3f ms" % tot)
+    # A/B of the two bf16 kernels: attn_w64=0 routes to attn_pipe_kernel (pv_attn.hip), 1 to attn_w64_kernel (pv_attn64.hip)
+    # (dev library, PV_MI355X_LIB=.../_lib/dev/libpv_mi355x.so: "abl<bits>" selects a timing-only ablation of attn_w64_kernel)
+    for arg in (sys.argv[1:] or ["0", "1"]):
+        if arg.startswith("abl"):
+            L.tune(attn_w64=1, attn_abl=int(arg[3:]))
+        else:
+            L.tune(attn_w64=int(arg))
+        print("attn_w64 = %s" % arg)
+        tot = sum(run(*s) * n for s, n in zip(SHAPES, (1, 1, 1, 1, 10, 1, 1)))
+        print("MViT-B 32x3 attention total per step: %.3f ms" % tot)
