@@ -52,7 +52,7 @@ struct LatTile {
 // NT: 16-channel MFMA row tiles per workgroup (slab = NT * 16 output channels); TM: voxel tiles per wave tile
 template <int NT, int TM>
 __global__ __launch_bounds__(kLatThreads) void tap_stream_kernel(const TapConv d, int ksteps, int ngroups,
-                                                                   int nchunks, int nsplit) {
+                                                                   int nchunks, int nsplit, int xcont) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int Kp = ksteps * 32;
   const int WLD = Kp + 8;   // row stride in elements: 16 B x odd -> conflict-free ds_read_b128
@@ -71,9 +71,12 @@ __global__ __launch_bounds__(kLatThreads) void tap_stream_kernel(const TapConv d
   const long M = (long)d.B * d.To * HWo;
   const int taps = d.kt * d.kh * d.kw;
   // the N splits of one voxel chunk are consecutive workgroups of one XCD: the activations are fetched from
-  // HBM once and re-read from that XCD's L2 by the other splits
+  // HBM once and re-read from that XCD's L2 by the other splits.  XCONT (round 6): an XCD takes a CONTIGUOUS run of
+  // chunks -- the consumers of an input frame (the kt output frames around it) or of an input row (the kh output rows)
+  // are neighbouring chunks, and dealt round-robin they sat on kt / kh different XCDs, each filling its own L2 with
+  // the same lines (PMC round 5: the fast pathway's (3,1,1) layers fetched 3.8 x their input)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int chunk = (slot / nsplit) * 8 + xcd;
+  const int chunk = xcont ? xcd * ((nchunks + 7) >> 3) + slot / nsplit : (slot / nsplit) * 8 + xcd;
   const int n0 = (slot % nsplit) * (NT * 16);
 
   // ---- stage the filter slab (LDS row r = channel n0 + perm(r)), BN scale / shift, the tap table ----
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(kLatThreads) void tap_stream_kernel(const TapConv d
 }
 
 template <int NT, int TM>
-int launch_lateral(const TapConv& d, int ksteps, size_t lds, hipStream_t s) {
+int launch_lateral(const TapConv& d, int ksteps, size_t lds, int xcont, hipStream_t s) {
   const long M = (long)d.B * d.To * d.Ho * d.Wo;
   const long ngroups = pv_ceil_div(M, (kLatThreads / 64) * TM * 16);
   const int nsplit = (int)pv_ceil_div(pv_round_up(d.cout, 8), NT * 16);
@@ -223,14 +226,17 @@ int launch_lateral(const TapConv& d, int ksteps, size_t lds, hipStream_t s) {
   long nchunks = pv_ceil_div(256 * per_cu, nsplit);
   if (nchunks > ngroups) nchunks = ngroups;
   const long blocks = pv_ceil_div(nchunks, 8) * 8 * nsplit;
-  PV_LAUNCH(kern, dim3((unsigned)blocks), dim3(kLatThreads), lds, s, d, ksteps, (int)ngroups, (int)nchunks, nsplit);
+  PV_LAUNCH(kern, dim3((unsigned)blocks), dim3(kLatThreads), lds, s, d, ksteps, (int)ngroups, (int)nchunks, nsplit, xcont);
   pv_note_kernel("tap_stream_kernel");   // (launched through a function pointer: PV_LAUNCH saw only the variable)
   PV_LAUNCH_CHECK();
   return PV_OK;
 }
 
 // PV_OK: launched; PV_ERR_UNSUPPORTED: not a geometry of the streaming kernel (nothing launched)
-int tapstream_launch(const TapConv& d, int k_limit, hipStream_t s) {
+// xcont: chunk -> XCD mapping (see the kernel).  Contiguous runs for the convolutions (same-box A/B on SlowFast-R50: the fast
+// pathway's res4 conv_a 27 -> 17 us, res3 30 -> 28 us, model +0.6 %); the time-strided lateral connections measured 3-6 % slower
+// with it at 64^2 and equal elsewhere, and keep the round-robin deal.
+int tapstream_launch(const TapConv& d, int k_limit, int xcont, hipStream_t s) {
   const int taps = d.kt * d.kh * d.kw;
   const long K = (long)taps * d.cin;
   if (K > k_limit || d.kt > 255 || d.kh > 255 || d.kw > 255) return PV_ERR_UNSUPPORTED;
@@ -244,9 +250,9 @@ int tapstream_launch(const TapConv& d, int k_limit, hipStream_t s) {
   while (nt > 2 && lds_of(nt) > 120 * 1024) nt >>= 1;
   if (lds_of(nt) > 120 * 1024) return PV_ERR_UNSUPPORTED;
   const size_t lds = lds_of(nt);
-  if (nt == 2) return launch_lateral<2, 2>(d, ksteps, lds, s);
-  if (nt == 4) return launch_lateral<4, 2>(d, ksteps, lds, s);
-  return launch_lateral<8, 1>(d, ksteps, lds, s);
+  if (nt == 2) return launch_lateral<2, 2>(d, ksteps, lds, xcont, s);
+  if (nt == 4) return launch_lateral<4, 2>(d, ksteps, lds, xcont, s);
+  return launch_lateral<8, 1>(d, ksteps, lds, xcont, s);
 }
 
 }  // namespace
@@ -265,7 +271,7 @@ int pv_tapstream_try(const pv_conv3d_desc& c, hipStream_t s) {
   d.To = c.To; d.Ho = c.Ho; d.Wo = c.Wo; d.cout = c.cout;
   d.kt = c.kt; d.kh = c.kh; d.kw = c.kw; d.st = c.st; d.sh = c.sh; d.sw = c.sw; d.pt = c.pt; d.ph = c.ph; d.pw = c.pw;
   d.act = c.act;
-  return tapstream_launch(d, 640, s);
+  return tapstream_launch(d, 640, pv_tune("tap_xcont", 1), s);
 }
 
 extern "C" int pv_lateral_fuse(const pv_lateral_desc* dp, pv_stream_t stream) {
@@ -287,7 +293,7 @@ extern "C" int pv_lateral_fuse(const pv_lateral_desc* dp, pv_stream_t stream) {
     d.To = l.To; d.Ho = l.H; d.Wo = l.W; d.cout = l.cout;
     d.kt = l.kt; d.kh = 1; d.kw = 1; d.st = l.st; d.sh = 1; d.sw = 1; d.pt = l.pt; d.ph = 0; d.pw = 0;
     d.act = l.act;
-    const int r = tapstream_launch(d, 256, s);
+    const int r = tapstream_launch(d, 256, pv_tune("lat_xcont", 0), s);
     if (r != PV_ERR_UNSUPPORTED) return r;
   }
   // fp32 parity mode, MFMA-bound widths and geometries outside the streaming kernel's range: the same arithmetic
