@@ -87,8 +87,8 @@ __global__ __launch_bounds__(64 * NW, NQB == 2 ? 1 : 2) void attn_w64_kernel(con
   constexpr int K_BYTES = KT * KLD * 2, V_BYTES = KT * D * 2;
   constexpr int NKF = 2 * NKS;                    // K fragments per tile (sub, ks)
   constexpr int NVF = 4 * NDB;                    // V fragments per tile (sk, db)
-  constexpr int KPRE = 5, KRING = 6;              // K fragments requested before their phase / ring depth
-  constexpr int VPRE = 5, VRING = 6;
+  constexpr int KPRE = NQB == 2 ? 5 : 4, KRING = KPRE + 1;   // K fragments requested before their phase / ring depth (the 256-register forms have no room for more)
+  constexpr int VPRE = NQB == 2 ? 5 : 4, VRING = VPRE + 1;
   constexpr int KLEAD = 2 * NQB, VLEAD = 4 * NQB; // MFMA slices between the last pre-read and the end of its phase
   static_assert(NKF >= KPRE && NVF >= VPRE, "rings assume at least KPRE fragments per tile");
   __shared__ __attribute__((aligned(16))) char smem[2 * K_BYTES + 3 * V_BYTES];
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(64 * NW, NQB == 2 ? 1 : 2) void attn_w64_kernel(con
   //      (zeros; their scores are masked in the last tile, their P is 0).  SPLIT: threads 0-255 stage K, 256-511 V. ----
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const int s_tid = tid & 255;
-  const bool role_v = SPLIT && tid >= 256;          // wave-uniform
+  const bool role_v = SPLIT && __builtin_amdgcn_readfirstlane(tid) >= 256;   // wave-uniform, and known to be (a per-lane select of
+                                                                              // the buffer resource puts every load into a waterfall loop)
   const int s_key = s_tid >> 2, s_cq = s_tid & 3;
   __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(K), 0, (int)(((long)(d.Nk - 1) * d.ldk + D) * 2), 0x00020000);
   __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(V), 0, (int)(((long)(d.Nk - 1) * d.ldv + D) * 2), 0x00020000);
@@ -607,8 +608,14 @@ template <int NQB, int NW> int launch_w64(const pv_attention_desc& d, hipStream_
 
 int pv_attn_w64_try(const pv_attention_desc& d, hipStream_t s) {
   if (d.dtype != PV_BF16 || d.head_dim != 96) return PV_ERR_UNSUPPORTED;
-  const int form = pv_tune("attn_w64", 4);   // 0: pv_attn.hip's kernels; 1: 64 rows per wave, one wave per SIMD; 2 / 3: 32 rows per
-                                             // wave, two waves per SIMD as one 8-wave workgroup / two 4-wave workgroups per CU
+  // 0: pv_attn.hip's kernels; 1: 64 rows per wave, one wave per SIMD; 2 / 3: 32 rows per wave, two waves per SIMD as one 8-wave
+  // workgroup / two 4-wave workgroups per CU; 4: form 1 while its 256-row items fit two rounds of the chip, else form 3.
+  // Default 3: in the micro-benchmark (batch 8, one kernel on the chip) form 1 wins the shapes with <= 3137 queries and the
+  // mix (4) the sum; in the model's default form -- two sub-batches of 4 as parallel graph branches -- form 3 wins every
+  // time: 1270 (attn_pipe_kernel) / 1286 (4) / 1287 (2) / 1297 (3) clips/s over three interleaved rounds
+  // (profiles/r6/model_ab_attn_w64_forms_call79.txt): its workgroups are half the size and leave registers for the
+  // other branch's kernels.
+  const int form = pv_tune("attn_w64", 3);
   if (!form) return PV_ERR_UNSUPPORTED;
   const long kv_bytes = ((long)d.Nk * (d.ldk > d.ldv ? d.ldk : d.ldv) + d.head_dim) * 2;   // 32-bit buffer offsets
   if (kv_bytes >= 0x7fffffffL) return PV_ERR_UNSUPPORTED;

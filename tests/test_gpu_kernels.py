@@ -35,8 +35,9 @@ def _attention_ref(q, k, v, heads, scale, residual_q):
     return o.permute(0, 2, 1, 3).reshape(B, Nq, Cw)
 
 
-def _run_attention(q, k, v, heads, scale, residual_q, pad=0):
-    """q/k/v: (B, N, heads*hd) device tensors, possibly channel slices of a wider buffer."""
+def _run_attention(q, k, v, heads, scale, residual_q, pad=0, routed=None):
+    """q/k/v: (B, N, heads*hd) device tensors, possibly channel slices of a wider buffer.  routed: a list that receives the
+    symbol of the kernel the descriptor is routed to under the current knobs."""
     B, Nq, Cw = q.shape
     o = torch.full((B, Nq, Cw + pad), 7.0, dtype=q.dtype, device="cuda")
     d = L.AttentionDesc()
@@ -46,6 +47,8 @@ def _run_attention(q, k, v, heads, scale, residual_q, pad=0):
     d.B, d.heads, d.head_dim, d.Nq, d.Nk = B, heads, Cw // heads, Nq, k.shape[1]
     d.scale, d.residual_q, d.dtype = scale, int(residual_q), pv_dtype(q)
     call("pv_attention", d)
+    if routed is not None:
+        routed.append(_routed_kernel(L.OP_ATTENTION, d))
     if pad:
         assert torch.all(o[:, :, Cw:] == 7.0)  # never writes outside its channels
     return o[:, :, :Cw]
@@ -119,6 +122,59 @@ def test_attention_online_softmax_rescale_branch(dtype):
     got = _run_attention(q, k, v, heads, hd ** -0.5, False)
     assert rel_err(got, want) <= TOL[dtype]
     assert rel_err(got[0, 17], v[0, 333].float()) <= 2e-2  # the spiked row is (almost) a copy of v[333]
+
+
+@pytest.mark.parametrize("form", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("B,heads,Nq,Nk,res", [
+    (2, 2, 785, 785, True),       # MViT-B block 15, residual_pool
+    (1, 1, 1000, 197, False),     # ragged key tail, several workgroups
+    (2, 4, 129, 65, True),        # one row past a 32-row block / one key past a tile
+    (1, 2, 300, 64, False),       # exactly one key tile: prologue + last step only
+    (1, 1, 130, 128, True),       # two full tiles
+    (1, 3, 257, 192, False),      # three full tiles (odd count), one row past a 256-row item
+    (1, 1, 40, 384, True),        # six full tiles: the pipelined steps on both parities
+    (1, 8, 33, 3137, False),      # long key loop
+    (2, 1, 3137, 785, True),      # MViT-B blocks 4-13 (one head of it)
+])
+def test_attention_every_kernel_form_of_head_dim_96(form, B, heads, Nq, Nk, res):
+    """pv_attention routes bf16 / head_dim 96 (MViT) by size between the forms of attn_w64_kernel (pv_attn64.hip: 64 query
+    rows per wave on one wave per SIMD; 32 rows per wave on two waves per SIMD as one 8-wave or two 4-wave workgroups per
+    CU) -- the default routing would leave a form untested at a given size, so each is forced through the development knob
+    (0 = attn_pipe_kernel of pv_attn.hip, 3 = the default, 4 = forms 1 / 3 by size), against the fp32 reference (layers/attention.py:531-539)."""
+    hd, dtype = 96, torch.bfloat16
+    Cw = heads * hd
+    q, k, v = _rand((B, Nq, Cw), 41, dtype), _rand((B, Nk, Cw), 42, dtype), _rand((B, Nk, Cw), 43, dtype)
+    want = _attention_ref(q, k, v, heads, hd ** -0.5, res)
+    routed = []
+    L.tune(attn_w64=form)
+    try:
+        got = _run_attention(q, k, v, heads, hd ** -0.5, res, pad=8, routed=routed)
+    finally:
+        L.tune(attn_w64=3)
+    assert rel_err(got, want) <= TOL[dtype]
+    assert routed[0] == ("attn_pipe_kernel" if form == 0 else "attn_w64_kernel"), routed
+
+
+@pytest.mark.parametrize("form", [1, 2, 3])
+def test_attention_forms_take_the_rescale_branch_and_a_masked_first_tile(form):
+    """The rescale block of attn_w64_kernel (accumulator registers scaled through inline assembly in the one-wave form) and the
+    ragged single-tile path: a spiked key late in the sequence, one in the very first tile, and Nk < 64."""
+    B, heads, hd, Nq, Nk = 1, 1, 96, 64, 400
+    dtype = torch.bfloat16
+    q, k, v = _rand((B, Nq, hd), 11, dtype, 0.5), _rand((B, Nk, hd), 12, dtype, 0.5), _rand((B, Nk, hd), 13, dtype)
+    k[0, 333] = (q[0, 17].float() * 8.0).to(dtype)
+    k[0, 2] = (q[0, 40].float() * 8.0).to(dtype)
+    k[0, 130] = (q[0, 50].float() * 6.0).to(dtype)    # row 50 (second 32-row block of a 64-row wave) grows at another tile
+    want = _attention_ref(q, k, v, heads, hd ** -0.5, False)
+    L.tune(attn_w64=form)
+    try:
+        got = _run_attention(q, k, v, heads, hd ** -0.5, False)
+        small = _run_attention(q[:, :, :], k[:, :37], v[:, :37], heads, hd ** -0.5, True)
+    finally:
+        L.tune(attn_w64=3)
+    assert rel_err(got, want) <= TOL[dtype]
+    assert rel_err(got[0, 17], v[0, 333].float()) <= 2e-2
+    assert rel_err(small, _attention_ref(q, k[:, :37], v[:, :37], heads, hd ** -0.5, True)) <= TOL[dtype]
 
 
 def test_attention_rejects_bad_descriptors():

@@ -131,3 +131,80 @@ def test_half_height_gemm_main_loop_carries_the_counted_waits_and_no_scratch(gem
     assert len(re.findall(r"global_load_lds_dwordx4", text)) >= 18 - 6
     m = re.search(r"^(_ZN\S*%s\S*):[^\n]*\n(.*?)^\s*\.size\s" % re.escape(frag), gemm9h_asm, re.S | re.M)
     assert "scratch_" not in m.group(2)
+
+
+@pytest.fixture(scope="module")
+def attn64_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not present")
+    out = str(tmp_path_factory.mktemp("isa_attn") / "pv_attn64.s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "pytorchvideo_amd", "csrc"), "-S", "--cuda-device-only", "-o", out,
+                           os.path.join(ROOT, "pytorchvideo_amd", "csrc", "pv_attn64.hip")], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _loop_with_mfmas(asm, mangled_fragment):
+    """Every basic block LLVM attributes to the kernel's loop (label on the header line itself: `.LBBn_m: ; =>This Inner Loop
+    Header`), cold blocks placed behind the back edge included."""
+    m = re.search(r"^(_ZN\S*%s\S*):[^\n]*\n(.*?)^\s*\.size\s" % re.escape(mangled_fragment), asm, re.S | re.M)
+    assert m, "kernel %s not found" % mangled_fragment
+    lines = m.group(2).split("\n")
+    for i, l in enumerate(lines):
+        if "Inner Loop Header" in l and l.startswith(".LBB"):
+            lab = l.split(":")[0][2:]            # BBn_m
+            idx = [j for j, x in enumerate(lines) if ("Header=" + lab + " ") in x]
+            end = (idx[-1] if idx else i) + 1    # (a single-block loop has no "in Loop" lines)
+            while end < len(lines) and not re.match(r"^\.LBB\d+_\d+:", lines[end]):
+                end += 1
+            body = lines[i:end]
+            if sum("v_mfma" in x for x in body) > 0:
+                return body
+    raise AssertionError("no loop with MFMAs in %s" % mangled_fragment)
+
+
+def _num_agpr(asm, mangled_fragment):
+    m = re.search(r"\.set\s+\S*%s\S*\.num_agpr,\s*(\d+)" % re.escape(mangled_fragment), asm)
+    assert m
+    return int(m.group(1))
+
+
+def test_attention_one_wave_form_keeps_its_tile_loop_free_of_accumulator_copies_and_scratch(attn64_asm):
+    """csrc/pv_attn64.hip, the form with 64 query rows per wave (NQB = 2, one wave per SIMD, ~500 registers): what round 6 had
+    to fight for, asserted on the emitted code -- the S^T MFMAs write arithmetic registers (inline assembly), O^T stays in
+    the accumulator half, and the two tile steps of the loop carry NO v_accvgpr_read/write (each would be an issue slot of an
+    issue-bound loop: the first version spent 128 of them per step) and no scratch access; a step holds 48 MFMAs, its 64
+    exponentials and 24 transpose reads of V."""
+    frag = "attn_w64_kernelILi96ELi2ELi4ELi0EE"
+    meta = _meta(attn64_asm, frag)
+    assert meta["private_segment_fixed_size"] == 0 and meta["vgpr_spill_count"] == 0
+    assert _num_agpr(attn64_asm, frag) >= 96 + 48  # O^T (96) and Q (48) at least
+    body = _loop_with_mfmas(attn64_asm, frag)
+    # the common path: everything of the loop outside the cold blocks (the rescale block and the ragged-tile mask are placed
+    # behind the loop's back edge by __builtin_expect; they are the only places that may touch accumulator registers by hand)
+    text = "\n".join(body)
+    hot = text
+    assert len(re.findall(r"v_mfma_f32_32x32x16_bf16", hot)) >= 96
+    assert len(re.findall(r"ds_read_b64_tr_b16", hot)) >= 48
+    assert len(re.findall(r"v_exp_f32", hot)) >= 128
+    assert "scratch_" not in text
+    # accumulator copies only inside the rescale block (4 reads + 4 writes per group of four registers, 24 groups per q block)
+    n_copy = len(re.findall(r"v_accvgpr_(read|write)_b32", text))
+    assert n_copy <= 2 * 2 * 96 * 2, n_copy        # two steps x two q blocks x 96 registers x (read + write), all in cold blocks
+    # ... and none between a step's first MFMA and its barrier (the straight-line phase 1)
+    for seg in re.split(r"s_barrier", text)[:-1]:
+        tail = seg.rsplit("s_cbranch", 1)[-1]      # from the last branch before the barrier = phase 1 of a step
+        if "v_mfma" in tail:
+            assert "v_accvgpr" not in tail
+
+
+@pytest.mark.parametrize("frag", ["attn_w64_kernelILi96ELi1ELi8ELi0EE", "attn_w64_kernelILi96ELi1ELi4ELi0EE"])
+def test_attention_two_wave_forms_use_no_accumulator_registers(attn64_asm, frag):
+    """The 256-register forms (32 query rows per wave, two waves per SIMD): a single "a" constraint makes hipcc split the
+    wave's 256 registers 128 / 128 and spill the arithmetic half -- they must compile without accumulator registers, and
+    their tile loop without scratch."""
+    meta = _meta(attn64_asm, frag)
+    assert _num_agpr(attn64_asm, frag) == 0 and meta["vgpr_count"] <= 256
+    body = "\n".join(_loop_with_mfmas(attn64_asm, frag))
+    assert "scratch_" not in body and "v_accvgpr" not in body
+    assert len(re.findall(r"v_mfma_f32_32x32x16_bf16", body)) >= 48
