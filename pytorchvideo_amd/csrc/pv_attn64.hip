@@ -592,8 +592,8 @@ template <int NQB, int NW> int launch_w64(const pv_attention_desc& d, hipStream_
   const long total = (long)d.B * d.heads * nqb;
   if (total <= 0 || total > 0x7fffffffL) return PV_ERR_UNSUPPORTED;
 #ifdef PV_DEV_ABLATION
-  if (NQB == 2) switch (pv_tune("attn_abl", 0)) {
-#define PV_ABL_CASE(a) case a: PV_LAUNCH((attn_w64_kernel<96, 2, 4, a>), dim3((unsigned)total), dim3(256), 0, s, d, nqb, (int)total); PV_LAUNCH_CHECK(); return PV_OK;
+  if (NW == 4) switch (pv_tune("attn_abl", 0)) {
+#define PV_ABL_CASE(a) case a: PV_LAUNCH((attn_w64_kernel<96, NQB, 4, a>), dim3((unsigned)total), dim3(256), 0, s, d, nqb, (int)total); PV_LAUNCH_CHECK(); return PV_OK;
     PV_ABL_CASE(1) PV_ABL_CASE(2) PV_ABL_CASE(4) PV_ABL_CASE(8) PV_ABL_CASE(16) PV_ABL_CASE(32) PV_ABL_CASE(64) PV_ABL_CASE(24) PV_ABL_CASE(65) PV_ABL_CASE(103)
 #undef PV_ABL_CASE
     default: break;

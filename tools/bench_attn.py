@@ -45,8 +45,9 @@ if __name__ == "__main__":
     # A/B of the two bf16 kernels: attn_w64=0 routes to attn_pipe_kernel (pv_attn.hip), 1 to attn_w64_kernel (pv_attn64.hip)
     # (dev library, PV_MI355X_LIB=.../_lib/dev/libpv_mi355x.so: "abl<bits>" selects a timing-only ablation of attn_w64_kernel)
     for arg in (sys.argv[1:] or ["0", "1"]):
-        if arg.startswith("abl"):
-            L.tune(attn_w64=1, attn_abl=int(arg[3:]))
+        if arg.startswith("abl"):      # abl<bits> (form 1) or abl<bits>f<form>
+            bits, _, form = arg[3:].partition("f")
+            L.tune(attn_w64=int(form or 1), attn_abl=int(bits))
         else:
             L.tune(attn_w64=int(arg))
         print("attn_w64 = %s" % arg)
