@@ -763,7 +763,9 @@ def _main(out):
         torch.cuda.empty_cache()
         secondary = {}
         for w2 in (("mvit_b_32x3", "slowfast_r50", "x3d_l") if world == 1 else ("mvit_b_32x3", "x3d_l")):
-            r2, m2, x2, _ = run_workload(w2, args, world, rank, device, max(10, args.steps // 2), 3,
+            # (the same K timed steps and W warm-up steps as the headline leg: with 10 steps behind 3 warm-up replays one slow
+            #  replay -- 20 ms among 5.4 ms ones, X3D-L, profiles/r6/bench_default_line.json -- moved a leg's mean by 20 %)
+            r2, m2, x2, _ = run_workload(w2, args, world, rank, device, max(10, args.steps), max(3, args.warmup),
                                          sustained_s=0.0 if args.no_sustained else 1.0)
             roof2 = None
             if rank == 0 or world == 1:
