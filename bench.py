@@ -42,7 +42,9 @@ WORKLOADS = {
                   desc="create_x3d(input_clip_length=16,input_crop_size=224) [B,3,16,224,224]"),
     "x3d_l": dict(batch=32, gflop=18.325, mb=604.0, bound="hbm", streams=2,
                   desc="create_x3d(16,224,depth_factor=5.0) [B,3,16,224,224]"),
-    "slowfast_r50": dict(batch=16, gflop=131.42, mb=740.0, bound="mfma",
+    # (two branches since round 6: 2673 -> 2716 clips/s over three interleaved pairs, profiles/r6/model_ab_slowfast_streams_call90.txt;
+    #  rounds 2-5 measured +-0 and kept one plan)
+    "slowfast_r50": dict(batch=16, gflop=131.42, mb=740.0, bound="mfma", streams=2,
                          desc="create_slowfast(model_depth=50) slow [B,3,8,256,256] + fast [B,3,32,256,256]"),
     "mvit_b_32x3": dict(batch=8, gflop=339.92, mb=1465.0, bound="mfma", streams=2,
                         desc="create_multiscale_vision_transformers(**mvit_video_base_32x3_config) [B,3,32,224,224]"),
