@@ -8,7 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = [("x3d_m", "X3D-M 16×224², b=32 (`configs[1]`, bench default; 2 branches)"),
          ("mvit_b_32x3", "MViT-B 32×3 224², b=8 (`configs[3]`; 2 branches)"),
-         ("slowfast_r50", "SlowFast-R50 8×8 256², b=16 (`configs[2]`)"),
+         ("slowfast_r50", "SlowFast-R50 8×8 256², b=16 (`configs[2]`; 2 branches)"),
          ("x3d_l", "X3D-L 16×224², b=32 per GPU (`configs[4]`, one GPU of the eight)")]
 
 
