@@ -550,7 +550,10 @@ int pv_gemm9h_try(const pv_conv3d_desc& d, bool pw, hipStream_t s) {
     // (the 256 x 256 kernel is the better one wherever ITS tiles fill the chip: pv_gemm9_try asks this kernel only below that
     // or where 256-channel tiles would be mostly padding)
     if ((tr ? waste128 : waste256) > 0.15) return PV_ERR_UNSUPPORTED;
-    if (total < (tr ? pv_tune("gemm9h_tr_min_tiles", 200) : pv_tune("gemm9h_min_tiles", 96))) return PV_ERR_UNSUPPORTED;
+    // measured in the two-branch bench forms (profiles/r6/model_ab_gemm9h_min_tiles_call95.txt): 96 -> 32 is +3 % on SlowFast-R50
+    // (res5's layers at 8 clips per branch: 64 / 32 tiles, still ahead of the 128 x 128 kernel on a quarter of the chip),
+    // transposed 200 -> 100 +2.5 % on MViT-B, +-0 on SlowFast-R50
+    if (total < (tr ? pv_tune("gemm9h_tr_min_tiles", 100) : pv_tune("gemm9h_min_tiles", 32))) return PV_ERR_UNSUPPORTED;
   }
   const bool rows = pw && d.x_bs == (long)d.To * d.Ho * d.Wo * d.ldx;
 #define PVH_GO(PWv, YFv)                                                \
