@@ -125,12 +125,26 @@ typedef struct pv_conv3d_desc {
   const float* x2_scale;     /* [cout] or NULL (=1) */
   int64_t x2_bs;
   int32_t x2_ld, x2_cin, x2_Hi, x2_Wi, x2_st, x2_sh, x2_sw;
+  /* Optional pointwise conv BEHIND this conv in the same launch (round 6) -- conv_b -> conv_c of a ResNet / SlowFast
+   * bottleneck (BottleneckBlock.forward, models/resnet.py:1345-1365; block built by create_bottleneck_block,
+   * models/resnet.py:98-132): when pw2_w is set
+   *   m = bf16(act(scale * conv(x) + shift))                       (conv_b + norm_b + act_b: `cout` channels, never stored)
+   *   y = pw2_act(pw2_scale * (W2 . m) + pw2_shift + residual)     (conv_c + norm_c + the block's residual join + final act)
+   * y, residual, ldy, ldr, y_bs, r_bs describe the pw2_cout-channel output; `act` is the inner activation.  W2 is
+   * [pw2_cout][round_up(cout,8)] in `dtype`.  The rounding of m is the one the unfused pair has at the tensor it stores.
+   * bf16 only, narrow first convs (the tap-streaming kernel's range) where pv_conv3d_pw2_supported(d) is 1. */
+  const void* pw2_w;
+  const float* pw2_scale;    /* [pw2_cout] or NULL (=1) */
+  const float* pw2_shift;    /* [pw2_cout] or NULL (=0) */
+  int32_t pw2_cout, pw2_act;
 } pv_conv3d_desc;
 int pv_conv3d(const pv_conv3d_desc* d, pv_stream_t stream);
 /* 1 if this geometry (pointers are ignored) can run with the fused temporal conv, else 0 */
 int pv_conv3d_dwt_supported(const pv_conv3d_desc* d);
 /* 1 if this geometry (pointers are ignored; x2_cin > 0) can run with the second K operand, else 0 */
 int pv_conv3d_x2_supported(const pv_conv3d_desc* d);
+/* 1 if this geometry (pointers are ignored; pw2_cout > 0) can run with the pointwise conv behind it, else 0 */
+int pv_conv3d_pw2_supported(const pv_conv3d_desc* d);
 
 /* ---- development knobs ---------------------------------------------------------------------
  * Kernel-routing choices that were settled by A/B measurements on the MI355X stay overridable for the tools

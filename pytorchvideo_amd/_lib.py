@@ -39,7 +39,8 @@ Conv3dDesc = _struct("Conv3dDesc", [
             "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "act", "a_act", "dtype", "y_f32", "r_f32")
     + [("dwt_w", _p)] + _ints("dwt_k", "c4_wpair") + [("pos_spatial", _p), ("pos_temporal", _p)]
     + _ints("dil_t", "dil_h", "dil_w")
-    + [("x2", _p), ("x2_scale", _p), ("x2_bs", _i64)] + _ints("x2_ld", "x2_cin", "x2_Hi", "x2_Wi", "x2_st", "x2_sh", "x2_sw"))
+    + [("x2", _p), ("x2_scale", _p), ("x2_bs", _i64)] + _ints("x2_ld", "x2_cin", "x2_Hi", "x2_Wi", "x2_st", "x2_sh", "x2_sw")
+    + [("pw2_w", _p), ("pw2_scale", _p), ("pw2_shift", _p)] + _ints("pw2_cout", "pw2_act"))
 
 DwConv3dDesc = _struct("DwConv3dDesc", [
     ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("psum", _p),
@@ -134,6 +135,7 @@ _SYMBOLS = [
     ("pv_conv3d", C.c_int, [C.POINTER(Conv3dDesc), _p]),
     ("pv_conv3d_dwt_supported", C.c_int, [C.POINTER(Conv3dDesc)]),
     ("pv_conv3d_x2_supported", C.c_int, [C.POINTER(Conv3dDesc)]),
+    ("pv_conv3d_pw2_supported", C.c_int, [C.POINTER(Conv3dDesc)]),
     ("pv_dwconv3d", C.c_int, [C.POINTER(DwConv3dDesc), _p]),
     ("pv_dwconv3d_psum_blocks", C.c_int, [C.POINTER(DwConv3dDesc)]),
     ("pv_dwconv3d_pw_supported", C.c_int, [C.POINTER(DwConv3dDesc)]),
@@ -187,7 +189,7 @@ _SYMBOLS = [
     ("pv_forward_gather", C.c_int, [_p, _p, _p, C.POINTER(GatherSrc), C.c_int, _p, _p, _p]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SYMBOLS]
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 _lib = None
 

@@ -570,6 +570,96 @@ def emit_conv_b(sess, conv_b, x, norm_b, act_b, producer=None):
     return y, None, L.ACT_NONE
 
 
+def _conv_bc_desc(sess, bb, a, residual, out):
+    """Geometry of conv_b -> conv_c as ONE pv_conv3d (pw2_* fields), or None when the pair is not of that shape."""
+    conv_b, conv_c = bb.conv_b, bb.conv_c
+    if not isinstance(conv_b, nn.Conv3d) or not isinstance(conv_c, nn.Conv3d) or sess.itemsize != 2 or a.f32:
+        return None
+    if conv_b.padding_mode != "zeros" or isinstance(conv_b.padding, str) or conv_c.padding_mode != "zeros" \
+            or isinstance(conv_c.padding, str):
+        return None
+    bn, se = _split_norm_b(bb.norm_b)
+    if se is not None or conv_b.groups != 1 or tuple(conv_b.dilation) != (1, 1, 1) or conv_b.in_channels != a.C:
+        return None
+    if conv_c.kernel_size != (1, 1, 1) or tuple(conv_c.stride) != (1, 1, 1) or _triple(conv_c.padding) != (0, 0, 0) \
+            or conv_c.groups != 1 or conv_c.in_channels != conv_b.out_channels:
+        return None
+    if a.ld < pad8(a.C) or (residual is not None and residual.f32):
+        return None
+    kt, kh, kw = conv_b.kernel_size
+    st, sh, sw = conv_b.stride
+    pt, ph, pw = _triple(conv_b.padding)
+    To, Ho, Wo = _conv_out(a.T, kt, st, pt), _conv_out(a.H, kh, sh, ph), _conv_out(a.W, kw, sw, pw)
+    if min(To, Ho, Wo) <= 0 or kt * kh * kw == 1:
+        return None
+    cout2 = conv_c.out_channels
+    if out is not None:
+        if (out.B, out.T, out.H, out.W, out.C) != (a.B, To, Ho, Wo, cout2) or out.f32:
+            return None
+        ldy, y_bs = out.ld, out.bs
+    else:
+        ldy, y_bs = pad8(cout2), To * Ho * Wo * pad8(cout2)
+    if residual is not None and ((residual.B, residual.T, residual.H, residual.W, residual.C) != (a.B, To, Ho, Wo, cout2)
+                                 or residual.ld != ldy or residual.bs != y_bs):
+        return None
+    return dict(x_bs=a.bs, y_bs=y_bs, r_bs=y_bs if residual is not None else 0, ldx=a.ld, ldy=ldy,
+                ldr=ldy if residual is not None else 0, B=a.B, Ti=a.T, Hi=a.H, Wi=a.W, cin=pad8(a.C), To=To, Ho=Ho, Wo=Wo,
+                cout=conv_b.out_channels, kt=kt, kh=kh, kw=kw, st=st, sh=sh, sw=sw, pt=pt, ph=ph, pw=pw,
+                dtype=sess.pv_dtype, pw2_cout=cout2)
+
+
+def can_fuse_conv_bc(sess, bb, a, residual, out, shortcut):
+    """True when conv_b (a narrow dense conv: the tap-streaming kernel's range) and the pointwise conv_c behind it can
+    run as one launch (csrc/pv_lateral.hip, PW2 mode): conv_b's output stays in registers as conv_c's MFMA operand.
+    Decided by the library from the geometry."""
+    if not tuning.get("fuse_bc") or shortcut is not None:
+        return False
+    g = _conv_bc_desc(sess, bb, a, residual, out)
+    if g is None:
+        return False
+    d = L.Conv3dDesc()
+    for k, v in g.items():
+        setattr(d, k, v)
+    return L.lib().pv_conv3d_pw2_supported(C.byref(d)) == 1
+
+
+def emit_fused_conv_bc(sess, bb, a, residual, final_act, out=None):
+    """conv_b + norm_b + act_b -> conv_c + norm_c + residual + final activation as one pv_conv3d (pw2_* fields).  The
+    inner tensor is rounded to bf16 exactly where the unfused pair stores it, so the arithmetic is the pair's."""
+    g = _conv_bc_desc(sess, bb, a, residual, out)
+    conv_b, conv_c = bb.conv_b, bb.conv_c
+    bn, _ = _split_norm_b(bb.norm_b)
+    cb, cc, cin_p = conv_b.out_channels, conv_c.out_channels, pad8(a.C)
+    taps = g["kt"] * g["kh"] * g["kw"]
+    y = out if out is not None else sess.alloc_act(a.B, g["To"], g["Ho"], g["Wo"], cc)
+    wb = torch.zeros(cb, taps, cin_p, dtype=torch.float32)
+    wb[:, :, : a.C] = conv_b.weight.detach().float().cpu().permute(0, 2, 3, 4, 1).reshape(cb, taps, a.C)
+    wc = torch.zeros(cc, pad8(cb), dtype=torch.float32)
+    wc[:, :cb] = conv_c.weight.detach().float().cpu().reshape(cc, cb)
+    scale_b, shift_b = fold_norm(bn, cb, conv_b.bias)
+    scale_c, shift_c = fold_norm(bb.norm_c, cc, conv_c.bias)
+    aff_b = bn is not None and not isinstance(bn, nn.Identity)
+    aff_c = bb.norm_c is not None and not isinstance(bb.norm_c, nn.Identity)
+    f = dict(g)
+    f.update(x=a.ptr, w=sess.add_weight(wb.to(sess.dtype)), y=y.ptr,
+             scale=sess.add_weight(scale_b) if aff_b else None,
+             shift=sess.add_weight(shift_b) if (aff_b or conv_b.bias is not None) else None,
+             residual=residual.ptr if residual is not None else None,
+             act=act_code(bb.act_b), a_act=L.ACT_NONE,
+             pw2_w=sess.add_weight(wc.to(sess.dtype)),
+             pw2_scale=sess.add_weight(scale_c) if aff_c else None,
+             pw2_shift=sess.add_weight(shift_c) if (aff_c or conv_c.bias is not None) else None,
+             pw2_act=final_act)
+    vox_in, vox_out = a.B * a.voxels, y.B * y.voxels
+    alg = sess.itemsize * (vox_in * cin_p + cb * taps * cin_p + cc * pad8(cb) + vox_out * pad8(cc)
+                           + (vox_out * pad8(cc) if residual is not None else 0))
+    flops = 2 * vox_out * (cb * taps * a.C + cc * cb)
+    sess.add_op(L.OP_CONV3D, f, label="conv_bc|%dx%dx%dx%d c%d->%d->%d k%dx%dx%d s%d%d%d+k1x1x1" % (
+        a.B, g["To"], g["Ho"], g["Wo"], a.C, cb, cc, g["kt"], g["kh"], g["kw"], g["st"], g["sh"], g["sw"]),
+        alg_bytes=alg, flops=flops)
+    return y
+
+
 def emit_bottleneck(sess, bb, x, residual=None, final_act=L.ACT_NONE, out=None, shortcut=None):
     """BottleneckBlock.forward (resnet.py:1345-1365) with the block's residual join and
     final activation fused into conv_c's epilogue."""
@@ -585,6 +675,11 @@ def emit_bottleneck(sess, bb, x, residual=None, final_act=L.ACT_NONE, out=None, 
                                         producer=(bb.conv_a, bb.norm_a, act_code(bb.act_a)))
     else:
         a = emit_conv(sess, bb.conv_a, x, bb.norm_a, act_code(bb.act_a), label="conv_a")
+        if can_fuse_conv_bc(sess, bb, a, residual, out, shortcut):
+            # conv_b -> conv_c in one pass: the inner tensor never leaves the registers (csrc/pv_lateral.hip, PW2 mode)
+            c = emit_fused_conv_bc(sess, bb, a, residual, final_act, out=out)
+            sess.release(a)
+            return c
         b, gate, deferred = emit_conv_b(sess, bb.conv_b, a, bb.norm_b, bb.act_b)
         sess.release(a)
     check_conv3d(bb.conv_c)

@@ -9,6 +9,7 @@ OPTIONS = {
     "fuse_ab": True,             # conv_a evaluated inside the depthwise conv_b kernel             (emit.can_fuse_pointwise_into_dw)
     "fuse_ab_max_cin": 64,       # ... while the block input has at most this many channels
     "fuse_block": True,          # a whole X3D residual block without squeeze-excitation as ONE launch (pv_bottleneck, round 6)  (emit.can_fuse_bottleneck)
+    "fuse_bc": True,             # conv_b (narrow dense conv) -> pointwise conv_c of a ResNet / SlowFast bottleneck as ONE launch (pv_conv3d pw2_*, round 6)  (emit.can_fuse_conv_bc)
     "fuse_stem": True,           # X3D stem (conv_xy + temporal depthwise + BN + ReLU) in one launch
     "fuse_kv_pool": True,        # MViT pool_k + pool_v as one depthwise launch                   (emit_mvit)
     "fuse_posenc": True,         # position tables added in the patch-embedding conv's epilogue   (emit_mvit)

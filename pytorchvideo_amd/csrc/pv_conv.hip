@@ -22,7 +22,7 @@ int pv_gemm_glds_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);  // pv_ge
 int pv_head_rows_try(const pv_conv3d_desc& d, hipStream_t s);              // pv_headgemm.hip
 int pv_gemm8_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);      // pv_gemm8.hip
 int pv_gemm9_try(const pv_conv3d_desc& d, bool pw, hipStream_t s);      // pv_gemm9.hip
-int pv_tapstream_try(const pv_conv3d_desc& d, hipStream_t s);           // pv_lateral.hip
+int pv_tapstream_try(const pv_conv3d_desc& d, hipStream_t s, bool dry = false);   // pv_lateral.hip
 int pv_stem_c4(const pv_conv3d_desc& d, hipStream_t s);                 // pv_stem.hip
 int pv_stem_dwt_supported(const pv_conv3d_desc& d);                     // pv_stem.hip
 int pv_pwconv_x2_supported(const pv_conv3d_desc& d);                    // pv_pwconv.hip
@@ -378,6 +378,12 @@ extern "C" int pv_conv3d_dwt_supported(const pv_conv3d_desc* d) {
   return pv_stem_dwt_supported(*d);
 }
 
+extern "C" int pv_conv3d_pw2_supported(const pv_conv3d_desc* d) {
+  if (!d || d->B <= 0 || d->cin <= 0 || d->cout <= 0 || d->pw2_cout <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
+  if (d->kt < 1 || d->kh < 1 || d->kw < 1 || d->kt * d->kh * d->kw == 1) return 0;   // a pointwise pair is the x2 / streaming kernels' work
+  return pv_tapstream_try(*d, nullptr, true) == PV_OK;
+}
+
 extern "C" int pv_conv3d_x2_supported(const pv_conv3d_desc* d) {
   if (!d || d->B <= 0 || d->cout <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
   if (d->kt * d->kh * d->kw != 1 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt || d->ph || d->pw) return 0;
@@ -411,6 +417,10 @@ extern "C" int pv_conv3d(const pv_conv3d_desc* dp, pv_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (c4) return pv_stem_c4(d, s);
   if (d.dwt_w || d.pos_spatial || d.pos_temporal) return PV_ERR_UNSUPPORTED;   // first-layer layout only
+  if (d.pw2_w) {   // a pointwise conv behind this one: the tap-streaming kernel only, no fallback
+    if (pw || d.x2 || d.pw2_cout <= 0 || d.dtype != PV_BF16) return PV_ERR_UNSUPPORTED;
+    return pv_tapstream_try(d, s);
+  }
   if (d.x2) {   // second K operand: streaming pointwise kernel only, no fallback
     if (!pw || d.dtype != PV_BF16 || !pv_pwconv_x2_supported(d)) return PV_ERR_UNSUPPORTED;
     return pv_pwconv_stream_try(d, s);

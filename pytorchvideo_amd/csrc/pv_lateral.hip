@@ -40,6 +40,11 @@ struct TapConv {       // the convolution the kernel evaluates (a lateral connec
   int To, Ho, Wo, cout;
   int kt, kh, kw, st, sh, sw, pt, ph, pw;
   int act;
+  // a pointwise conv behind this one in the same launch (pv_conv3d_desc.pw2_*: conv_b -> conv_c of a bottleneck): then y,
+  // y_bs, ldy and the residual describe ITS cout2-channel output, and this conv's own output exists only as MFMA operands
+  const void* w2; const float* scale2; const float* shift2; const void* r;
+  long r_bs;
+  int ldr, cout2, act2;
 };
 
 struct LatTile {
@@ -50,8 +55,14 @@ struct LatTile {
 };
 
 // NT: 16-channel MFMA row tiles per workgroup (slab = NT * 16 output channels); TM: voxel tiles per wave tile
-template <int NT, int TM>
-__global__ __launch_bounds__(kLatThreads) void tap_stream_kernel(const TapConv d, int ksteps, int ngroups,
+// PW2: a pointwise conv behind the tap conv (conv_b -> conv_c of a bottleneck).  The epilogue's registers -- lane (n16, q) holds
+// channels 32 p + 8 q .. + 7 of voxel n16 after BatchNorm and the activation, rounded to bf16 -- ARE the B operand of a
+// 16 x 16 x 32 MFMA for K step p of the second product, so the inner tensor goes from accumulators to operands without
+// leaving the lane: no LDS exchange, no HBM round trip.  W2 sits in LDS behind the first slab (rows permuted the same way, so
+// the second epilogue again owns 8 consecutive channels per lane); the second product runs 32 output channels at a time with
+// the residual of the next 32 requested before the MFMAs of the current ones.  nsplit is 1 in this mode.
+template <int NT, int TM, bool PW2>
+__global__ __launch_bounds__(kLatThreads, (PW2 && NT == 2) ? 4 : 1) void tap_stream_kernel(const TapConv d, int ksteps, int ngroups,
                                                                    int nchunks, int nsplit, int xcont) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int Kp = ksteps * 32;
@@ -60,6 +71,12 @@ __global__ __launch_bounds__(kLatThreads) void tap_stream_kernel(const TapConv d
   float* sc_s = reinterpret_cast<float*>(smem_raw + (size_t)NT * 16 * WLD * 2);
   float* sh_s = sc_s + NT * 16;
   int2* tap_s = reinterpret_cast<int2*>(sh_s + NT * 16);   // [ksteps][4]: (dt | dh << 8 | dw << 16, byte offset of tap + channel)
+  // PW2: [pairs2 * 32][W2LD] weights, then scale / shift of the second conv
+  constexpr int W2LD = NT * 16 + 8;
+  const int pairs2 = PW2 ? (pv_round_up(d.cout2, 8) + 31) / 32 : 0;
+  bf16_t* w2_s = reinterpret_cast<bf16_t*>(smem_raw + (((size_t)NT * 16 * WLD * 2 + (size_t)2 * NT * 16 * 4 + (size_t)ksteps * 4 * 8 + 15) & ~(size_t)15));
+  float* sc2_s = reinterpret_cast<float*>(w2_s + (size_t)pairs2 * 32 * W2LD);
+  float* sh2_s = sc2_s + pairs2 * 32;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -108,6 +125,24 @@ __global__ __launch_bounds__(kLatThreads) void tap_stream_kernel(const TapConv d
                                              (unsigned)d.ldx * 2u + (unsigned)c * 2u)}
                             : int2{-1, 0};
     }
+    if constexpr (PW2) {
+      const bf16_t* __restrict__ W2 = static_cast<const bf16_t*>(d.w2);
+      const int K2 = cout_p8;              // W2 is [cout2][round_up(cout, 8)]
+      constexpr int cpr2 = NT * 16 / 8;
+      for (int id = tid; id < pairs2 * 32 * cpr2; id += kLatThreads) {
+        const int r = id / cpr2, kc = id - r * cpr2;
+        const int tn = r >> 4, ii = r & 15;
+        const int c = (tn >> 1) * 32 + (ii >> 2) * 8 + (tn & 1) * 4 + (ii & 3);
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (c < d.cout2 && kc * 8 < K2) v = *reinterpret_cast<const bf16x8*>(W2 + (long)c * K2 + kc * 8);
+        *reinterpret_cast<bf16x8*>(w2_s + r * W2LD + kc * 8) = v;
+      }
+      for (int i = tid; i < pairs2 * 32; i += kLatThreads) {
+        const bool ok = i < d.cout2;
+        sc2_s[i] = ok ? (d.scale2 ? d.scale2[i] : 1.f) : 0.f;
+        sh2_s[i] = ok ? (d.shift2 ? d.shift2[i] : 0.f) : 0.f;
+      }
+    }
   }
   __syncthreads();
 
@@ -117,6 +152,9 @@ __global__ __launch_bounds__(kLatThreads) void tap_stream_kernel(const TapConv d
       const_cast<void*>(d.x), 0, (int)((unsigned)d.B * (unsigned)d.x_bs * 2u), 0x00020000);
   __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
       d.y, 0, (int)((unsigned)d.B * (unsigned)d.y_bs * 2u), 0x00020000);
+  const bool has_r = PW2 && d.r != nullptr;
+  __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(has_r ? d.r : d.x), 0, has_r ? (int)((unsigned)d.B * (unsigned)d.y_bs * 2u) : 0, 0x00020000);
   const int live_pairs = min(NT / 2, (cout_p8 - n0 + 31) / 32);   // wave-uniform
   constexpr int NP = NT / 2;
   constexpr int NWV = kLatThreads / 64;
@@ -178,6 +216,13 @@ __global__ __launch_bounds__(kLatThreads) void tap_stream_kernel(const TapConv d
       for (int i = 0; i < TM; ++i) xf[i] = xn[i];
     }
     // ---- epilogue: lane (n16, q) owns channels n0 + 32 p + 8 q .. + 7 of its voxel ----
+    bf16x8 mid[PW2 ? NP : 1][TM];
+    if constexpr (PW2) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) mid[p][i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       if (p >= live_pairs) break;
@@ -202,9 +247,77 @@ __global__ __launch_bounds__(kLatThreads) void tap_stream_kernel(const TapConv d
         bf16x8 ob;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ob[j] = (bf16_t)v[j];
-        const bool ok = cur[i].ok && c0 < cout_p8;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), ry,
-                                               (int)(ok ? cur[i].yoff + (unsigned)cl * 2u : kOOB), 0, 0);
+        if constexpr (PW2) {
+          mid[p][i] = ob;      // channels past cout are zeros (zero weights, zero shift, zeroed above)
+        } else {
+          const bool ok = cur[i].ok && c0 < cout_p8;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), ry,
+                                                 (int)(ok ? cur[i].yoff + (unsigned)cl * 2u : kOOB), 0, 0);
+        }
+      }
+    }
+    if constexpr (PW2) {
+      // ---- the second product, 32 output channels per pass; lane (n16, q) owns channels 32 p2 + 8 q .. + 7 of its voxel ----
+      const int cout2_p8 = pv_round_up(d.cout2, 8);
+      u32x4 rq[TM], rn[TM];
+      auto load_r = [&](u32x4 (&dst)[TM], int p2) {
+        const int c0 = p2 * 32 + q * 8;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          dst[i] = __builtin_amdgcn_raw_buffer_load_b128(
+              rr, (int)(has_r && p2 < pairs2 && cur[i].ok && c0 < cout2_p8 ? cur[i].yoff + (unsigned)c0 * 2u : kOOB), 0, 0);
+      };
+      // (the residual has the output's strides: one offset serves both.  The narrow variant runs four waves per SIMD and
+      // requests a pass's residual at the top of the pass; the wide one, two waves per SIMD, one pass ahead)
+      constexpr bool kAhead = NT > 2;
+      if (kAhead) load_r(rq, 0);
+      for (int p2 = 0; p2 < pairs2; ++p2) {
+        if (kAhead) load_r(rn, p2 + 1);
+        else load_r(rq, p2);
+        f32x4 a2[2][TM];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a2[h][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sp = 0; sp < NP; ++sp) {
+          if (sp >= live_pairs) break;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w2_s + ((p2 * 2 + h) * 16 + n16) * W2LD + sp * 32 + q * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a2[h][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, mid[sp][i], a2[h][i], 0, 0, 0);
+          }
+        }
+        const int cl = p2 * 32 + q * 8;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc2_s + cl), s1 = *reinterpret_cast<const f32x4*>(sc2_s + cl + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh2_s + cl), h1 = *reinterpret_cast<const f32x4*>(sh2_s + cl + 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          float v[8];
+          const bf16x8 rb = __builtin_bit_cast(bf16x8, rq[i]);   // zeros where there is no residual (out-of-range read)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = a2[0][i][j] * s0[j] + h0[j] + (float)rb[j];
+            v[4 + j] = a2[1][i][j] * s1[j] + h1[j] + (float)rb[4 + j];
+          }
+          pv_apply_act_n<true>(v, d.act2);
+          if (cl + 8 > d.cout2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (cl + j >= d.cout2) v[j] = 0.f;
+          }
+          bf16x8 ob;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ob[j] = (bf16_t)v[j];
+          const bool ok = cur[i].ok && cl < cout2_p8;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ob), ry,
+                                                 (int)(ok ? cur[i].yoff + (unsigned)cl * 2u : kOOB), 0, 0);
+        }
+        if (kAhead) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) rq[i] = rn[i];
+        }
       }
     }
 #pragma unroll
@@ -212,12 +325,13 @@ __global__ __launch_bounds__(kLatThreads) void tap_stream_kernel(const TapConv d
   }
 }
 
-template <int NT, int TM>
+template <int NT, int TM, bool PW2 = false>
 int launch_lateral(const TapConv& d, int ksteps, size_t lds, int xcont, hipStream_t s) {
   const long M = (long)d.B * d.To * d.Ho * d.Wo;
   const long ngroups = pv_ceil_div(M, (kLatThreads / 64) * TM * 16);
   const int nsplit = (int)pv_ceil_div(pv_round_up(d.cout, 8), NT * 16);
-  auto kern = tap_stream_kernel<NT, TM>;
+  if (PW2 && nsplit != 1) return PV_ERR_UNSUPPORTED;
+  auto kern = tap_stream_kernel<NT, TM, PW2>;
   if (lds > 64 * 1024)
     PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // one resident generation of workgroups; the rest is the grid-stride loop (the slab is staged once per workgroup)
@@ -236,7 +350,8 @@ int launch_lateral(const TapConv& d, int ksteps, size_t lds, int xcont, hipStrea
 // xcont: chunk -> XCD mapping (see the kernel).  Contiguous runs for the convolutions (same-box A/B on SlowFast-R50: the fast
 // pathway's res4 conv_a 27 -> 17 us, res3 30 -> 28 us, model +0.6 %); the time-strided lateral connections measured 3-6 % slower
 // with it at 64^2 and equal elsewhere, and keep the round-robin deal.
-int tapstream_launch(const TapConv& d, int k_limit, int xcont, hipStream_t s) {
+// dry: geometry check only (pv_conv3d_pw2_supported), nothing is launched
+int tapstream_launch(const TapConv& d, int k_limit, int xcont, hipStream_t s, bool dry = false) {
   const int taps = d.kt * d.kh * d.kw;
   const long K = (long)taps * d.cin;
   if (K > k_limit || d.kt > 255 || d.kh > 255 || d.kw > 255) return PV_ERR_UNSUPPORTED;
@@ -247,6 +362,16 @@ int tapstream_launch(const TapConv& d, int k_limit, int xcont, hipStream_t s) {
   if (!small_offsets) return PV_ERR_UNSUPPORTED;
   int nt = cout_p8 <= 32 ? 2 : (cout_p8 <= 64 ? 4 : 8);
   auto lds_of = [&](int t) { return (size_t)t * 16 * (ksteps * 32 + 8) * 2 + (size_t)2 * t * 16 * 4 + (size_t)ksteps * 4 * 8; };
+  if (d.cout2 > 0) {
+    // the second conv's slab behind the first: the first conv must produce all of its channels in one workgroup
+    if (cout_p8 > 64 || d.cout2 > 1024 || (d.r && (d.r_bs != d.y_bs || d.ldr != d.ldy))) return PV_ERR_UNSUPPORTED;
+    const size_t pairs2 = (size_t)(pv_round_up(d.cout2, 8) + 31) / 32;
+    const size_t lds = ((lds_of(nt) + 15) & ~(size_t)15) + pairs2 * 32 * (nt * 16 + 8) * 2 + 2 * pairs2 * 32 * 4;
+    if (lds > 150 * 1024) return PV_ERR_UNSUPPORTED;
+    if (dry) return PV_OK;
+    if (nt == 2) return launch_lateral<2, 2, true>(d, ksteps, lds, xcont, s);
+    return launch_lateral<4, 2, true>(d, ksteps, lds, xcont, s);
+  }
   while (nt > 2 && lds_of(nt) > 120 * 1024) nt >>= 1;
   if (lds_of(nt) > 120 * 1024) return PV_ERR_UNSUPPORTED;
   const size_t lds = lds_of(nt);
@@ -259,11 +384,16 @@ int tapstream_launch(const TapConv& d, int k_limit, int xcont, hipStream_t s) {
 
 // Narrow dense convolutions of pv_conv3d (called before its generic kernel): bf16, no residual / gate / second operand,
 // no dilation, <= 128 output channels, K = taps * cin <= 640.  Returns PV_ERR_UNSUPPORTED for everything else.
-int pv_tapstream_try(const pv_conv3d_desc& c, hipStream_t s) {
-  if (c.dtype != PV_BF16 || c.y_f32 || c.residual || c.a_gate || c.a_act != PV_ACT_NONE || c.x2 || c.dwt_w || c.pos_spatial)
+// With pw2_w set (a pointwise conv behind it, <= 64 channels in between): the residual belongs to the second conv.
+// dry: the second-conv mode's geometry check (pv_conv3d_pw2_supported: pointers are ignored, pw2_cout > 0 selects the mode)
+int pv_tapstream_try(const pv_conv3d_desc& c, hipStream_t s, bool dry) {
+  const bool pw2 = dry ? c.pw2_cout > 0 : c.pw2_w != nullptr;
+  if (c.dtype != PV_BF16 || c.y_f32 || c.a_gate || c.a_act != PV_ACT_NONE || c.x2 || c.dwt_w || c.pos_spatial)
     return PV_ERR_UNSUPPORTED;
+  if (c.residual && (!pw2 || c.r_f32)) return PV_ERR_UNSUPPORTED;
+  if (pw2 && (c.pw2_cout <= 0 || (!dry && c.ldy < pv_round_up(c.pw2_cout, 8)))) return PV_ERR_UNSUPPORTED;
   if (c.dil_t > 1 || c.dil_h > 1 || c.dil_w > 1 || c.cin % 8 || pv_round_up(c.cout, 8) > 128) return PV_ERR_UNSUPPORTED;
-  if (!pv_tune("tapstream", 1)) return PV_ERR_UNSUPPORTED;
+  if (!pw2 && !pv_tune("tapstream", 1)) return PV_ERR_UNSUPPORTED;
   TapConv d;
   d.x = c.x; d.w = c.w; d.y = c.y; d.scale = c.scale; d.shift = c.shift;
   d.x_bs = c.x_bs; d.y_bs = c.y_bs; d.ldx = c.ldx; d.ldy = c.ldy;
@@ -271,7 +401,9 @@ int pv_tapstream_try(const pv_conv3d_desc& c, hipStream_t s) {
   d.To = c.To; d.Ho = c.Ho; d.Wo = c.Wo; d.cout = c.cout;
   d.kt = c.kt; d.kh = c.kh; d.kw = c.kw; d.st = c.st; d.sh = c.sh; d.sw = c.sw; d.pt = c.pt; d.ph = c.ph; d.pw = c.pw;
   d.act = c.act;
-  return tapstream_launch(d, 640, pv_tune("tap_xcont", 1), s);
+  d.w2 = pw2 ? c.pw2_w : nullptr; d.scale2 = c.pw2_scale; d.shift2 = c.pw2_shift; d.r = pw2 ? (dry && !c.residual && c.ldr > 0 ? static_cast<const void*>(&c) /* geometry check: a residual is announced by its strides */ : c.residual) : nullptr;
+  d.r_bs = c.r_bs; d.ldr = c.ldr; d.cout2 = pw2 ? c.pw2_cout : 0; d.act2 = c.pw2_act;
+  return tapstream_launch(d, 640, pv_tune("tap_xcont", 1), s, dry);
 }
 
 extern "C" int pv_lateral_fuse(const pv_lateral_desc* dp, pv_stream_t stream) {
@@ -293,6 +425,7 @@ extern "C" int pv_lateral_fuse(const pv_lateral_desc* dp, pv_stream_t stream) {
     d.To = l.To; d.Ho = l.H; d.Wo = l.W; d.cout = l.cout;
     d.kt = l.kt; d.kh = 1; d.kw = 1; d.st = l.st; d.sh = 1; d.sw = 1; d.pt = l.pt; d.ph = 0; d.pw = 0;
     d.act = l.act;
+    d.w2 = nullptr; d.scale2 = nullptr; d.shift2 = nullptr; d.r = nullptr; d.r_bs = 0; d.ldr = 0; d.cout2 = 0; d.act2 = 0;
     const int r = tapstream_launch(d, 256, pv_tune("lat_xcont", 0), s);
     if (r != PV_ERR_UNSUPPORTED) return r;
   }

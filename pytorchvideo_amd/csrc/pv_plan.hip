@@ -10,7 +10,7 @@
 
 namespace {
 thread_local std::string g_last_error;
-constexpr int kAbiVersion = 31;
+constexpr int kAbiVersion = 32;
 }  // namespace
 
 int pv_set_hip_error(hipError_t e, const char* what) {

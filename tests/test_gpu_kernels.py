@@ -1191,6 +1191,118 @@ def test_narrow_dense_conv_on_the_tap_streaming_kernel(B, T, H, W, cin, cout, k,
     assert rel_err(y1, y0) <= 4e-3      # the generic kernel: same products, other summation order
 
 
+# ------------------------------------------------------------------ conv_b -> conv_c in one launch (pv_conv3d pw2_*, csrc/pv_lateral.hip)
+@pytest.mark.parametrize("B,T,H,W,cin,cmid,cout2,k,stride,res,act_b", [
+    (2, 4, 16, 16, 64, 64, 256, (1, 3, 3), (1, 1, 1), True, L.ACT_RELU),    # SlowFast / ResNet res2: 64 -> 64 -> 256 + identity
+    (2, 8, 16, 16, 8, 8, 32, (1, 3, 3), (1, 1, 1), True, L.ACT_RELU),       # fast pathway res2: 8 -> 8 -> 32
+    (1, 4, 13, 11, 16, 16, 64, (1, 3, 3), (1, 1, 1), False, L.ACT_RELU),    # ragged voxel tiles, no residual
+    (2, 4, 12, 12, 32, 24, 72, (3, 1, 1), (1, 1, 1), True, L.ACT_RELU),     # inner / outer widths that are not multiples of 32
+    (1, 6, 10, 10, 64, 64, 200, (1, 3, 3), (1, 2, 2), True, L.ACT_NONE),    # strided conv_b, no inner activation, ragged last 32 channels
+    (1, 3, 9, 9, 16, 36, 20, (3, 3, 3), (1, 1, 1), False, L.ACT_RELU),      # every tap direction, 36 inner channels (8-padding inside a pair)
+])
+def test_conv_b_and_pointwise_conv_c_in_one_launch(B, T, H, W, cin, cmid, cout2, k, stride, res, act_b):
+    """pv_conv3d with pw2_*: conv_b + BN + act -> (bf16) -> conv_c + BN + residual + ReLU, the inner tensor kept in registers as
+    the second product's MFMA operand -- vs torch in fp32 with the inner tensor rounded to bf16 where the unfused pair stores
+    it, and vs the unfused pair of pv_conv3d launches."""
+    dtype = torch.bfloat16
+    pad = tuple(kk // 2 for kk in k)
+    g = torch.Generator().manual_seed(5 * cin + cmid + cout2)
+    cin_p, cm_p, c2_p = (cin + 7) // 8 * 8, (cmid + 7) // 8 * 8, (cout2 + 7) // 8 * 8
+    x = torch.zeros(B, T, H, W, cin_p)
+    x[..., :cin] = torch.randn(B, T, H, W, cin, generator=g)
+    x = x.to(dtype).cuda()
+    taps = k[0] * k[1] * k[2]
+    wb = (torch.randn((cmid, cin) + k, generator=g) * (cin * taps) ** -0.5).to(dtype)
+    wc = (torch.randn(cout2, cmid, generator=g) * cmid ** -0.5).to(dtype)
+    sb, hb = (torch.rand(cmid, generator=g) + 0.5).cuda(), (torch.rand(cmid, generator=g) - 0.5).cuda()
+    sc, hc = (torch.rand(cout2, generator=g) + 0.5).cuda(), (torch.rand(cout2, generator=g) - 0.5).cuda()
+    mid = F.conv3d(x[..., :cin].float().cpu().permute(0, 4, 1, 2, 3), wb.float(), stride=stride, padding=pad)
+    mid = mid * sb.cpu().view(1, -1, 1, 1, 1) + hb.cpu().view(1, -1, 1, 1, 1)
+    mid = (F.relu(mid) if act_b == L.ACT_RELU else mid).to(dtype).float()
+    To, Ho, Wo = mid.shape[2:]
+    want = torch.einsum("bcthw,oc->bothw", mid, wc.float()) * sc.cpu().view(1, -1, 1, 1, 1) + hc.cpu().view(1, -1, 1, 1, 1)
+    r = None
+    if res:
+        r = torch.zeros(B, To, Ho, Wo, c2_p)
+        r[..., :cout2] = torch.randn(B, To, Ho, Wo, cout2, generator=g)
+        r = r.to(dtype).cuda()
+        want = want + r[..., :cout2].float().cpu().permute(0, 4, 1, 2, 3)
+    want = F.relu(want)
+    wbp = torch.zeros(cmid, taps, cin_p, dtype=dtype)
+    wbp[:, :, :cin] = wb.permute(0, 2, 3, 4, 1).reshape(cmid, -1, cin)
+    wcp = torch.zeros(cout2, cm_p, dtype=dtype)
+    wcp[:, :cmid] = wc
+    wbp, wcp = wbp.cuda(), wcp.cuda()
+
+    def conv_b_desc(y, ld, cout):
+        d = L.Conv3dDesc()
+        d.x, d.w, d.y, d.scale, d.shift = x.data_ptr(), wbp.data_ptr(), y.data_ptr(), sb.data_ptr(), hb.data_ptr()
+        d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * cin_p, To * Ho * Wo * ld, cin_p, ld
+        d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, cin_p, To, Ho, Wo, cout
+        d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, *stride, *pad)
+        d.act, d.a_act, d.dtype = act_b, L.ACT_NONE, L.PV_BF16
+        return d
+
+    # one launch
+    y1 = torch.full((B, To, Ho, Wo, c2_p), 5.0, dtype=dtype, device="cuda")
+    d = conv_b_desc(y1, c2_p, cmid)
+    d.pw2_w, d.pw2_scale, d.pw2_shift, d.pw2_cout, d.pw2_act = wcp.data_ptr(), sc.data_ptr(), hc.data_ptr(), cout2, L.ACT_RELU
+    if res:
+        d.residual, d.r_bs, d.ldr = r.data_ptr(), To * Ho * Wo * c2_p, c2_p
+    assert L.lib().pv_conv3d_pw2_supported(C.byref(d)) == 1
+    call("pv_conv3d", d)
+    assert _routed_kernel(L.OP_CONV3D, d) == "tap_stream_kernel"
+    first = y1.clone()
+    call("pv_conv3d", d)
+    assert torch.equal(first, y1)                       # a second launch gives the same bits
+    # the unfused pair
+    ym = torch.full((B, To, Ho, Wo, cm_p), 5.0, dtype=dtype, device="cuda")
+    call("pv_conv3d", conv_b_desc(ym, cm_p, cmid))
+    y0 = torch.full((B, To, Ho, Wo, c2_p), 5.0, dtype=dtype, device="cuda")
+    e = L.Conv3dDesc()
+    e.x, e.w, e.y, e.scale, e.shift = ym.data_ptr(), wcp.data_ptr(), y0.data_ptr(), sc.data_ptr(), hc.data_ptr()
+    e.x_bs, e.y_bs, e.ldx, e.ldy = To * Ho * Wo * cm_p, To * Ho * Wo * c2_p, cm_p, c2_p
+    e.B, e.Ti, e.Hi, e.Wi, e.cin, e.To, e.Ho, e.Wo, e.cout = B, To, Ho, Wo, cm_p, To, Ho, Wo, cout2
+    e.kt = e.kh = e.kw = e.st = e.sh = e.sw = 1
+    e.act, e.a_act, e.dtype = L.ACT_RELU, L.ACT_NONE, L.PV_BF16
+    if res:
+        e.residual, e.r_bs, e.ldr = r.data_ptr(), To * Ho * Wo * c2_p, c2_p
+    call("pv_conv3d", e)
+    assert rel_err(y1[..., :cout2].permute(0, 4, 1, 2, 3), want) <= 1e-2
+    assert torch.all(y1[..., cout2:] == 0)               # padding channels are written as zeros
+    assert rel_err(y1, y0) <= 4e-3                       # same operands, same roundings; only the summation order differs
+
+
+def test_pointwise_conv_behind_a_conv_is_declined_outside_the_streaming_kernels_range():
+    """pv_conv3d_pw2_supported / pv_conv3d: more than 64 inner channels, a pointwise first conv, fp32 and a residual with other
+    strides than the output are declined (the emitter then keeps the two launches); nothing falls back to another kernel."""
+    def desc(cin=64, cmid=64, cout2=256, k=(1, 3, 3), dtype=L.PV_BF16):
+        d = L.Conv3dDesc()
+        B, T, H, W = 2, 4, 16, 16
+        d.x_bs, d.y_bs, d.ldx, d.ldy = T * H * W * cin, T * H * W * cout2, cin, cout2
+        d.B, d.Ti, d.Hi, d.Wi, d.cin, d.To, d.Ho, d.Wo, d.cout = B, T, H, W, cin, T, H, W, cmid
+        d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = (*k, 1, 1, 1, *(kk // 2 for kk in k))
+        d.dtype, d.pw2_cout = dtype, cout2
+        return d
+    sup = lambda d: L.lib().pv_conv3d_pw2_supported(C.byref(d))
+    assert sup(desc()) == 1
+    assert sup(desc(cmid=128)) == 0
+    assert sup(desc(k=(1, 1, 1))) == 0
+    assert sup(desc(dtype=L.PV_F32)) == 0
+    assert sup(desc(cin=256, k=(3, 3, 3))) == 0          # K = 6912: not a streaming problem
+    d = desc()
+    d.residual, d.r_bs, d.ldr = 1, d.y_bs * 2, d.ldy      # (pointer value irrelevant for the geometry check)
+    assert sup(d) == 0
+    # and the launch itself declines what the check declines
+    x = torch.zeros(2, 4, 16, 16, 64, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(128, 9 * 64, dtype=torch.bfloat16, device="cuda")
+    w2 = torch.zeros(256, 128, dtype=torch.bfloat16, device="cuda")
+    y = torch.zeros(2, 4, 16, 16, 256, dtype=torch.bfloat16, device="cuda")
+    d = desc(cmid=128)
+    d.x, d.w, d.y, d.pw2_w = x.data_ptr(), w.data_ptr(), y.data_ptr(), w2.data_ptr()
+    assert L.lib().pv_conv3d(C.byref(d), None) == L.PV_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("M,Cin,H,Cout,ln,res", [
     (300, 96, 384, 192, False, True),       # MViT-B block 0 (width change: residual = proj(norm2(x)), own launch)
     (50, 96, 384, 96, True, False),         # 96 -> 96 with the LayerNorm in the kernel

@@ -417,3 +417,23 @@ def test_the_oracles_storage_emulation_routes_pools_by_the_emitters_threshold():
     with OF.storage_emulation(pool_stream_min_elems=123):
         assert OF._POOL_STREAM_MIN_ELEMS == 123
     assert OF._POOL_STREAM_MIN_ELEMS == OF.POOL_STREAM_MIN_ELEMS_DEFAULT
+
+
+def test_slowfast_plan_fuses_conv_b_and_conv_c_where_conv_b_is_narrow(monkeypatch):
+    """Round 6 (`pv_conv3d` pw2_*, emit.can_fuse_conv_bc): 13 of SlowFast-R50's bottlenecks -- the fast pathway's 12 blocks without
+    a projection shortcut and block 1 of the slow pathway's res2 -- run conv_b -> conv_c as one launch; first blocks (shortcut folded
+    into conv_c), slow res2's last block (writes into the lateral concat buffer) and the wide slow stages keep two launches.
+    Host half of the conversion only (emit_only): runs without a GPU."""
+    from pytorchvideo_amd.accelerator import convert_to_deployable_form
+    from pytorchvideo_amd.accelerator.mi355x import tuning
+    from pytorchvideo_amd.models import create_slowfast
+
+    def n_ops(flag):
+        monkeypatch.setitem(tuning.OPTIONS, "fuse_bc", flag)
+        m = create_slowfast().eval()
+        transmute_model(m, "mi355x")
+        x = [torch.zeros(1, dtype=torch.bfloat16).expand(2, 3, 8, 256, 256), torch.zeros(1, dtype=torch.bfloat16).expand(2, 3, 32, 256, 256)]
+        return convert_to_deployable_form(m, x, dtype=torch.bfloat16, emit_only=True)["ops"]
+
+    assert tuning.OPTIONS["fuse_bc"] is True
+    assert n_ops(False) - n_ops(True) == 13

@@ -187,7 +187,11 @@ if __name__ == "__main__":
     ap.add_argument("--fills", default="trained_like")
     ap.add_argument("--bench-batch", action="store_true", help="also the bench batch with its stream count, bf16")
     ap.add_argument("--json", default="")
+    ap.add_argument("--tune", default="", help="k=v,k=v: emitter options / library knobs (accelerator/mi355x/tuning.py)")
     a = ap.parse_args()
+    if a.tune:
+        from pytorchvideo_amd.accelerator.mi355x import tuning
+        tuning.apply(a.tune)
     from bench import WORKLOADS
     rows = []
     for w in a.workloads.split(","):
