@@ -437,3 +437,33 @@ def test_slowfast_plan_fuses_conv_b_and_conv_c_where_conv_b_is_narrow(monkeypatc
 
     assert tuning.OPTIONS["fuse_bc"] is True
     assert n_ops(False) - n_ops(True) == 13
+
+
+def test_conv_b_conv_c_fusion_decisions_of_the_emitter():
+    """emit.can_fuse_conv_bc on single bottlenecks (host only; the library's pv_conv3d_pw2_supported decides the geometry)."""
+    from pytorchvideo_amd.models.resnet import create_bottleneck_block
+
+    def block(inner=64, out=256, k=(1, 3, 3), groups=1, stride=(1, 1, 1)):
+        return create_bottleneck_block(dim_in=out, dim_inner=inner, dim_out=out, conv_a_kernel_size=(1, 1, 1), conv_a_stride=(1, 1, 1),
+                                       conv_a_padding=(0, 0, 0), conv_b_kernel_size=k, conv_b_stride=stride,
+                                       conv_b_padding=tuple(kk // 2 for kk in k), conv_b_num_groups=groups).eval()
+
+    def decide(bb, dtype=torch.bfloat16, inner=64, out=256, res_ld=None, with_out=None, shortcut=None, stride=(1, 1, 1)):
+        sess = Session(dtype=dtype)
+        a = sess.alloc_act(2, 4, 16, 16, inner)
+        To, Ho, Wo = 4 // stride[0], 16 // stride[1], 16 // stride[2]
+        r = sess.alloc_act(2, To, Ho, Wo, out, ld=res_ld)
+        o = None if with_out is None else sess.alloc_act(2, To, Ho, Wo, with_out[0], ld=with_out[1]).channel_slice(0, out)
+        return E.can_fuse_conv_bc(sess, bb, a, r, o, shortcut)
+
+    assert decide(block()) is True                                                  # SlowFast / ResNet res2: 64 -> 64 -> 256 + identity
+    assert decide(block(8, 32), inner=8, out=32) is True                            # fast pathway
+    assert decide(block(stride=(1, 2, 2)), stride=(1, 2, 2)) is True                # strided conv_b
+    assert decide(block(), dtype=torch.float32) is False                            # fp32 parity mode: two launches
+    assert decide(block(128, 512), inner=128, out=512) is False                     # 128 inner channels: an MFMA-bound GEMM
+    assert decide(block(64, 256, k=(3, 3, 3))) is False                             # K = 1728: not a streaming problem
+    assert decide(block(64, 256, k=(1, 1, 1))) is False                             # a pointwise pair
+    assert decide(block(64, 256, groups=64)) is False                               # depthwise / grouped conv_b (CSN)
+    assert decide(block(), with_out=(320, 320)) is False                            # output = a slice of the lateral concat buffer:
+    #                                                                                 residual and output strides differ
+    assert decide(block(), shortcut=("conv_s", "norm_s", "x2")) is False            # projection shortcut folded into conv_c
